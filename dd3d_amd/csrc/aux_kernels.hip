@@ -1,0 +1,159 @@
+// Memory-bound helper kernels of the forward path (gfx950): input normalisation + padding,
+// 2x2 max pooling, intrinsics inverse, error plumbing of the C ABI.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace dd3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Norm3 {
+  float mean[3], stdv[3];
+};
+
+// One thread per output pixel: three strided byte reads (each plane is read fully coalesced across the wave), one
+// 16-byte NHWC4 store.  The division is kept (not folded into a multiply) so the value equals torch's (x-mean)/std.
+__global__ __launch_bounds__(256) void preprocess_u8_nhwc4_kernel(const uint8_t* __restrict__ src, const int32_t* __restrict__ sizes,
+                                                                  float* __restrict__ dst, int B, int Hp, int Wp, Norm3 nm) {
+  const long npix = (long)B * Hp * Wp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long t = i / Wp;
+    const int y = (int)(t % Hp);
+    const int b = (int)(t / Hp);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (y < sizes[2 * b] && x < sizes[2 * b + 1]) {
+      const long plane = (long)Hp * Wp;
+      const uint8_t* p = src + (long)b * 3 * plane + (long)y * Wp + x;
+      o[0] = ((float)p[0] - nm.mean[0]) / nm.stdv[0];
+      o[1] = ((float)p[plane] - nm.mean[1]) / nm.stdv[1];
+      o[2] = ((float)p[2 * plane] - nm.mean[2]) / nm.stdv[2];
+    }
+    *reinterpret_cast<f32x4*>(dst + i * 4) = o;
+  }
+}
+
+// thread per (output pixel, 4-channel group)
+__global__ __launch_bounds__(256) void maxpool2x2_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C4,
+                                                              int in_pitch, int out_pitch) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float* p = in + (((long)b * H + 2 * ho) * W + 2 * wo) * in_pitch + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(p + in_pitch);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(p + (long)W * in_pitch);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(p + (long)W * in_pitch + in_pitch);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+    *reinterpret_cast<f32x4*>(out + (((long)b * Ho + ho) * Wo + wo) * out_pitch + c) = o;
+  }
+}
+
+// fine[b, y, x, :] += coarse[b, y/2, x/2, :]   (FPN top-down path: F.interpolate(scale 2, nearest) + add)
+__global__ __launch_bounds__(256) void upsample2x_add_nhwc_kernel(float* __restrict__ fine, const float* __restrict__ coarse, int B, int H, int W,
+                                                                  int C4, int fine_pitch, int coarse_pitch) {
+  const long total = (long)B * H * W * C4;
+  const int Hc = H >> 1, Wc = W >> 1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float* f = fine + (((long)b * H + y) * W + x) * fine_pitch + c;
+    const float* q = coarse + (((long)b * Hc + (y >> 1)) * Wc + (x >> 1)) * coarse_pitch + c;
+    *reinterpret_cast<f32x4*>(f) = *reinterpret_cast<const f32x4*>(f) + *reinterpret_cast<const f32x4*>(q);
+  }
+}
+
+// General 3x3 inverse by cofactors (the reference calls torch.inverse on the stacked intrinsics).
+__global__ void invert3x3_kernel(const float* __restrict__ K, float* __restrict__ invK, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* m = K + 9 * b;
+  const float a = m[0], bb = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
+  const float det = a * A + bb * Bc + c * Cc;
+  const float r = 1.0f / det;
+  float* o = invK + 9 * b;
+  o[0] = A * r;
+  o[1] = -(bb * i - c * h) * r;
+  o[2] = (bb * f - c * e) * r;
+  o[3] = Bc * r;
+  o[4] = (a * i - c * g) * r;
+  o[5] = -(a * f - c * d) * r;
+  o[6] = Cc * r;
+  o[7] = -(a * h - bb * g) * r;
+  o[8] = (a * e - bb * d) * r;
+}
+
+}  // namespace dd3d
+
+extern "C" int dd3d_abi_version(void) { return DD3D_ABI_VERSION; }
+extern "C" const char* dd3d_last_error(void) { return dd3d::g_err; }
+extern "C" const char* dd3d_arch(void) { return "gfx950"; }
+
+extern "C" int dd3d_preprocess_u8_nhwc4(const uint8_t* src, const int32_t* sizes, float* dst, int32_t B, int32_t Hp, int32_t Wp,
+                                        const float mean[3], const float stdv[3], void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(src && sizes && dst && B > 0 && Hp > 0 && Wp > 0, "dd3d_preprocess_u8_nhwc4: bad arguments");
+  Norm3 nm;
+  for (int i = 0; i < 3; ++i) nm.mean[i] = mean[i], nm.stdv[i] = stdv[i];
+  const long npix = (long)B * Hp * Wp;
+  const int grid = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+  hipLaunchKernelGGL(preprocess_u8_nhwc4_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, sizes, dst, B, Hp,
+                     Wp, nm);
+  return check_launch("preprocess_u8_nhwc4_kernel");
+}
+
+extern "C" int dd3d_maxpool2x2_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                                    int32_t out_pitch, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(in && out && B > 0, "dd3d_maxpool2x2_nhwc: bad arguments");
+  DD3D_REQUIRE((H % 2) == 0 && (W % 2) == 0, "dd3d_maxpool2x2_nhwc: H=%d W=%d must be even", H, W);
+  DD3D_REQUIRE((C % 4) == 0 && (in_pitch % 4) == 0 && (out_pitch % 4) == 0, "dd3d_maxpool2x2_nhwc: C / pitches must be multiples of 4");
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(maxpool2x2_nhwc_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, B, H, W, C / 4,
+                     in_pitch, out_pitch);
+  return check_launch("maxpool2x2_nhwc_kernel");
+}
+
+extern "C" int dd3d_upsample2x_add_nhwc(float* fine, const float* coarse, int32_t B, int32_t H, int32_t W, int32_t C, int32_t fine_pitch,
+                                        int32_t coarse_pitch, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(fine && coarse && B > 0, "dd3d_upsample2x_add_nhwc: bad arguments");
+  DD3D_REQUIRE((H % 2) == 0 && (W % 2) == 0, "dd3d_upsample2x_add_nhwc: H=%d W=%d must be even", H, W);
+  DD3D_REQUIRE((C % 4) == 0 && (fine_pitch % 4) == 0 && (coarse_pitch % 4) == 0, "dd3d_upsample2x_add_nhwc: C / pitches must be multiples of 4");
+  const long total = (long)B * H * W * (C / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(upsample2x_add_nhwc_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), fine, coarse, B, H, W, C / 4,
+                     fine_pitch, coarse_pitch);
+  return check_launch("upsample2x_add_nhwc_kernel");
+}
+
+extern "C" int dd3d_invert_intrinsics(const float* K, float* inv_K, int32_t B, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(K && inv_K && B > 0, "dd3d_invert_intrinsics: bad arguments");
+  hipLaunchKernelGGL(invert3x3_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), K, inv_K, B);
+  return check_launch("invert3x3_kernel");
+}

@@ -1,0 +1,599 @@
+// Post-head kernels of the DD3D forward path for gfx950: everything between the head maps and the final detections
+// runs on the device with fixed-capacity buffers and no host synchronisation.
+//
+//   fcos_select_decode_kernel  one 1024-thread block per (level, image): sigmoid score, threshold, ordered compaction
+//                              (= torch.nonzero order), exact top-k by radix select, then the fused per-candidate 2D/3D
+//                              decode (quaternion normalise, depth un-normalise, allocentric->egocentric, size scaling).
+//   nms_sort_kernel            per image: gather levels, stable bitonic sort by score, coordinate-trick offsets.
+//   nms_mask_kernel            64x64 IoU bit-mask tiles (upper triangle).
+//   nms_finalize_kernel        per image: greedy reduce of the mask, top-k on the 2D score, resize/clip/filter, output.
+//
+// These are latency/HBM-bound integer+scalar-float kernels (<= ~150 flop per candidate): no MFMA.
+// Floating-point contraction is off so IoU / score comparisons round like the reference's separate mul/add ops.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace dd3d {
+
+constexpr int PT = 1024;        // threads per block for the per-image / per-level kernels
+constexpr int TOPK_MAX = 1024;  // PRE_NMS_TOPK capacity of the LDS candidate list
+constexpr int NCAP_MAX = 8192;  // max candidates per image (levels * topk) the LDS sorter handles
+constexpr float QEPS = 1e-7f;   // tridet/modeling/dd3d/fcos3d.py:13
+
+// ------------------------------------------------------------------------------------------------ block primitives
+// exclusive prefix sum over the block's 1024 threads; `total` = block sum.  wsum: 16 ints of LDS.  Ends with a barrier.
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < PT / 64; ++w) {
+    const int t = wsum[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  total = tot;
+  return base + x - v;
+}
+
+// in-LDS bitonic sort into "descending key, ascending val on ties" order.  P = power of two.
+__device__ __forceinline__ bool sorts_before(float ka, int va, float kb, int vb) { return ka > kb || (ka == kb && va < vb); }
+
+__device__ void block_bitonic_sort(float* keys, int* vals, int P) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P; i += PT) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float ka = keys[i], kb = keys[ixj];
+          const int va = vals[i], vb = vals[ixj];
+          const bool up = (i & k) == 0;  // this pair must end in sorted order (up) or reversed
+          const bool swap = up ? sorts_before(kb, vb, ka, va) : sorts_before(ka, va, kb, vb);
+          if (swap) {
+            keys[i] = kb, keys[ixj] = ka;
+            vals[i] = vb, vals[ixj] = va;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------ select + decode
+struct SelectK {
+  dd3d_select_args a;
+};
+
+__global__ __launch_bounds__(PT) void fcos_select_decode_kernel(const SelectK P) {
+  const dd3d_select_args& a = P.a;
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int C = a.num_classes;
+  const int H = a.H[l], W = a.W[l], HW = H * W;
+  const int n_el = HW * C;
+  const float* cls = a.cls[l];
+  const float* b2d = a.box2d[l];
+  const float* b3d = a.box3d[l];
+  const long pix0 = (long)b * HW;
+  int32_t* sidx = a.scratch_idx + a.scratch_off[l] + (long)b * a.scratch_img_stride;
+  float* sscore = a.scratch_score + a.scratch_off[l] + (long)b * a.scratch_img_stride;
+
+  __shared__ int wsum[PT / 64];
+  __shared__ int hist[256];
+  __shared__ int sel_e[TOPK_MAX];
+  __shared__ float sel_s[TOPK_MAX];
+  __shared__ int sh_bucket, sh_kk, sh_flag;
+
+  // ---- phase 1: score, threshold, ordered compaction  (fcos2d.py:274-300)
+  int running = 0;
+  for (int base = 0; base < n_el; base += PT) {
+    const int e = base + tid;
+    int pass = 0;
+    float score = 0.f;
+    if (e < n_el) {
+      const int loc = e / C;
+      const int c = e - loc * C;
+      const float sc = sigmoidf(cls[(pix0 + loc) * a.cls_pitch + c]);
+      const float ct = sigmoidf(b2d[(pix0 + loc) * a.b2d_pitch + 4]);
+      score = sc * ct;
+      pass = a.thresh_with_ctr ? (score > a.pre_nms_thresh) : (sc > a.pre_nms_thresh);
+    }
+    int total;
+    const int pos = running + block_excl_scan(pass, wsum, total);
+    if (pass) {
+      sidx[pos] = e;
+      sscore[pos] = score;
+    }
+    running += total;
+  }
+  const int n = running;
+  const int k = min(n, a.topk);
+  if (tid == 0) {
+    a.npass[b * a.num_levels + l] = n;
+    a.counts[b * a.num_levels + l] = k;
+    sh_flag = 0;
+  }
+  __syncthreads();  // scratch writes visible to the whole block
+
+  // ---- phase 2: exact top-k  (fcos2d.py:309-317; order inside the level stays ascending (loc, class))
+  if (n <= k) {
+    if (tid < n) {
+      sel_e[tid] = sidx[tid];
+      sel_s[tid] = sscore[tid];
+    }
+  } else {
+    // radix select of the k-th largest score (scores are positive floats => uint order == float order)
+    unsigned prefix = 0, mask = 0;
+    int kk = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += PT) {
+        const unsigned key = __float_as_uint(sscore[i]);
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int cum = 0, bsel = 0;
+        for (int bkt = 255; bkt >= 0; --bkt) {
+          const int c = hist[bkt];
+          if (cum + c >= kk) {
+            bsel = bkt;
+            break;
+          }
+          cum += c;
+        }
+        sh_bucket = bsel;
+        sh_kk = kk - cum;
+      }
+      __syncthreads();
+      prefix |= (unsigned)sh_bucket << shift;
+      mask |= 0xFFu << shift;
+      kk = sh_kk;
+      __syncthreads();
+    }
+    const unsigned T = prefix;  // key of the k-th largest; take every key > T and the first `kk` keys == T
+    int run_gt = 0, run_eq = 0;
+    for (int base = 0; base < n; base += PT) {
+      const int i = base + tid;
+      int gt = 0, eq = 0, e = 0;
+      float sc = 0.f;
+      if (i < n) {
+        sc = sscore[i];
+        e = sidx[i];
+        const unsigned key = __float_as_uint(sc);
+        gt = key > T;
+        eq = key == T;
+      }
+      int total;
+      const int ex = block_excl_scan(gt | (eq << 16), wsum, total);
+      const int gt_before = run_gt + (ex & 0xFFFF);
+      const int eq_before = run_eq + (ex >> 16);
+      if (gt || (eq && eq_before < kk)) {
+        const int pos = gt_before + min(eq_before, kk);
+        sel_e[pos] = e;
+        sel_s[pos] = sc;
+      }
+      run_gt += total & 0xFFFF;
+      run_eq += total >> 16;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: decode  (fcos2d.py:319-336, fcos3d.py:343-399, fcos3d.py:16-52, geometry.py:15-55)
+  const int NS = a.num_levels * a.topk;
+  float* cand = a.cand + (long)b * DD3D_CAND_FIELDS * NS + l * a.topk;
+  float q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 1.f;
+  int bad = 0;
+  const bool active = tid < k;
+  if (active) {
+    const int e = sel_e[tid];
+    const float s_in = sel_s[tid];
+    const int loc = e / C;
+    const int c = e - loc * C;
+    const int stride = a.stride[l];
+    const float off = a.loc_offset_half ? (float)(stride / 2) : 0.f;
+    const float lx = (float)((loc % W) * stride) + off;  // tensor2d.py:6-25
+    const float ly = (float)((loc / W) * stride) + off;
+    const float* r = b2d + (pix0 + loc) * a.b2d_pitch;
+    cand[0 * NS + tid] = lx - r[0];
+    cand[1 * NS + tid] = ly - r[1];
+    cand[2 * NS + tid] = lx + r[2];
+    cand[3 * NS + tid] = ly + r[3];
+    const float score = sqrtf(s_in);  // fcos2d.py:333
+    cand[4 * NS + tid] = score;
+    cand[6 * NS + tid] = __int_as_float(c);
+    cand[7 * NS + tid] = __int_as_float(e);
+    cand[8 * NS + tid] = lx;
+    cand[9 * NS + tid] = ly;
+    if (b3d == nullptr) {
+      cand[5 * NS + tid] = score;
+      for (int f = 10; f < DD3D_CAND_FIELDS; ++f) cand[f * NS + tid] = 0.f;
+    } else {
+      const int C3 = a.class_agnostic_3d ? 1 : C;
+      const int c3 = a.class_agnostic_3d ? 0 : c;
+      const float* p = b3d + (pix0 + loc) * a.b3d_pitch;  // channel = component * C3 + class  (fcos3d.py:335-339)
+      float qa = p[0 * C3 + c3], qb = p[1 * C3 + c3], qc = p[2 * C3 + c3], qd = p[3 * C3 + c3];
+      float cx = p[4 * C3 + c3], cy = p[5 * C3 + c3];
+      float depth = p[6 * C3 + c3];
+      const float s0 = p[7 * C3 + c3], s1 = p[8 * C3 + c3], s2 = p[9 * C3 + c3];
+      const float conf = sigmoidf(p[10 * C3 + c3]);
+      cand[5 * NS + tid] = score * conf;  // scores_3d, fcos3d.py:375-376
+      const float* K = a.inv_K + 9 * b;
+      // quat / max(|quat|, eps), then / |quat| again  (fcos3d.py:31-34)
+      float nrm = fmaxf(sqrtf(qa * qa + qb * qb + qc * qc + qd * qd), QEPS);
+      qa /= nrm, qb /= nrm, qc /= nrm, qd /= nrm;
+      nrm = sqrtf(qa * qa + qb * qb + qc * qc + qd * qd);
+      qa /= nrm, qb /= nrm, qc /= nrm, qd /= nrm;
+      if (a.scale_depth_by_focal) {  // fcos3d.py:36-38
+        const float pixel_size = sqrtf(K[0] * K[0] + K[4] * K[4]);
+        depth = depth / (pixel_size * a.focal_factor);
+      }
+      if (a.depth_is_distance) {  // fcos3d.py:40-41, ray through the *location*
+        const float rx = K[0] * lx + K[1] * ly + K[2], ry = K[3] * lx + K[4] * ly + K[5], rz = K[6] * lx + K[7] * ly + K[8];
+        depth = depth / fmaxf(sqrtf(rx * rx + ry * ry + rz * rz), QEPS);
+      }
+      depth = fminf(fmaxf(depth, a.min_depth), a.max_depth);
+      cx += lx, cy += ly;  // proj_ctr + locations
+      if (a.allocentric) {
+        // R_obj_to_local = M(q)  ([ext] pytorch3d quaternion_to_matrix)
+        const float two_s = 2.0f / (qa * qa + qb * qb + qc * qc + qd * qd);
+        const float o00 = 1 - two_s * (qc * qc + qd * qd), o01 = two_s * (qb * qc - qd * qa), o02 = two_s * (qb * qd + qc * qa);
+        const float o10 = two_s * (qb * qc + qd * qa), o11 = 1 - two_s * (qb * qb + qd * qd), o12 = two_s * (qc * qd - qb * qa);
+        const float o20 = two_s * (qb * qd - qc * qa), o21 = two_s * (qc * qd + qb * qa), o22 = 1 - two_s * (qb * qb + qc * qc);
+        // local frame from the viewing ray through proj_ctr  (geometry.py:30-41)
+        float zx = K[0] * cx + K[1] * cy + K[2], zy = K[3] * cx + K[4] * cy + K[5], zz = K[6] * cx + K[7] * cy + K[8];
+        const float zn = sqrtf(zx * zx + zy * zy + zz * zz);
+        zx /= zn, zy /= zn, zz /= zn;
+        float yx = 0.f - zy * zx, yy = 1.f - zy * zy, yz = 0.f - zy * zz;
+        const float yn = sqrtf(yx * yx + yy * yy + yz * yz);
+        yx /= yn, yy /= yn, yz /= yn;
+        const float xx = yy * zz - yz * zy, xy = yz * zx - yx * zz, xz = yx * zy - yy * zx;  // cross(y, z)
+        // R = [x y z] (columns) * R_obj
+        const float m00 = xx * o00 + yx * o10 + zx * o20, m01 = xx * o01 + yx * o11 + zx * o21, m02 = xx * o02 + yx * o12 + zx * o22;
+        const float m10 = xy * o00 + yy * o10 + zy * o20, m11 = xy * o01 + yy * o11 + zy * o21, m12 = xy * o02 + yy * o12 + zy * o22;
+        const float m20 = xz * o00 + yz * o10 + zz * o20, m21 = xz * o01 + yz * o11 + zz * o21, m22 = xz * o02 + yz * o12 + zz * o22;
+        // [ext] pytorch3d matrix_to_quaternion (0.5.x/0.6.x): candidate of the largest |component|, no sign canonicalisation
+        const float t0 = 1.f + m00 + m11 + m22, t1 = 1.f + m00 - m11 - m22, t2 = 1.f - m00 + m11 - m22, t3 = 1.f - m00 - m11 + m22;
+        const float a0 = t0 > 0.f ? sqrtf(t0) : 0.f, a1 = t1 > 0.f ? sqrtf(t1) : 0.f;
+        const float a2 = t2 > 0.f ? sqrtf(t2) : 0.f, a3 = t3 > 0.f ? sqrtf(t3) : 0.f;
+        int best = 0;
+        float am = a0;
+        if (a1 > am) best = 1, am = a1;
+        if (a2 > am) best = 2, am = a2;
+        if (a3 > am) best = 3, am = a3;
+        const float den = 2.0f * fmaxf(am, 0.1f);
+        if (best == 0) q0 = a0 * a0, q1 = m21 - m12, q2 = m02 - m20, q3 = m10 - m01;
+        else if (best == 1) q0 = m21 - m12, q1 = a1 * a1, q2 = m10 + m01, q3 = m02 + m20;
+        else if (best == 2) q0 = m02 - m20, q1 = m10 + m01, q2 = a2 * a2, q3 = m12 + m21;
+        else q0 = m10 - m01, q1 = m20 + m02, q2 = m21 + m12, q3 = a3 * a3;
+        q0 /= den, q1 /= den, q2 /= den, q3 /= den;
+        qn = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+        bad = !(fabsf(qn - 1.0f) <= 1e-3f + 1e-5f);  // torch.allclose(qn, 1, atol=1e-3) with the default rtol
+      } else {
+        q0 = qa, q1 = qb, q2 = qc, q3 = qd;
+      }
+      const float* cs = a.canon_sizes + 3 * c;
+      cand[14 * NS + tid] = cx;
+      cand[15 * NS + tid] = cy;
+      cand[16 * NS + tid] = depth;
+      cand[17 * NS + tid] = (tanhf(s0) + 1.0f) * cs[0];
+      cand[18 * NS + tid] = (tanhf(s1) + 1.0f) * cs[1];
+      cand[19 * NS + tid] = (tanhf(s2) + 1.0f) * cs[2];
+    }
+  }
+  if (b3d != nullptr) {
+    // the renormalisation is triggered for the whole (level, image) batch if ANY norm is off (geometry.py:48-53)
+    if (bad) atomicOr(&sh_flag, 1);
+    __syncthreads();
+    if (active) {
+      if (sh_flag) {
+        const float d = fmaxf(qn, QEPS);
+        q0 /= d, q1 /= d, q2 /= d, q3 /= d;
+      }
+      cand[10 * NS + tid] = q0;
+      cand[11 * NS + tid] = q1;
+      cand[12 * NS + tid] = q2;
+      cand[13 * NS + tid] = q3;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ NMS
+struct NmsK {
+  dd3d_nms_args a;
+  int ncap;   // round_up(levels*topk, 64)
+  int ncap2;  // next power of two >= levels*topk (size of the LDS sort arrays)
+};
+
+// mode written to nvalid[g][1]
+enum { NMS_TRICK = 0, NMS_PER_CLASS = 1, NMS_NONE = 2 };
+
+__global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
+  const dd3d_nms_args& a = P.a;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int L = a.num_levels, NS = L * a.topk;
+  const float* cand = a.cand + (long)g * DD3D_CAND_FIELDS * NS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // keys[ncap2] | vals[ncap2]
+  float* keys = reinterpret_cast<float*>(dyn_lds);
+  int* vals = reinterpret_cast<int*>(dyn_lds) + P.ncap2;
+  __shared__ int pref[DD3D_MAX_LEVELS + 1];
+  __shared__ float red[PT / 64];
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < L; ++l) {
+      pref[l] = acc;
+      acc += a.counts[g * L + l];
+    }
+    pref[L] = acc;
+  }
+  __syncthreads();
+  const int n = pref[L];
+  const bool suppress = a.do_nms && a.nms_thresh > 0.f;
+  int Pn = 1;
+  while (Pn < n) Pn <<= 1;
+  const float* key_src = cand + (a.use_score3d ? 5 : 4) * NS;
+  float mx = -INFINITY;
+  for (int i = tid; i < Pn; i += PT) {
+    float key = -INFINITY;
+    int val = 0x7fffffff;
+    if (i < n) {
+      int l = 0;
+      while (l + 1 < L && i >= pref[l + 1]) ++l;
+      const int slot = l * a.topk + (i - pref[l]);
+      key = key_src[slot];
+      val = slot;  // slots grow with the concatenated (level-major) index => ties keep the Instances.cat order
+      mx = fmaxf(mx, fmaxf(fmaxf(cand[0 * NS + slot], cand[1 * NS + slot]), fmaxf(cand[2 * NS + slot], cand[3 * NS + slot])));
+    }
+    keys[i] = key;
+    vals[i] = val;
+  }
+  // boxes.max() for the coordinate trick
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < PT / 64; ++w) mx = fmaxf(mx, red[w]);
+  if (suppress) block_bitonic_sort(keys, vals, Pn);
+  __syncthreads();
+  const int mode = !suppress ? NMS_NONE : (4 * n > 4000 ? NMS_PER_CLASS : NMS_TRICK);  // torchvision 0.10 batched_nms
+  if (tid == 0) {
+    a.nvalid[2 * g] = n;
+    a.nvalid[2 * g + 1] = mode;
+  }
+  const float off_unit = mx + 1.0f;
+  for (int p = tid; p < n; p += PT) {
+    const int slot = vals[p];
+    const int c = __float_as_int(cand[6 * NS + slot]);
+    const float off = mode == NMS_TRICK ? (float)c * off_unit : 0.f;
+    a.sort_idx[(long)g * P.ncap + p] = slot;
+    a.scls[(long)g * P.ncap + p] = c;
+    float* sb = a.sbox + ((long)g * P.ncap + p) * 4;
+    sb[0] = cand[0 * NS + slot] + off;
+    sb[1] = cand[1 * NS + slot] + off;
+    sb[2] = cand[2 * NS + slot] + off;
+    sb[3] = cand[3 * NS + slot] + off;
+  }
+}
+
+// [ext] torchvision nms_kernel: bit j of mask[i][cb] = (cb*64+j > i) && IoU(i, cb*64+j) > thr
+__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsK P) {
+  const dd3d_nms_args& a = P.a;
+  const int g = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x, lane = threadIdx.x;
+  const int n = a.nvalid[2 * g], mode = a.nvalid[2 * g + 1];
+  if (mode == NMS_NONE || cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+  __shared__ float cbox[64][4];
+  __shared__ int ccls[64];
+  const float* sbox = a.sbox + (long)g * P.ncap * 4;
+  const int* scls = a.scls + (long)g * P.ncap;
+  const int cj = cb * 64 + lane;
+  if (cj < n) {
+    cbox[lane][0] = sbox[cj * 4 + 0], cbox[lane][1] = sbox[cj * 4 + 1];
+    cbox[lane][2] = sbox[cj * 4 + 2], cbox[lane][3] = sbox[cj * 4 + 3];
+    ccls[lane] = scls[cj];
+  }
+  __syncthreads();
+  const int i = rb * 64 + lane;
+  if (i >= n) return;
+  const float ax1 = sbox[i * 4 + 0], ay1 = sbox[i * 4 + 1], ax2 = sbox[i * 4 + 2], ay2 = sbox[i * 4 + 3];
+  const int ac = scls[i];
+  const float sa = (ax2 - ax1) * (ay2 - ay1);
+  unsigned long long bits = 0;
+  const int jmax = min(64, n - cb * 64);
+  for (int j = 0; j < jmax; ++j) {
+    const int col = cb * 64 + j;
+    if (col <= i) continue;
+    if (mode == NMS_PER_CLASS && ccls[j] != ac) continue;
+    const float left = fmaxf(ax1, cbox[j][0]), right = fminf(ax2, cbox[j][2]);
+    const float top = fmaxf(ay1, cbox[j][1]), bottom = fminf(ay2, cbox[j][3]);
+    const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+    const float inter = w * h;
+    const float sb = (cbox[j][2] - cbox[j][0]) * (cbox[j][3] - cbox[j][1]);
+    if (inter / (sa + sb - inter) > a.nms_thresh) bits |= 1ull << j;
+  }
+  a.mask[((long)g * P.ncap + i) * (P.ncap / 64) + cb] = bits;
+}
+
+__global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
+  const dd3d_nms_args& a = P.a;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int L = a.num_levels, NS = L * a.topk;
+  const float* cand = a.cand + (long)g * DD3D_CAND_FIELDS * NS;
+  const int n = a.nvalid[2 * g], mode = a.nvalid[2 * g + 1];
+  const int* sort_idx = a.sort_idx + (long)g * P.ncap;
+  const int nw = P.ncap / 64;
+  const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(a.mask) + (long)g * P.ncap * nw;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // removed | kept | tkeys | tvals
+  unsigned long long* removed = reinterpret_cast<unsigned long long*>(dyn_lds);  // [NCAP_MAX/64]
+  int* kept = reinterpret_cast<int*>(removed + NCAP_MAX / 64);  // [ncap2] sorted positions that survive NMS, in order
+  float* tkeys = reinterpret_cast<float*>(kept + P.ncap2);      // [ncap2] scratch for the top-k threshold
+  int* tvals = reinterpret_cast<int*>(tkeys + P.ncap2);         // [ncap2]
+  __shared__ int wsum[PT / 64];
+  __shared__ unsigned long long sh_keepbits;
+  __shared__ int sh_nkeep;
+  __shared__ float sh_thr;
+
+  int nkeep = 0;
+  if (mode == NMS_NONE) {
+    for (int i = tid; i < n; i += PT) kept[i] = i;
+    nkeep = n;
+    __syncthreads();
+  } else {
+    const int nwords = (n + 63) / 64;
+    for (int i = tid; i < NCAP_MAX / 64; i += PT) removed[i] = 0;
+    if (tid == 0) sh_nkeep = 0;
+    __syncthreads();
+    for (int rb = 0; rb < nwords; ++rb) {
+      if (tid < 64) {  // wave 0: resolve the 64 candidates of this block row sequentially (diagonal word only)
+        const int i = rb * 64 + tid;
+        const unsigned long long diag = i < n ? mask[(long)i * nw + rb] : 0ull;
+        unsigned long long rem = removed[rb];
+        unsigned long long keepbits = 0;
+        const int lim = min(64, n - rb * 64);
+        for (int j = 0; j < lim; ++j) {
+          const unsigned long long dj = __shfl(diag, j, 64);
+          if (!((rem >> j) & 1ull)) {
+            keepbits |= 1ull << j;
+            rem |= dj;
+          }
+        }
+        if (tid == 0) sh_keepbits = keepbits;
+        // append the kept positions in order
+        const int base = sh_nkeep;
+        if ((keepbits >> tid) & 1ull) kept[base + __popcll(keepbits & ((1ull << tid) - 1ull))] = i;
+        if (tid == 0) sh_nkeep = base + __popcll(keepbits);
+      }
+      __syncthreads();
+      // everyone: OR the kept rows into the removed bitmap of the later column words
+      const unsigned long long kb = sh_keepbits;
+      for (int cw = rb + 1 + tid; cw < nwords; cw += PT) {
+        unsigned long long acc = removed[cw];
+        unsigned long long bitsleft = kb;
+        while (bitsleft) {
+          const int j = __ffsll((long long)bitsleft) - 1;
+          bitsleft &= bitsleft - 1;
+          acc |= mask[(long)(rb * 64 + j) * nw + cw];
+        }
+        removed[cw] = acc;
+      }
+      __syncthreads();
+    }
+    nkeep = sh_nkeep;
+  }
+
+  // ---- top-k on the 2D score with >= (fcos2d.py:359-365).  kthvalue(n-k+1 smallest) == k-th largest.
+  const float* score2d = cand + 4 * NS;
+  float thr = -INFINITY;
+  if (a.do_nms && a.post_topk > 0 && nkeep > a.post_topk) {
+    int Pn = 1;
+    while (Pn < nkeep) Pn <<= 1;
+    for (int i = tid; i < Pn; i += PT) {
+      tkeys[i] = i < nkeep ? score2d[sort_idx[kept[i]]] : -INFINITY;
+      tvals[i] = i;
+    }
+    __syncthreads();
+    block_bitonic_sort(tkeys, tvals, Pn);
+    if (tid == 0) sh_thr = tkeys[a.post_topk - 1];
+    __syncthreads();
+    thr = sh_thr;
+  }
+
+  // ---- resize / clip / drop empty ([ext] detector_postprocess) + ordered write-out
+  const float* osz = a.out_size + 4 * g;
+  const float in_h = osz[0], in_w = osz[1], out_h = osz[2], out_w = osz[3];
+  const float sx = out_w / in_w, sy = out_h / in_h;
+  float* det = a.det + (long)g * a.det_cap * DD3D_DET_FIELDS;
+  int running = 0;
+  for (int base = 0; base < nkeep; base += PT) {
+    const int i = base + tid;
+    int pass = 0, slot = 0;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    if (i < nkeep) {
+      slot = sort_idx[kept[i]];
+      pass = score2d[slot] >= thr;
+      x1 = cand[0 * NS + slot], y1 = cand[1 * NS + slot], x2 = cand[2 * NS + slot], y2 = cand[3 * NS + slot];
+      if (a.do_postprocess) {
+        x1 = fminf(fmaxf(x1 * sx, 0.f), out_w), x2 = fminf(fmaxf(x2 * sx, 0.f), out_w);
+        y1 = fminf(fmaxf(y1 * sy, 0.f), out_h), y2 = fminf(fmaxf(y2 * sy, 0.f), out_h);
+        pass = pass && (x2 - x1) > 0.f && (y2 - y1) > 0.f;
+      }
+    }
+    int total;
+    const int pos = running + block_excl_scan(pass, wsum, total);
+    if (pass && pos < a.det_cap) {
+      float* d = det + (long)pos * DD3D_DET_FIELDS;
+      d[0] = x1, d[1] = y1, d[2] = x2, d[3] = y2;
+      d[4] = cand[4 * NS + slot];
+      d[5] = cand[5 * NS + slot];
+      d[6] = (float)__float_as_int(cand[6 * NS + slot]);
+      d[7] = (float)(slot / a.topk);
+#pragma unroll
+      for (int f = 8; f < DD3D_DET_FIELDS; ++f) d[f] = cand[f * NS + slot];
+    }
+    running += total;
+  }
+  if (tid == 0) a.det_count[g] = running;
+}
+
+}  // namespace dd3d
+
+extern "C" int dd3d_fcos_select_decode(const dd3d_select_args* args, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(args, "dd3d_fcos_select_decode: null args");
+  DD3D_REQUIRE(args->num_levels > 0 && args->num_levels <= DD3D_MAX_LEVELS, "dd3d_fcos_select_decode: num_levels=%d", args->num_levels);
+  DD3D_REQUIRE(args->topk > 0 && args->topk <= TOPK_MAX, "dd3d_fcos_select_decode: topk=%d exceeds %d", args->topk, TOPK_MAX);
+  DD3D_REQUIRE(args->B > 0 && args->num_classes > 0, "dd3d_fcos_select_decode: B=%d classes=%d", args->B, args->num_classes);
+  DD3D_REQUIRE(args->cand && args->counts && args->npass && args->scratch_idx && args->scratch_score, "dd3d_fcos_select_decode: null buffer");
+  for (int l = 0; l < args->num_levels; ++l) DD3D_REQUIRE(args->cls[l] && args->box2d[l], "dd3d_fcos_select_decode: null head map at level %d", l);
+  DD3D_REQUIRE(args->box3d[0] == nullptr || (args->inv_K && args->canon_sizes), "dd3d_fcos_select_decode: 3D decode needs inv_K and canon_sizes");
+  SelectK P;
+  P.a = *args;
+  hipLaunchKernelGGL(fcos_select_decode_kernel, dim3(args->num_levels, args->B), dim3(PT), 0, reinterpret_cast<hipStream_t>(stream), P);
+  return check_launch("fcos_select_decode_kernel");
+}
+
+extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(args, "dd3d_nms_finalize: null args");
+  const int ns = args->num_levels * args->topk;
+  DD3D_REQUIRE(args->G > 0 && ns > 0 && ns <= NCAP_MAX, "dd3d_nms_finalize: levels*topk=%d exceeds %d", ns, NCAP_MAX);
+  DD3D_REQUIRE(args->cand && args->counts && args->out_size && args->sort_idx && args->sbox && args->scls && args->mask && args->nvalid &&
+                   args->det && args->det_count,
+               "dd3d_nms_finalize: null buffer");
+  DD3D_REQUIRE(args->det_cap > 0, "dd3d_nms_finalize: det_cap=%d", args->det_cap);
+  NmsK P;
+  P.a = *args;
+  P.ncap = (ns + 63) / 64 * 64;
+  P.ncap2 = 64;
+  while (P.ncap2 < ns) P.ncap2 <<= 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t lds_sort = (size_t)P.ncap2 * 8;
+  const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 12;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NCAP_MAX / 64 * 8 + NCAP_MAX * 12);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(args->G), dim3(PT), lds_sort, st, P);
+  int rc = check_launch("nms_sort_kernel");
+  if (rc != DD3D_OK) return rc;
+  const int nb = P.ncap / 64;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, args->G), dim3(64), 0, st, P);
+  rc = check_launch("nms_mask_kernel");
+  if (rc != DD3D_OK) return rc;
+  hipLaunchKernelGGL(nms_finalize_kernel, dim3(args->G), dim3(PT), lds_fin, st, P);
+  return check_launch("nms_finalize_kernel");
+}

@@ -1,0 +1,123 @@
+"""ctypes binding of libdd3d_hip.so (C ABI declared in include/dd3d_hip.h).
+
+The library is the ONLY compute path of this package: importing ``lib()`` raises if the shared object
+has not been built (``python -c "import __graft_entry__ as g; g.build()"``) -- there is no eager / CPU
+fallback anywhere in ``dd3d_amd``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(__file__), "lib", "libdd3d_hip.so")
+_lib = None
+
+MAX_LEVELS = 8
+CAND_FIELDS = 20
+DET_FIELDS = 20
+
+TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_64x128 = 0, 1, 2, 3, 4
+TILE_SHAPES = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_128x32: (128, 32),
+               TILE_64x128: (64, 128)}
+
+# numpy mirror of `dd3d_conv_seg` (120 bytes) -- arrays of it are uploaded to the device as raw bytes.
+CONV_SEG_DTYPE = np.dtype(
+    [("in_", "<u8"), ("w", "<u8"), ("scale", "<u8"), ("bias", "<u8"), ("lo", "<u8"), ("res", "<u8"), ("out", "<u8"),
+     ("B", "<i4"), ("H", "<i4"), ("W", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"), ("in_pitch", "<i4"), ("out_pitch", "<i4"),
+     ("res_pitch", "<i4"), ("M", "<i4"), ("res_mode", "<i4"), ("reserved0", "<i4", (2, )), ("ws_row0", "<i4"),
+     ("reserved", "<i4", (3, ))]
+)
+assert CONV_SEG_DTYPE.itemsize == 120
+
+
+class ConvLaunch(C.Structure):
+    """`dd3d_conv_launch`."""
+    _fields_ = [
+        ("segs", C.c_void_p), ("tiles", C.c_void_p), ("workspace", C.c_void_p), ("nsegs", C.c_int32), ("ntiles", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("Cin", C.c_int32), ("N", C.c_int32),
+        ("Kpad", C.c_int32), ("Npad", C.c_int32), ("relu", C.c_int32), ("splitk", C.c_int32), ("ws_rows", C.c_int32),
+        ("tile_cfg", C.c_int32)
+    ]
+
+
+class SelectArgs(C.Structure):
+    """`dd3d_select_args`."""
+    _fields_ = [
+        ("cls", C.c_void_p * MAX_LEVELS), ("box2d", C.c_void_p * MAX_LEVELS), ("box3d", C.c_void_p * MAX_LEVELS),
+        ("H", C.c_int32 * MAX_LEVELS), ("W", C.c_int32 * MAX_LEVELS), ("stride", C.c_int32 * MAX_LEVELS),
+        ("cls_pitch", C.c_int32), ("b2d_pitch", C.c_int32), ("b3d_pitch", C.c_int32), ("num_levels", C.c_int32),
+        ("B", C.c_int32), ("num_classes", C.c_int32), ("class_agnostic_3d", C.c_int32), ("loc_offset_half", C.c_int32),
+        ("thresh_with_ctr", C.c_int32), ("topk", C.c_int32), ("pre_nms_thresh", C.c_float), ("min_depth", C.c_float),
+        ("max_depth", C.c_float), ("focal_factor", C.c_float), ("scale_depth_by_focal", C.c_int32), ("allocentric", C.c_int32),
+        ("depth_is_distance", C.c_int32), ("inv_K", C.c_void_p), ("canon_sizes", C.c_void_p), ("scratch_idx", C.c_void_p),
+        ("scratch_score", C.c_void_p), ("scratch_off", C.c_int64 * MAX_LEVELS), ("scratch_img_stride", C.c_int64),
+        ("cand", C.c_void_p), ("counts", C.c_void_p), ("npass", C.c_void_p)
+    ]
+
+
+class NmsArgs(C.Structure):
+    """`dd3d_nms_args`."""
+    _fields_ = [
+        ("cand", C.c_void_p), ("counts", C.c_void_p), ("G", C.c_int32), ("num_levels", C.c_int32), ("topk", C.c_int32),
+        ("do_nms", C.c_int32), ("use_score3d", C.c_int32), ("nms_thresh", C.c_float), ("post_topk", C.c_int32),
+        ("do_postprocess", C.c_int32), ("out_size", C.c_void_p), ("sort_idx", C.c_void_p), ("sbox", C.c_void_p),
+        ("scls", C.c_void_p), ("mask", C.c_void_p), ("nvalid", C.c_void_p), ("det", C.c_void_p), ("det_count", C.c_void_p),
+        ("det_cap", C.c_int32)
+    ]
+
+
+EXPORTS = [
+    "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
+    "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
+    "dd3d_invert_intrinsics", "dd3d_nms_finalize"
+]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises HipLibraryMissing if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryMissing(
+            f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "dd3d_amd has no CPU / eager fallback."
+        )
+    L = C.CDLL(_LIB_PATH)
+    L.dd3d_abi_version.restype = C.c_int
+    L.dd3d_last_error.restype = C.c_char_p
+    L.dd3d_arch.restype = C.c_char_p
+    L.dd3d_conv_tile_shape.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.dd3d_conv2d_igemm_f32.argtypes = [C.POINTER(ConvLaunch), C.c_void_p]
+    L.dd3d_preprocess_u8_nhwc4.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+        C.c_void_p
+    ]
+    L.dd3d_maxpool2x2_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    L.dd3d_upsample2x_add_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    L.dd3d_fcos_select_decode.argtypes = [C.POINTER(SelectArgs), C.c_void_p]
+    L.dd3d_invert_intrinsics.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.dd3d_nms_finalize.argtypes = [C.POINTER(NmsArgs), C.c_void_p]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError if the .so is stale
+    assert L.dd3d_abi_version() == 1, "libdd3d_hip.so ABI version mismatch; rebuild"
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"libdd3d_hip {what} failed (rc={rc}): {lib().dd3d_last_error().decode()}")
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

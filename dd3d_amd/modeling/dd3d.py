@@ -1,0 +1,171 @@
+"""``DD3D`` meta-architecture: the drop-in boundary of the forward path.
+
+Same registered name, constructor signature ``(cfg)``, attributes and call contract as
+tridet/modeling/dd3d/core.py:18-175:  ``model(batched_inputs: List[dict]) -> List[{"instances": Instances}]``.
+Only the inference branch exists here (training is out of scope); everything from the
+uint8 image to the final detections runs in the HIP engine (dd3d_amd.engine) on the model's device.
+"""
+import torch
+from torch import nn
+
+from dd3d_amd.engine import ForwardPlan
+from dd3d_amd.modeling.heads import FCOS2DHead, FCOS3DHead
+from dd3d_amd.registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY
+from dd3d_amd.structures import Boxes, Boxes3D, Instances, ShapeSpec
+
+
+def build_feature_extractor(cfg, input_shape=None):
+    """tridet/modeling/feature_extractor/__init__.py:13-26."""
+    if input_shape is None:
+        input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
+    return BACKBONE_REGISTRY.get(cfg.FE.BUILDER)(cfg, input_shape)
+
+
+@META_ARCH_REGISTRY.register()
+class DD3D(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = build_feature_extractor(cfg)
+        backbone_output_shape = self.backbone.output_shape()
+        self.in_features = cfg.DD3D.IN_FEATURES or list(backbone_output_shape.keys())
+        self.backbone_output_shape = [backbone_output_shape[f] for f in self.in_features]
+        if list(self.in_features) != list(backbone_output_shape.keys()):
+            raise NotImplementedError("DD3D.IN_FEATURES must select every FPN output (all reference configs do)")
+        self.feature_locations_offset = cfg.DD3D.FEATURE_LOCATIONS_OFFSET
+
+        self.fcos2d_head = FCOS2DHead(cfg, self.backbone_output_shape)
+        if cfg.MODEL.BOX3D_ON:
+            self.fcos3d_head = FCOS3DHead(cfg, self.backbone_output_shape)
+            self.only_box2d = False
+        else:
+            self.only_box2d = True
+
+        self.postprocess_in_inference = cfg.DD3D.INFERENCE.DO_POSTPROCESS
+        self.do_nms = cfg.DD3D.INFERENCE.DO_NMS
+        self.do_bev_nms = cfg.DD3D.INFERENCE.DO_BEV_NMS
+        self.bev_nms_iou_thresh = cfg.DD3D.INFERENCE.BEV_NMS_IOU_THRESH
+        self.nusc_sample_aggregate_in_inference = cfg.DD3D.INFERENCE.NUSC_SAMPLE_AGGREGATE
+        self.num_classes = cfg.DD3D.NUM_CLASSES
+
+        self.register_buffer("pixel_mean", torch.Tensor(list(cfg.MODEL.PIXEL_MEAN)).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.Tensor(list(cfg.MODEL.PIXEL_STD)).view(-1, 1, 1))
+        self._plans = {}
+        self.use_graph = True
+        self.training = False
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("dd3d_amd implements the inference forward path only")
+        return super().train(False)
+
+    # ------------------------------------------------------------------ plan management
+    def invalidate_plans(self):
+        """Call after changing weights in place (plans hold packed copies of the weights)."""
+        self._plans = {}
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_plans()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._plans = {}
+        return r
+
+    def _sync_flags(self):
+        """`do_test` / TTA flip these attributes on the instance (scripts/train.py:206-209,268-272); mirror them
+        into the config the plan is built from."""
+        inf = self.cfg.DD3D.INFERENCE
+        inf.DO_POSTPROCESS, inf.DO_NMS = bool(self.postprocess_in_inference), bool(self.do_nms)
+        return (bool(self.postprocess_in_inference), bool(self.do_nms), bool(self.do_bev_nms))
+
+    def get_plan(self, B, Hp, Wp, world_size=1):
+        key = (B, Hp, Wp, world_size) + self._sync_flags()
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size)
+            if self.use_graph and world_size == 1:
+                plan.capture()
+            self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ host side of forward
+    def stage_inputs(self, batched_inputs, plan=None):
+        """core.py:65-72: gather images/intrinsics; the padded canvas geometry is ImageList.from_tensors'
+        (image_list.py:120-142).  Returns (plan, image_sizes)."""
+        images = [x["image"] for x in batched_inputs]
+        image_sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        div = self.backbone.size_divisibility
+        H = max(s[0] for s in image_sizes)
+        W = max(s[1] for s in image_sizes)
+        if div > 1:
+            H, W = (H + div - 1) // div * div, (W + div - 1) // div * div
+        B = len(images)
+        if "intrinsics" not in batched_inputs[0]:
+            if not self.only_box2d:
+                raise ValueError("DD3D with BOX3D_ON needs 'intrinsics' in every input dict")
+            K = torch.eye(3).repeat(B, 1, 1) * 2.0
+        else:
+            K = torch.stack([x["intrinsics"].float().cpu() for x in batched_inputs], 0)
+            if torch.allclose(K[0], torch.eye(3)):
+                raise ValueError("Intrinsics is Identity.")  # image_list.py:57-62
+        if plan is None:
+            plan = self.get_plan(B, H, W)
+        for i, im in enumerate(images):
+            assert im.dtype == torch.uint8 and im.shape[0] == 3, "expected uint8 (3,H,W) images (dataset_mapper.py:127)"
+            plan.in_u8[i, :, :im.shape[1], :im.shape[2]].copy_(im, non_blocking=True)
+        sizes = torch.tensor(image_sizes, dtype=torch.int32)
+        outsz = torch.tensor(
+            [[s[0], s[1], x.get("height", s[0]), x.get("width", s[1])] for s, x in zip(image_sizes, batched_inputs)],
+            dtype=torch.float32
+        )
+        plan.in_sizes.copy_(sizes, non_blocking=True)
+        plan.in_K.copy_(K.reshape(B, 9), non_blocking=True)
+        plan.in_outsize.copy_(outsz, non_blocking=True)
+        return plan, image_sizes
+
+    def collect(self, plan, batched_inputs, image_sizes, first=0):
+        """Detection buffer -> List[{"instances": Instances}] with the reference's fields (core.py:153-164)."""
+        counts = plan.det_count.cpu()
+        n_max = int(counts.max()) if counts.numel() else 0
+        if n_max > plan.det_cap:
+            raise RuntimeError(f"{n_max} detections exceed the detection buffer ({plan.det_cap}); raise det_cap")
+        det = plan.det[:, :max(n_max, 1)]
+        inv_K = plan.inv_K.view(-1, 3, 3)
+        results = []
+        for i, (inp, isz) in enumerate(zip(batched_inputs, image_sizes)):
+            g = first + i
+            n = int(counts[g])
+            d = det[g, :n]
+            if self.postprocess_in_inference:
+                size = (int(inp.get("height", isz[0])), int(inp.get("width", isz[1])))
+            else:
+                size = isz
+            r = Instances(size)
+            r.pred_boxes = Boxes(d[:, 0:4].contiguous())
+            r.scores = d[:, 4].contiguous()
+            r.pred_classes = d[:, 6].to(torch.int64)
+            r.locations = d[:, 8:10].contiguous()
+            r.fpn_levels = d[:, 7].to(torch.int64)
+            if not self.only_box2d:
+                r.pred_boxes3d = Boxes3D(
+                    d[:, 10:14].contiguous(), d[:, 14:16].contiguous(), d[:, 16:17].contiguous(), d[:, 17:20].contiguous(),
+                    inv_K[i][None].expand(n, 3, 3)
+                )
+                r.scores_3d = d[:, 5].contiguous()
+            results.append({"instances": r})
+        return results
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        if self.do_bev_nms:
+            raise NotImplementedError("DD3D.INFERENCE.DO_BEV_NMS is not part of this round (default False, dd3d.yaml:15)")
+        plan, image_sizes = self.stage_inputs(batched_inputs)
+        plan.run()
+        return self.collect(plan, batched_inputs, image_sizes)

@@ -1,0 +1,196 @@
+"""DLA-34 + FPN(P3..P7) backbone: parameter tree and backbone builders.
+
+Mirrors the module/parameter naming of tridet/modeling/feature_extractor/dla.py:24-361,536-561 and of
+detectron2's FPN / LastLevelP6P7 [ext] so reference checkpoints load unchanged
+(``backbone.bottom_up.level3.tree1.root.conv.weight`` ...).  The arithmetic lives in the HIP engine;
+``dd3d_amd.engine`` walks this tree to build its launch plan.
+"""
+import math
+from collections import OrderedDict
+
+from torch import nn
+
+from dd3d_amd.layers import Conv2d, get_norm
+from dd3d_amd.registry import BACKBONE_REGISTRY
+from dd3d_amd.structures import ShapeSpec
+
+
+def _msra_fill(conv):
+    """[ext] fvcore c2_msra_fill: kaiming_normal_(fan_out, relu), bias 0 (dla.py:296-298)."""
+    nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+    if conv.bias is not None:
+        nn.init.constant_(conv.bias, 0)
+
+
+def _xavier_fill(conv):
+    """[ext] fvcore c2_xavier_fill: kaiming_uniform_(a=1), bias 0 (detectron2 FPN / LastLevelP6P7)."""
+    nn.init.kaiming_uniform_(conv.weight, a=1)
+    if conv.bias is not None:
+        nn.init.constant_(conv.bias, 0)
+
+
+class BasicBlock(nn.Module):
+    """dla.py:24-62."""
+    def __init__(self, inplanes, planes, stride=1, norm="BN"):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=norm == "", norm=get_norm(norm, planes))
+        self.conv2 = Conv2d(planes, planes, 3, stride=1, padding=1, bias=norm == "", norm=get_norm(norm, planes))
+        self.stride = stride
+
+
+class Root(nn.Module):
+    """dla.py:146-167 (kernel_size 1, residual False in every config)."""
+    def __init__(self, in_channels, out_channels, norm="BN"):
+        super().__init__()
+        self.conv = Conv2d(in_channels, out_channels, 1, bias=norm == "", norm=get_norm(norm, out_channels))
+
+
+class Tree(nn.Module):
+    """dla.py:170-247."""
+    def __init__(self, levels, in_channels, out_channels, stride=1, level_root=False, root_dim=0, norm="BN"):
+        super().__init__()
+        if root_dim == 0:
+            root_dim = 2 * out_channels
+        if level_root:
+            root_dim += in_channels
+        if levels == 1:
+            self.tree1 = BasicBlock(in_channels, out_channels, stride, norm=norm)
+            self.tree2 = BasicBlock(out_channels, out_channels, 1, norm=norm)
+            self.root = Root(root_dim, out_channels, norm=norm)
+        else:
+            self.tree1 = Tree(levels - 1, in_channels, out_channels, stride, root_dim=0, norm=norm)
+            self.tree2 = Tree(levels - 1, out_channels, out_channels, root_dim=root_dim + out_channels, norm=norm)
+        self.level_root, self.root_dim, self.levels, self.stride = level_root, root_dim, levels, stride
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.project = None
+        if in_channels != out_channels and levels == 1:
+            self.project = Conv2d(in_channels, out_channels, 1, bias=norm == "", norm=get_norm(norm, out_channels))
+
+
+class DLA(nn.Module):
+    """dla.py:250-355 with BasicBlock."""
+    def __init__(self, levels, channels, out_features=None, norm="BN"):
+        super().__init__()
+        self.levels, self.channels = levels, channels
+        self.base_layer = Conv2d(3, channels[0], 7, stride=1, padding=3, bias=norm == "", norm=get_norm(norm, channels[0]))
+        self.level0 = self._make_conv_level(channels[0], channels[0], levels[0], norm=norm)
+        self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2, norm=norm)
+        self.level2 = Tree(levels[2], channels[1], channels[2], 2, level_root=False, norm=norm)
+        self.level3 = Tree(levels[3], channels[2], channels[3], 2, level_root=True, norm=norm)
+        self.level4 = Tree(levels[4], channels[3], channels[4], 2, level_root=True, norm=norm)
+        self.level5 = Tree(levels[5], channels[4], channels[5], 2, level_root=True, norm=norm)
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                _msra_fill(m)
+        self._out_features = out_features or ["level5"]
+        self._out_feature_channels = {f"level{i}": channels[i] for i in range(6)}
+        self._out_feature_strides = {f"level{i}": 2**i for i in range(6)}
+
+    @staticmethod
+    def _make_conv_level(inplanes, planes, convs, stride=1, norm="BN"):
+        mods = []
+        for i in range(convs):
+            mods.append(
+                Conv2d(inplanes, planes, 3, stride=stride if i == 0 else 1, padding=1, bias=norm == "", norm=get_norm(norm, planes))
+            )
+            inplanes = planes
+        return nn.Sequential(*mods)
+
+    def output_shape(self):
+        return {
+            n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n])
+            for n in self._out_features
+        }
+
+    @property
+    def size_divisibility(self):
+        return 32
+
+
+def dla34(cfg):
+    """dla.py:359-361."""
+    return DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], out_features=list(cfg.OUT_FEATURES), norm=cfg.NORM)
+
+
+DLA_NAME_TO_BUILDER = {"DLA-34": dla34}  # the only DLA variant any reference config selects
+
+
+class LastLevelP6P7(nn.Module):
+    """[ext] detectron2 LastLevelP6P7: p6 = conv3x3s2(x), p7 = conv3x3s2(relu(p6)), both with bias."""
+    def __init__(self, in_channels, out_channels, in_feature="res5"):
+        super().__init__()
+        self.num_levels, self.in_feature = 2, in_feature
+        self.p6 = Conv2d(in_channels, out_channels, 3, 2, 1)
+        self.p7 = Conv2d(out_channels, out_channels, 3, 2, 1)
+        for m in (self.p6, self.p7):
+            _xavier_fill(m)
+
+
+class LastLevelP6(nn.Module):
+    """tridet/modeling/feature_extractor/vovnet.py:411-425."""
+    def __init__(self, in_channels, out_channels, in_feature="res5"):
+        super().__init__()
+        self.num_levels, self.in_feature = 1, in_feature
+        self.p6 = Conv2d(in_channels, out_channels, 3, 2, 1)
+        _xavier_fill(self.p6)
+
+
+class FPN(nn.Module):
+    """[ext] detectron2.modeling.backbone.FPN parameter layout: fpn_lateral{s}, fpn_output{s}, top_block."""
+    def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
+        super().__init__()
+        assert fuse_type in ("sum", "avg")
+        shapes = bottom_up.output_shape()
+        strides = [shapes[f].stride for f in in_features]
+        use_bias = norm == ""
+        self.stages = []
+        for f, s in zip(in_features, strides):
+            st = int(math.log2(s))
+            lateral = Conv2d(shapes[f].channels, out_channels, 1, bias=use_bias, norm=get_norm(norm, out_channels))
+            output = Conv2d(out_channels, out_channels, 3, 1, 1, bias=use_bias, norm=get_norm(norm, out_channels))
+            _xavier_fill(lateral), _xavier_fill(output)
+            self.add_module(f"fpn_lateral{st}", lateral)
+            self.add_module(f"fpn_output{st}", output)
+            self.stages.append(st)
+        self.top_block = top_block
+        self.bottom_up = bottom_up
+        self.in_features = list(in_features)
+        self._fuse_type = fuse_type
+        self._out_feature_strides = OrderedDict((f"p{st}", 2**st) for st in self.stages)
+        if top_block is not None:
+            for i in range(top_block.num_levels):
+                st = self.stages[-1] + 1 + i
+                self._out_feature_strides[f"p{st}"] = 2**st
+        self._out_features = list(self._out_feature_strides.keys())
+        self._out_feature_channels = {k: out_channels for k in self._out_features}
+        self._size_divisibility = strides[-1]
+
+    @property
+    def size_divisibility(self):
+        return self._size_divisibility
+
+    def output_shape(self):
+        return OrderedDict(
+            (n, ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]))
+            for n in self._out_features
+        )
+
+
+@BACKBONE_REGISTRY.register()
+def build_dla_backbone(cfg, input_shape):
+    """dla.py:445-459 (cfg = cfg.FE.BACKBONE)."""
+    assert input_shape.channels == 3, "Only supports 3-channel input for now."
+    return DLA_NAME_TO_BUILDER[cfg.NAME](cfg)
+
+
+@BACKBONE_REGISTRY.register()
+def build_fcos_dla_fpn_backbone_p67(cfg, input_shape):
+    """dla.py:536-561."""
+    bottom_up = build_dla_backbone(cfg.FE.BACKBONE, input_shape)
+    out_channels = cfg.FE.FPN.OUT_CHANNELS
+    backbone = FPN(
+        bottom_up=bottom_up, in_features=cfg.FE.FPN.IN_FEATURES, out_channels=out_channels, norm=cfg.FE.FPN.NORM,
+        top_block=LastLevelP6P7(out_channels, out_channels, "p5"), fuse_type=cfg.FE.FPN.FUSE_TYPE
+    )
+    backbone._size_divisibility *= 4
+    return backbone

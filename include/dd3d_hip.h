@@ -1,0 +1,209 @@
+/*
+ * dd3d_hip.h -- C ABI of the MI355X (gfx950) DD3D forward-path library  (libdd3d_hip.so)
+ *
+ * The reference (TRI-ML/dd3d) has no FFI of its own for this path: it is pure Python and reaches
+ * native code only through third-party wheels (cuDNN via torch, torchvision.ops.nms,
+ * detectron2._C.nms_rotated, pytorch3d).  The entry points below are what a maintainer would bind
+ * INSTEAD of those calls; each one cites the reference call site(s) it replaces.  See
+ * INTEGRATION.md for the ctypes stub on the reference side.
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers, int sizes, an opaque hipStream_t passed as void*.
+ *   - every buffer is owned by the caller (PyTorch caching allocator); the library allocates no
+ *     persistent device memory and never synchronises the device.
+ *   - kernels are enqueued asynchronously on `stream`; calls are safe under hipGraph stream capture.
+ *   - return value: 0 = ok, <0 = error (DD3D_E_*); dd3d_last_error() gives a message (thread-local).
+ *   - all activations are NHWC fp32 with an explicit per-pixel pitch, so a conv can read / write a
+ *     channel slice of a wider buffer (this is how torch.cat in dla.py:161 disappears).
+ */
+#ifndef DD3D_HIP_H
+#define DD3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD3D_ABI_VERSION 1
+
+#define DD3D_OK 0
+#define DD3D_E_INVALID (-1)  /* bad argument (shape / alignment / enum) */
+#define DD3D_E_LAUNCH (-2)   /* hip launch error */
+#define DD3D_E_UNSUPPORTED (-3)
+
+#define DD3D_MAX_LEVELS 8
+#define DD3D_CAND_FIELDS 20 /* SoA fields of a decoded candidate, see dd3d_fcos_select_decode */
+#define DD3D_DET_FIELDS 20  /* AoS fields of a final detection, see dd3d_nms_finalize */
+
+int dd3d_abi_version(void);
+const char* dd3d_last_error(void);
+/* "gfx950" -- the only architecture the code objects are built for. */
+const char* dd3d_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on f32 MFMA (v_mfma_f32_32x32x2_f32), fused epilogue.
+ * Replaces: every nn.Conv2d / detectron2 Conv2d(+FrozenBN/BN +ReLU) on the path --
+ *   tridet/modeling/feature_extractor/dla.py:50-62,160-167,233-247,346-355 (DLA blocks, roots),
+ *   detectron2 FPN lateral/output/top-block convs [ext] (built at dla.py:550-557),
+ *   tridet/modeling/dd3d/fcos2d.py:137-152 and fcos3d.py:163-180 (towers, predictors, Scale/Offset),
+ *   plus the residual add (dla.py:59-60) and torch.cat before a Root (dla.py:161), which are folded
+ *   into the epilogue / the pitch addressing.
+ *
+ * One launch processes `nsegs` segments that share the filter geometry (KH,KW,stride,pad,Cin,N) but
+ * have their own tensors: e.g. the 5 FPN levels x 3 head towers of one tower layer = 15 segments.
+ *
+ *   out[m, n] = max( lo[n],  relu?( sum_k A[m,k] * Wp[n,k] * scale[n] + bias[n] + res[...] ) )
+ *
+ * K ordering of the packed filter Wp[Npad][Kpad] (n-major, k contiguous):
+ *   k = (c / CC) * (KH*KW*CC) + (kh*KW + kw) * CC + (c % CC),   CC = min(Cin, 32),
+ * zero-padded to Kpad (multiple of 32) and Npad (multiple of 32).  Cin must be 4, 16 or a multiple of 32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dd3d_conv_seg {  /* array lives in DEVICE memory */
+  const float* in;     /* NHWC input, already offset to the first input channel                  */
+  const float* w;      /* packed filter [Npad][Kpad]                                             */
+  const float* scale;  /* [N] folded-norm / Scale multiplier                                     */
+  const float* bias;   /* [N] folded-norm shift / conv bias / Offset                             */
+  const float* lo;     /* [N] per-channel lower clamp (0 => ReLU on that channel, -inf => none), or NULL */
+  const float* res;    /* residual source (NHWC) or NULL                                         */
+  float* out;          /* NHWC output, already offset to the first output channel                */
+  int32_t B, H, W;     /* input batch / height / width                                           */
+  int32_t Ho, Wo;      /* output height / width                                                   */
+  int32_t in_pitch, out_pitch, res_pitch; /* floats per pixel of the respective buffers          */
+  int32_t M;           /* B*Ho*Wo                                                                */
+  int32_t res_mode;    /* 0 none, 1 add res[m, n] (same pixel) before the clamp                  */
+  int32_t reserved0[2];
+  int32_t ws_row0;     /* first row of this segment in the split-K workspace                     */
+  int32_t reserved[3];
+} dd3d_conv_seg;
+
+typedef struct dd3d_conv_launch {  /* host memory */
+  const dd3d_conv_seg* segs; /* device */
+  const int32_t* tiles;      /* device, ntiles x {seg, m0} */
+  float* workspace;          /* device, [splitk][ws_rows][round_up(N,4)] partial sums when splitk > 1, else NULL */
+  int32_t nsegs, ntiles;
+  int32_t KH, KW, stride, pad;
+  int32_t Cin, N, Kpad, Npad;
+  int32_t relu;      /* 1: clamp every output channel at 0 */
+  int32_t splitk;    /* >= 1 */
+  int32_t ws_rows;   /* rows per split in the workspace */
+  int32_t tile_cfg;  /* DD3D_TILE_* */
+} dd3d_conv_launch;
+
+#define DD3D_TILE_128x128 0
+#define DD3D_TILE_128x64 1
+#define DD3D_TILE_64x64 2
+#define DD3D_TILE_128x32 3
+#define DD3D_TILE_64x128 4
+#define DD3D_TILE_COUNT 5
+/* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
+int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
+int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pre-processing.  Replaces DD3D.preprocess_image + ImageList.from_tensors
+ * (tridet/modeling/dd3d/core.py:61-72, tridet/structures/image_list.py:120-142):
+ * (u8 - mean)/std per channel inside the (h_i, w_i) image, 0.0 in the right/bottom padding.
+ *   src  : uint8 [B][3][Hp][Wp] (CHW planes, canvas already at the padded size)
+ *   sizes: int32 [B][2] = (h_i, w_i), device
+ *   dst  : fp32 NHWC [B][Hp][Wp][4], channel 3 = 0
+ * ------------------------------------------------------------------------------------------------ */
+int dd3d_preprocess_u8_nhwc4(const uint8_t* src, const int32_t* sizes, float* dst, int32_t B, int32_t Hp, int32_t Wp,
+                             const float mean[3], const float std[3], void* stream);
+
+/* 2x2 stride-2 max pooling, NHWC with pitches.  Replaces nn.MaxPool2d(2, 2) = Tree.downsample
+ * (tridet/modeling/feature_extractor/dla.py:224-225,235).  H, W even; C % 4 == 0. */
+int dd3d_maxpool2x2_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                         int32_t out_pitch, void* stream);
+
+/* fine[b,y,x,:] += coarse[b,y/2,x/2,:].  Replaces the FPN top-down step of detectron2 FPN.forward [ext]:
+ * prev = lateral + F.interpolate(prev, scale_factor=2, mode="nearest").  H, W (of `fine`) even; C % 4 == 0. */
+int dd3d_upsample2x_add_nhwc(float* fine, const float* coarse, int32_t B, int32_t H, int32_t W, int32_t C,
+                             int32_t fine_pitch, int32_t coarse_pitch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused per-(image, level) candidate selection + 2D/3D decode.
+ * Replaces FCOS2DInference.forward_for_single_feature_map (fcos2d.py:270-344),
+ * FCOS3DInference.forward_for_single_feature_map (fcos3d.py:328-399), predictions_to_boxes3d
+ * (fcos3d.py:16-52), allocentric_to_egocentric / unproject_points2d (tridet/utils/geometry.py:15-112),
+ * pytorch3d quaternion_to_matrix / matrix_to_quaternion [ext], compute_features_locations
+ * (tridet/utils/tensor2d.py:6-25).
+ *
+ * Head maps are NHWC with these channel layouts (C = num classes, C3 = 1 if class-agnostic else C):
+ *   cls  [B*HW][cls_pitch]  : logits 0..C-1
+ *   box2d[B*HW][b2d_pitch]  : relu(scale*reg) 0..3, centerness logit 4
+ *   box3d[B*HW][b3d_pitch]  : quat 4*C3 (comp*C3+cls), ctr 2*C3, depth C3, size 3*C3, conf C3
+ * Output (per image b): cand[b][f][level*topk + j], f < DD3D_CAND_FIELDS:
+ *   0-3 box x1,y1,x2,y2 | 4 score=sqrt(cls*ctr) | 5 score_3d | 6 class (int bits) | 7 loc*C+class (int bits)
+ *   8-9 location x,y | 10-13 quat wxyz (egocentric) | 14-15 proj_ctr | 16 depth | 17-19 size WLH
+ * counts[b][level] = number of valid slots (<= topk); npass[b][level] = #scores over threshold.
+ * Candidate order inside a level = ascending (loc, class), i.e. torch.nonzero order.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dd3d_select_args {  /* host memory */
+  const float* cls[DD3D_MAX_LEVELS];
+  const float* box2d[DD3D_MAX_LEVELS];
+  const float* box3d[DD3D_MAX_LEVELS]; /* NULL entries => 2D only (MODEL.BOX3D_ON false) */
+  int32_t H[DD3D_MAX_LEVELS], W[DD3D_MAX_LEVELS], stride[DD3D_MAX_LEVELS];
+  int32_t cls_pitch, b2d_pitch, b3d_pitch;
+  int32_t num_levels, B, num_classes;
+  int32_t class_agnostic_3d;
+  int32_t loc_offset_half;       /* DD3D.FEATURE_LOCATIONS_OFFSET == "half" */
+  int32_t thresh_with_ctr;       /* DD3D.FCOS2D.INFERENCE.THRESH_WITH_CTR */
+  int32_t topk;                  /* PRE_NMS_TOPK */
+  float pre_nms_thresh;
+  float min_depth, max_depth, focal_factor;
+  int32_t scale_depth_by_focal, allocentric, depth_is_distance;
+  const float* inv_K;            /* [B][9] row-major inverse intrinsics, device */
+  const float* canon_sizes;      /* [>=num_classes][3] (W,L,H), device */
+  int32_t* scratch_idx;          /* device, per (b,level) region; offsets below  */
+  float* scratch_score;
+  int64_t scratch_off[DD3D_MAX_LEVELS]; /* element offset of level l's region for image 0 */
+  int64_t scratch_img_stride;           /* elements per image */
+  float* cand;                   /* [B][DD3D_CAND_FIELDS][num_levels*topk] */
+  int32_t* counts;               /* [B][num_levels] */
+  int32_t* npass;                /* [B][num_levels] */
+} dd3d_select_args;
+int dd3d_fcos_select_decode(const dd3d_select_args* args, void* stream);
+
+/* Closed-form inverse of the (B,3,3) intrinsics.  Replaces images.intrinsics.inverse() (core.py:93). */
+int dd3d_invert_intrinsics(const float* K, float* inv_K, int32_t B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Class-aware 2D NMS + top-k + resize.  Replaces FCOS2DInference.nms_and_top_k (fcos2d.py:346-367) =
+ * detectron2.layers.batched_nms -> torchvision.ops.batched_nms / nms [ext] (rank by score_3d,
+ * coordinate trick when 4*n <= 4000 else per-class), torch.kthvalue top-k on the 2D score with >=,
+ * and detectron2 detector_postprocess [ext] (core.py:153-160).
+ *   cand/counts as written by dd3d_fcos_select_decode for G images (after the RCCL gather: G = all images)
+ *   out_size [G][4] = (in_h, in_w, out_h, out_w) float, device
+ *   det [G][det_cap][DD3D_DET_FIELDS]:
+ *     0-3 box | 4 score | 5 score_3d | 6 class | 7 fpn level | 8-9 location | 10-13 quat | 14-15 proj_ctr
+ *     | 16 depth | 17-19 size            (class / level stored as float-valued integers)
+ *   det_count [G]; order = descending score_3d (torchvision keep order).
+ * Workspaces (device): sort_idx int32 [G][ncap], sbox float [G][ncap][4], scls int32 [G][ncap],
+ *   mask uint64 [G][ncap][ncap/64], nvalid int32 [G][2], where ncap = round_up(num_levels*topk, 64).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dd3d_nms_args {  /* host memory */
+  const float* cand;
+  const int32_t* counts;
+  int32_t G, num_levels, topk;
+  int32_t do_nms;          /* DD3D.INFERENCE.DO_NMS */
+  int32_t use_score3d;     /* rank by score_3d (BOX3D_ON) else score */
+  float nms_thresh;        /* <= 0 disables suppression (fcos2d.py:349) */
+  int32_t post_topk;       /* POST_NMS_TOPK */
+  int32_t do_postprocess;  /* DD3D.INFERENCE.DO_POSTPROCESS */
+  const float* out_size;
+  int32_t* sort_idx;
+  float* sbox;
+  int32_t* scls;
+  uint64_t* mask;
+  int32_t* nvalid;
+  float* det;
+  int32_t* det_count;
+  int32_t det_cap;
+} dd3d_nms_args;
+int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DD3D_HIP_H */

@@ -1,0 +1,104 @@
+"""Offline calibration of the synthetic weights (dev tool; run once per architecture, result committed).
+
+    python tests/golden/calibrate_synthetic.py dd3d_kitti_dla34 dla34_kitti
+
+Runs the CPU oracle on synthetic image 0 at the benchmark resolution and records, for every norm layer, the
+(mean, std) of its input activation and, for every predictor conv, a (gain, bias) -- see
+dd3d_amd/synthetic.py.  Output: dd3d_amd/data/synth_calib_<tag>.json (a few KB).
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import dd3d_amd.modeling  # noqa: E402,F401
+from dd3d_amd import META_ARCH_REGISTRY, get_cfg  # noqa: E402
+from dd3d_amd.synthetic import calib_path, make_inputs, make_state_dict  # noqa: E402
+from oracle import dd3d_oracle as O  # noqa: E402
+
+
+def main(experiment, tag, H=384, W=1280, dataset="kitti", target_frac=0.01):
+    cfg = get_cfg(experiment)
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    sd0 = make_state_dict(model, seed=0, calib={})
+    sd = {k: v.clone() for k, v in sd0.items()}
+    calib = {}
+    inputs = make_inputs(1, H, W, dataset=dataset)
+
+    def hook(prefix, x, sd_):
+        m0, s0 = float(x.mean()), float(x.std())
+        calib[prefix] = [m0, s0]
+        sd_[prefix + ".running_mean"] = m0 + sd0[prefix + ".running_mean"] * s0
+        sd_[prefix + ".running_var"] = sd0[prefix + ".running_var"] * s0 * s0
+
+    with torch.no_grad():
+        _, st = O.dd3d_forward(sd, cfg, inputs, hook=hook, stop_after_heads=True)
+        feats = st["features"]
+        n2, n3 = cfg.DD3D.FCOS2D.NUM_CLS_CONVS, cfg.DD3D.FCOS3D.NUM_CONVS
+        towers = {"cls": [], "box2d": [], "box3d": []}
+        for l, f in enumerate(feats):
+            towers["cls"].append(O._tower(sd, "fcos2d_head.cls_tower", f, l, n2))
+            towers["box2d"].append(O._tower(sd, "fcos2d_head.box2d_tower", f, l, cfg.DD3D.FCOS2D.NUM_BOX_CONVS))
+            towers["box3d"].append(O._tower(sd, "fcos3d_head.box3d_tower", f, l, n3))
+
+        def raw(name, tower):
+            outs = [F.conv2d(t, sd[name + ".weight"], None, padding=1).permute(0, 2, 3, 1).reshape(-1, sd[name + ".weight"].shape[0])
+                    for t in towers[tower]]
+            return torch.cat(outs, 0)
+
+        targets = {  # predictor -> (tower, target std, target mean)
+            "fcos2d_head.cls_logits": ("cls", 1.2, -5.0),
+            "fcos2d_head.centerness": ("box2d", 1.0, 0.0),
+            "fcos2d_head.box2d_reg": ("box2d", 1.0, 1.0),
+            "fcos3d_head.box3d_quat.0": ("box3d", 1.0, 0.0),
+            "fcos3d_head.box3d_ctr.0": ("box3d", 1.0, 0.0),
+            "fcos3d_head.box3d_depth.0": ("box3d", 1.0, 0.0),
+            "fcos3d_head.box3d_size.0": ("box3d", 0.5, 0.0),
+            "fcos3d_head.box3d_conf.0": ("box3d", 1.0, 0.0),
+        }
+        if hasattr(model, "attr_logits"):
+            targets["attr_logits"] = ("cls", 1.0, 0.0)
+            targets["speed"] = ("cls", 1.0, 0.5)
+        for name, (tower, tstd, tmean) in targets.items():
+            r = raw(name, tower)
+            gain = tstd / float(r.std())
+            bias = tmean - gain * float(r.mean())
+            calib[name] = [gain, bias]
+
+        # fine-tune the classifier bias so that ~target_frac of (location, class) scores pass PRE_NMS_THRESH
+        g, b = calib["fcos2d_head.cls_logits"]
+        logit0 = raw("fcos2d_head.cls_logits", "cls") * g + sd0["fcos2d_head.cls_logits.bias"]
+        gc, bc = calib["fcos2d_head.centerness"]
+        ctr = torch.sigmoid(raw("fcos2d_head.centerness", "box2d") * gc + sd0["fcos2d_head.centerness.bias"] + bc)
+        thr = cfg.DD3D.FCOS2D.INFERENCE.PRE_NMS_THRESH
+        lo, hi = b - 6.0, b + 6.0
+        for _ in range(40):
+            mid = 0.5 * (lo + hi)
+            frac = float(((torch.sigmoid(logit0 + mid) * ctr) > thr).float().mean())
+            if frac > target_frac:
+                hi = mid
+            else:
+                lo = mid
+        calib["fcos2d_head.cls_logits"] = [g, 0.5 * (lo + hi)]
+        print(f"cls bias {b:.3f} -> {0.5 * (lo + hi):.3f}, pass fraction {frac:.4f}")
+
+    os.makedirs(os.path.dirname(calib_path(tag)), exist_ok=True)
+    with open(calib_path(tag), "w") as f:
+        json.dump({k: [round(v[0], 6), round(v[1], 6)] for k, v in calib.items()}, f, indent=0, sort_keys=True)
+    # verify with the public generator
+    sd2 = make_state_dict(model, seed=0, calib=json.load(open(calib_path(tag))))
+    with torch.no_grad():
+        res, st = O.dd3d_forward(sd2, cfg, inputs)
+    npass = [[len(i["fg_inds"]) for i in info] for info in st["level_info"]]
+    print("verify: candidates per level", npass, "detections", [len(r["scores"]) for r in res])
+    print("feature std per level", [round(float(f.std()), 3) for f in st["features"]])
+
+
+if __name__ == "__main__":
+    exp = sys.argv[1] if len(sys.argv) > 1 else "dd3d_kitti_dla34"
+    tag = sys.argv[2] if len(sys.argv) > 2 else "dla34_kitti"
+    hw = (384, 1280) if "kitti" in exp else (896, 1600)
+    main(exp, tag, hw[0], hw[1], "kitti" if "kitti" in exp else "nusc")

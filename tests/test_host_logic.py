@@ -1,0 +1,139 @@
+"""Host-side logic of the forward path (no GPU): filter packing / K ordering, tiling choice, plan construction,
+the drop-in surface (registry names, state-dict keys, config keys) and the C-ABI exports."""
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _emulate_igemm(x, wp, meta, stride, pad):
+    """Plain-torch restatement of the kernel's gather: A[m, k] with k = (c/CC)*(T*CC) + tap*CC + c%CC."""
+    B, Cin, H, W = x.shape
+    KH, KW, cin_p = meta["KH"], meta["KW"], meta["Cin"]
+    CC, T = min(cin_p, 32), KH * KW
+    xp = F.pad(x, (pad, pad, pad, pad, 0, cin_p - Cin))
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    A = torch.zeros(B, Ho, Wo, meta["Kpad"])
+    for k in range(T * cin_p):
+        chunk, rem = divmod(k, T * CC)
+        tap, c = divmod(rem, CC)
+        dh, dw = divmod(tap, KW)
+        A[..., k] = xp[:, chunk * CC + c, dh:dh + stride * Ho:stride, dw:dw + stride * Wo:stride]
+    return torch.einsum("bhwk,nk->bnhw", A, wp[:meta["N"]])
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad", [(3, 16, 7, 1, 3), (16, 32, 3, 2, 1), (64, 40, 3, 1, 1), (96, 8, 1, 1, 0)])
+def test_pack_filter_k_order(cin, cout, k, stride, pad):
+    from dd3d_amd.engine import pack_filter
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, cin, 9, 11, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g)
+    wp, meta = pack_filter(w, "cpu")
+    assert wp.shape == (meta["Npad"], meta["Kpad"]) and meta["Kpad"] % 32 == 0 and meta["Npad"] % 32 == 0
+    ref = F.conv2d(x, w, stride=stride, padding=pad)
+    assert torch.allclose(_emulate_igemm(x, wp, meta, stride, pad), ref, atol=1e-4)
+
+
+def test_kw_magic_division():
+    for kw in (1, 3, 5, 7):
+        magic = 65536 // kw + 1
+        for tap in range(64):
+            assert (tap * magic) >> 16 == tap // kw
+
+
+def test_choose_tiling_fills_the_chip():
+    from dd3d_amd import hip
+    from dd3d_amd.engine import choose_tiling
+    levels = [7680, 1920, 480, 120, 30]
+    cfg, sk = choose_tiling(levels * 3, 256, 2304)  # the head-tower launch
+    assert sk == 1 and hip.TILE_SHAPES[cfg] == (128, 128)
+    cfg, sk = choose_tiling([480], 512, 4608)  # DLA level5: tiny M, long K -> split-K
+    bm, bn = hip.TILE_SHAPES[cfg]
+    assert sk > 1 and -(-480 // bm) * (512 // bn) * sk >= 200
+    cfg, sk = choose_tiling([491520], 16, 224)
+    assert hip.TILE_SHAPES[cfg][1] == 32
+
+
+def test_plan_construction_dry_run(kitti_dla34, hiplib):
+    """The whole launch plan can be built without a GPU; its conv work matches BASELINE.md's 110.384 GMAC (+ the
+    Cin 3->4 padding of the 7x7 stem and the duplicated tiny P6 conv)."""
+    from dd3d_amd.engine import ConvOp, ForwardPlan
+    cfg, model, sd = kitti_dla34
+    model.load_state_dict(sd)
+    plan = ForwardPlan(model, 1, 384, 1280, device="cpu", dry_run=True)
+    convs = [op for op in plan.ops if isinstance(op, ConvOp)]
+    gmac = plan.conv_macs / 1e9
+    assert abs(gmac - (110.384 + 0.3853 + 0.0708)) < 0.01, gmac
+    assert [f.H * f.W for f in plan.features] == [7680, 1920, 480, 120, 30]
+    towers = [c for c in convs if c.name.startswith("towers.")]
+    assert len(towers) == 4 and all(c.info["nsegs"] == 15 for c in towers)
+    with pytest.raises(RuntimeError):
+        plan.launch()  # no CPU execution path exists
+
+
+def test_registry_and_state_dict_surface(kitti_dla34):
+    from dd3d_amd import BACKBONE_REGISTRY, META_ARCH_REGISTRY
+    cfg, model, sd = kitti_dla34
+    assert "DD3D" in META_ARCH_REGISTRY._obj_map and "build_fcos_dla_fpn_backbone_p67" in BACKBONE_REGISTRY._obj_map
+    keys = set(model.state_dict().keys())
+    for k in [
+        "pixel_mean", "backbone.bottom_up.base_layer.weight", "backbone.bottom_up.base_layer.norm.running_var",
+        "backbone.bottom_up.level0.0.weight", "backbone.bottom_up.level2.project.weight",
+        "backbone.bottom_up.level3.tree1.tree2.conv2.norm.weight", "backbone.bottom_up.level3.tree2.root.conv.weight",
+        "backbone.bottom_up.level5.root.conv.weight", "backbone.fpn_lateral3.weight", "backbone.fpn_output5.norm.bias",
+        "backbone.top_block.p6.bias", "backbone.top_block.p7.weight", "fcos2d_head.cls_tower.0.weight",
+        "fcos2d_head.cls_tower.3.norm.4.running_mean", "fcos2d_head.box2d_tower.2.norm.0.num_batches_tracked",
+        "fcos2d_head.cls_logits.bias", "fcos2d_head.scales_box2d_reg.4.scale", "fcos3d_head.box3d_tower.1.norm.2.weight",
+        "fcos3d_head.box3d_quat.0.weight", "fcos3d_head.box3d_depth.0.weight", "fcos3d_head.scales_depth.0.scale",
+        "fcos3d_head.offsets_depth.3.bias", "fcos3d_head.mean_depth_per_level"
+    ]:
+        assert k in keys, k
+    assert "fcos3d_head.box3d_depth.0.bias" not in keys  # no bias when USE_SCALE (fcos3d.py:116)
+    assert model.state_dict()["backbone.bottom_up.level3.tree2.root.conv.weight"].shape == (128, 448, 1, 1)
+    assert model.state_dict()["backbone.bottom_up.level5.root.conv.weight"].shape == (512, 1280, 1, 1)
+    assert model.backbone.size_divisibility == 128
+    assert abs(float(model.state_dict()["fcos3d_head.scales_depth.1.scale"]) - 0.3 * 7.139) < 1e-5
+    for attr in ("device", "postprocess_in_inference", "do_nms", "do_bev_nms", "only_box2d", "bev_nms_iou_thresh", "num_classes"):
+        assert hasattr(model, attr)
+    with pytest.raises(NotImplementedError):
+        model.train()
+
+
+def test_reference_guards():
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    import dd3d_amd.modeling  # noqa: F401
+    cfg = get_cfg("dd3d_kitti_dla34", {"DD3D": {"FCOS2D": {"USE_DEFORMABLE": True}}})
+    with pytest.raises(ValueError, match="Not supported yet"):
+        META_ARCH_REGISTRY.get("DD3D")(cfg)
+
+
+def test_cabi_exports_match_header(hiplib):
+    """Every function declared in include/dd3d_hip.h is exported by the built library (no compute calls here)."""
+    from dd3d_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "dd3d_hip.h")).read()
+    declared = set(re.findall(r"\b(dd3d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    for name in declared:
+        assert getattr(hiplib, name) is not None
+    assert hiplib.dd3d_abi_version() == 1 and hiplib.dd3d_arch() == b"gfx950"
+    import ctypes as C
+    bm, bn = C.c_int32(), C.c_int32()
+    for cfg_id, shape in hip.TILE_SHAPES.items():
+        assert hiplib.dd3d_conv_tile_shape(cfg_id, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == shape
+    assert hiplib.dd3d_conv_tile_shape(99, C.byref(bm), C.byref(bn)) < 0 and b"tile_cfg" in hiplib.dd3d_last_error()
+    assert C.sizeof(hip.ConvLaunch) == 80 and hip.CONV_SEG_DTYPE.itemsize == 120
+
+
+def test_config_surface():
+    from dd3d_amd import get_cfg
+    c = get_cfg("dd3d_kitti_dla34")
+    assert c.DD3D.FCOS2D.INFERENCE.NMS_THRESH == 0.75 and c.DD3D.FCOS2D.INFERENCE.PRE_NMS_TOPK == 1000
+    assert c.DD3D.FCOS3D.CANONICAL_BOX3D_SIZES[0] == [1.61876949, 3.89154523, 1.52969237]
+    assert c.FE.BUILDER == "build_fcos_dla_fpn_backbone_p67" and c.DD3D.IN_FEATURES is None
+    n = get_cfg("dd3d_nusc_v99")
+    assert n.DD3D.NUM_CLASSES == 10 and n.DD3D.NUSC.INFERENCE.NUM_IMAGES_PER_SAMPLE == 6
+    assert n.MODEL.META_ARCHITECTURE == "NuscenesDD3D" and n.FE.BUILDER == "build_fcos_vovnet_fpn_backbone_p6"

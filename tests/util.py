@@ -1,0 +1,61 @@
+"""Helpers shared by the parity tests (test infrastructure; may import the oracle)."""
+import torch
+
+
+def rel_err(a, b, floor=1e-3):
+    """max |a-b| / max(|b|, floor*max|b|): relative error that does not blow up on near-zero entries."""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    if b.numel() == 0:
+        return 0.0
+    den = b.abs().clamp(min=floor * max(float(b.abs().max()), 1e-30))
+    return float(((a - b).abs() / den).max())
+
+
+def max_abs(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max()) if b.numel() else 0.0
+
+
+def quat_err(qa, qb):
+    """quaternions compared up to sign (pytorch3d's matrix_to_quaternion does not canonicalise it)."""
+    qa, qb = qa.detach().float().cpu(), qb.detach().float().cpu()
+    if qb.numel() == 0:
+        return 0.0
+    return float(torch.minimum((qa - qb).abs().amax(1), (qa + qb).abs().amax(1)).max())
+
+
+def gpu_model(cfg, sd, use_graph=True):
+    from dd3d_amd import build_model
+    model = build_model(cfg)
+    model.load_state_dict(sd)
+    model.use_graph = use_graph
+    return model
+
+
+def oracle_heads_to_plan(plan, st, num_classes):
+    """Overwrite the plan's head-map buffers with the oracle's head maps (NCHW -> fused NHWC layout)."""
+    for l in range(len(st["logits"])):
+        nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+        plan.cls_maps[l].t.zero_()
+        plan.cls_maps[l].t[..., :num_classes] = nhwc(st["logits"][l]).to(plan.device)
+        plan.b2d_maps[l].t.zero_()
+        plan.b2d_maps[l].t[..., 0:4] = nhwc(st["box2d_reg"][l]).to(plan.device)
+        plan.b2d_maps[l].t[..., 4:5] = nhwc(st["centerness"][l]).to(plan.device)
+        fused = torch.cat([st["quat"][l], st["ctr"][l], st["depth"][l], st["size"][l], st["conf"][l]], 1)
+        plan.b3d_maps[l].t.zero_()
+        plan.b3d_maps[l].t[..., :fused.shape[1]] = nhwc(fused).to(plan.device)
+
+
+def candidates_from_plan(plan, b=0):
+    """Decoded candidates of image b as a dict of CPU tensors, concatenated over levels (Instances.cat order)."""
+    import numpy as np
+    cand = plan.cand[b].cpu()
+    counts = plan.counts[b].cpu().tolist()
+    slots = torch.cat([torch.arange(c) + l * plan.topk for l, c in enumerate(counts)]).long()
+    c = cand[:, slots]
+    ints = lambda row: torch.from_numpy(c[row].numpy().view(np.int32).copy()).long()
+    return dict(
+        pred_boxes=c[0:4].T, scores=c[4], scores_3d=c[5], pred_classes=ints(6), flat_index=ints(7), locations=c[8:10].T, quat=c[10:14].T,
+        proj_ctr=c[14:16].T, depth=c[16:17].T, size=c[17:20].T, counts=counts,
+        fpn_levels=torch.cat([torch.full((c_, ), l) for l, c_ in enumerate(counts)]).long()
+    )
