@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Throughput benchmark of the DD3D-DLA34 forward path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one forward pass of the hot path (uint8 image already resident in HBM -> final detections in HBM) over one
+batch of synthetic 384x1280 KITTI-shaped frames, ``--batch`` images per GPU (default 1 = BASELINE.json configs[1]
+"DD3D-DLA34 KITTI3D 384x1280 bs=1 fp32 inference"; one image per GPU per step as the north star shards them).
+For N > 1 every rank forwards its own images and the step includes the RCCL all_gather of the decoded candidates and
+the batched NMS over all N*batch images (dd3d_amd/parallel.py).
+
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch,
+conv_igemm_f32_kernel<2,2,2,2,false>): algorithmic FLOPs of one launch / its mean duration measured here with HIP
+events on the launch stream, against the dense f32-MFMA peak.  ``cpu_baseline`` is the CPU oracle (a restatement
+"port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32
+GFLOP_PER_IMAGE = 220.77  # DD3D-DLA34 KITTI 384x1280, 2 x 110.384 GMAC
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--height", type=int, default=384)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-forwards", type=int, default=3)
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_tower_hbm_bytes.json"),
+                    help="optional PMC-derived HBM bytes per launch of the dominant kernel (see profiles/README.md)")
+    return ap.parse_args()
+
+
+def kernel_time_us(plan, op, iters=20):
+    """Mean duration of one op's launch(es), HIP events recorded on the launch stream (= torch's current stream)."""
+    from dd3d_amd import hip
+    st = hip.current_stream()
+    for _ in range(3):
+        op(plan.lib, st)
+    torch.cuda.synchronize()
+    t = 0.0
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        op(plan.lib, st)
+        e1.record()
+        e1.synchronize()
+        t += e0.elapsed_time(e1)
+    return t / iters * 1e3
+
+
+def main():
+    args = parse_args()
+    from dd3d_amd import build_model, get_cfg
+    from dd3d_amd.engine import ConvOp
+    from dd3d_amd.parallel import DistributedForward, init_distributed
+    from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
+    import torch.distributed as dist
+
+    rank, local, world = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
+    dev = torch.device("cuda", local)
+
+    cfg = get_cfg("dd3d_kitti_dla34")
+    model = build_model(cfg)
+    sd = make_state_dict(model, calib=load_calib("dla34_kitti"))
+    model.load_state_dict(sd)
+    B = args.batch
+    inputs = make_inputs(B, args.height, args.width, seed=1000 + rank * B)
+    runner = DistributedForward(model, B, *_padded(model, args.height, args.width), use_graph=not args.no_graph)
+    plan = runner.plan
+    model.stage_inputs(inputs, plan=plan)  # H2D once: inputs are resident in HBM when the timed region starts
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    out = {
+        "metric": "images/sec (384x1280) DD3D-DLA34 fwd", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"DD3D-DLA34 KITTI3D {args.height}x{args.width} bs={B}/GPU fp32 inference (BASELINE.json configs[1]); "
+                        "uint8 image in HBM -> normalise/pad -> DLA-34 -> FPN P3-P7 -> FCOS2D/3D heads -> select/decode -> NMS",
+            "global_batch": world * B, "parallelism": f"dp{world}" + ("+rccl_allgather_candidates" if world > 1 else ""),
+            "hip_graph": not args.no_graph, "gflop_per_image": GFLOP_PER_IMAGE,
+            "achieved_tflops_per_gpu": round(value / world * GFLOP_PER_IMAGE / 1e3, 2),
+            "frac_of_f32_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the head-tower launches (4 per forward, 66 % of all FLOPs)
+        towers = [op for op in plan.ops if isinstance(op, ConvOp) and op.name.startswith("towers.")]
+        us = sum(kernel_time_us(plan, op) for op in towers) / len(towers)
+        flops = 2.0 * towers[0].macs  # algorithmic: 2 * (sum over levels of B*H*W) * 3 towers * 256 * (9*256)
+        achieved = flops / (us * 1e-6) / 1e12
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {
+            "kernel": "dd3d::conv_igemm_f32_kernel<2,2,2,2,false> (head towers, 15 segments / launch)", "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": traffic, "flops_per_launch": flops, "avg_launch_us": round(us, 2), "tile": list(towers[0].info["tile"]),
+            "blocks": towers[0].info["blocks"],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _padded(model, H, W):
+    d = model.backbone.size_divisibility
+    return (H + d - 1) // d * d, (W + d - 1) // d * d
+
+
+def cpu_baseline(cfg, sd, args):
+    """The oracle (oracle/dd3d_oracle.py, a torch-CPU fp32 restatement of the reference forward) on the host cores:
+    1 warm-up + ``--cpu-forwards`` timed single-image forwards of the same workload."""
+    from dd3d_amd.synthetic import make_inputs
+    from oracle import dd3d_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    inputs = make_inputs(1, args.height, args.width)
+    with torch.no_grad():
+        O.dd3d_forward(sd, cfg, inputs)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_forwards):
+            O.dd3d_forward(sd, cfg, inputs)
+        dt = (time.perf_counter() - t0) / args.cpu_forwards
+    return {
+        "value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{args.cpu_forwards} forwards of 1 synthetic {args.height}x{args.width} image (after 1 warm-up), "
+                  f"torch {torch.__version__} CPU fp32, {threads} threads",
+    }
+
+
+if __name__ == "__main__":
+    main()

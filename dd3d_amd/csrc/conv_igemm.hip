@@ -233,16 +233,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
   }
 }
 
-// Split-K second pass: sum the partial slabs and apply the epilogue.  One block per m-tile, 16 B per lane.
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKArgs a, int BM) {
+// Split-K second pass: sum the partial slabs and apply the epilogue.  grid = (m-tiles, BM / 8): one block per 8 output rows,
+// 16 B per lane, so even a 30-tile layer spreads over the whole chip.
+constexpr int RED_ROWS = 8;
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKArgs a) {
   const int seg_id = a.tiles[2 * blockIdx.x];
-  const int m0 = a.tiles[2 * blockIdx.x + 1];
+  const int m0 = a.tiles[2 * blockIdx.x + 1] + blockIdx.y * RED_ROWS;
   const dd3d_conv_seg s = a.segs[seg_id];
   const gcfp g_ws = as_g(a.ws);
   const gcfp g_res = as_g(s.res);
   const gfp g_out = as_g(s.out);
   const int n4 = a.N4 >> 2;  // workspace rows are N4 = round_up(N, 4) floats wide; columns >= N are never written nor used
-  for (int idx = threadIdx.x; idx < BM * n4; idx += 256) {
+  for (int idx = threadIdx.x; idx < RED_ROWS * n4; idx += 256) {
     const int r = idx / n4;
     const int c = (idx - r * n4) * 4;
     const int m = m0 + r;
@@ -287,7 +289,7 @@ static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
   int rc = check_launch("conv_igemm_f32_kernel");
   if (rc != DD3D_OK) return rc;
   if (ka.splitk > 1) {
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ka.ntiles), dim3(256), 0, st, ka, BM);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ka.ntiles, BM / RED_ROWS), dim3(256), 0, st, ka);
     rc = check_launch("conv_splitk_reduce_kernel");
   }
   return rc;

@@ -117,11 +117,13 @@ def test_aux_kernels(hiplib):
     sizes = torch.tensor([[16, 24], [11, 19]], dtype=torch.int32)
     mean, std = [103.53, 116.28, 123.675], [57.375, 57.12, 58.395]
     dst = torch.empty((2, 16, 24, 4), device="cuda")
-    hip.check(hiplib.dd3d_preprocess_u8_nhwc4(img.cuda().data_ptr(), sizes.cuda().data_ptr(), dst.data_ptr(), 2, 16, 24,
+    img_d, sizes_d = img.cuda(), sizes.cuda()  # keep the device copies alive until the kernels have run
+    hip.check(hiplib.dd3d_preprocess_u8_nhwc4(img_d.data_ptr(), sizes_d.data_ptr(), dst.data_ptr(), 2, 16, 24,
                                               (C.c_float * 3)(*mean), (C.c_float * 3)(*std), hip.current_stream()))
     K = torch.tensor([[[748.7, 0.3, 632.5], [0, 748.8, 179.4], [0, 0, 1.0]], [[1260.9, 0, 812.7], [0, 1260.8, 489.3], [0, 0, 1]]])
     invK = torch.empty((2, 9), device="cuda")
-    hip.check(hiplib.dd3d_invert_intrinsics(K.cuda().data_ptr(), invK.data_ptr(), 2, hip.current_stream()))
+    K_d = K.cuda()
+    hip.check(hiplib.dd3d_invert_intrinsics(K_d.data_ptr(), invK.data_ptr(), 2, hip.current_stream()))
     torch.cuda.synchronize()
     ref = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
     ref[1, :, 11:, :] = 0
