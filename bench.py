@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-forwards", type=int, default=3)
+    ap.add_argument("--cpu-forwards", type=int, default=5)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_tower_hbm_bytes.json"),
                     help="optional PMC-derived HBM bytes per launch of the dominant kernel (see profiles/README.md)")
     return ap.parse_args()
@@ -156,24 +156,45 @@ def _padded(model, H, W):
     return (H + d - 1) // d * d, (W + d - 1) // d * d
 
 
-def cpu_baseline(cfg, sd, args):
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256 logical
+    CPUs to a container that is only allowed a fraction of them; 256 torch threads on that quota thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(cfg, sd, args, budget_s=25.0):
     """The oracle (oracle/dd3d_oracle.py, a torch-CPU fp32 restatement of the reference forward) on the host cores:
-    1 warm-up + ``--cpu-forwards`` timed single-image forwards of the same workload."""
+    one warm-up at 1/16 of the pixels, then single-image forwards of the bench workload until ~``budget_s`` of CPU
+    time is spent (at least one, at most ``--cpu-forwards``)."""
     from dd3d_amd.synthetic import make_inputs
     from oracle import dd3d_oracle as O
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     inputs = make_inputs(1, args.height, args.width)
     with torch.no_grad():
-        O.dd3d_forward(sd, cfg, inputs)
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_forwards):
+        O.dd3d_forward(sd, cfg, make_inputs(1, max(128, args.height // 4 // 128 * 128), max(128, args.width // 4 // 128 * 128)))
+        n, t0 = 0, time.perf_counter()
+        while n < args.cpu_forwards and (n == 0 or time.perf_counter() - t0 < budget_s * n / (n + 1)):
             O.dd3d_forward(sd, cfg, inputs)
-        dt = (time.perf_counter() - t0) / args.cpu_forwards
+            n += 1
+        dt = (time.perf_counter() - t0) / n
     return {
-        "value": round(1.0 / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{args.cpu_forwards} forwards of 1 synthetic {args.height}x{args.width} image (after 1 warm-up), "
-                  f"torch {torch.__version__} CPU fp32, {threads} threads",
+        "value": round(1.0 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+        "sample": f"{n} forward(s) of 1 synthetic {args.height}x{args.width} image (after a small warm-up), oracle/dd3d_oracle.py on "
+                  f"torch {torch.__version__} CPU fp32 with {threads} threads (os.cpu_count()={os.cpu_count()})",
     }
 
 

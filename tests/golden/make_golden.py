@@ -1,0 +1,103 @@
+"""Generate golden vectors by running the REAL reference forward (tridet.modeling.dd3d.core.DD3D from /root/reference)
+on CPU, on top of the third-party shims in ref_shims.py.  Run in the build container only (the reference tree does not
+exist on the GPU box); the .npz files it writes are committed and are what tests/test_oracle_golden.py checks the
+oracle (and, on the GPU, the HIP path) against.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+from tests.golden import ref_shims  # noqa: E402
+
+TRAINING_ONLY_KEYS = {  # keys the reference constructor reads for its loss / target modules (never used in inference)
+    "DD3D": {
+        "FCOS2D": {"LOSS": {"ALPHA": 0.25, "GAMMA": 2.0, "LOC_LOSS_TYPE": "giou"}},
+        "FCOS3D": {
+            "LOSS": {"SMOOTH_L1_BETA": 0.05, "MAX_LOSS_PER_GROUP_DISENT": 20.0, "CONF_3D_TEMPERATURE": 1.0, "WEIGHT_BOX3D": 2.0,
+                     "WEIGHT_CONF3D": 1.0},
+            "PREPARE_TARGET": {"CENTER_SAMPLE": True, "POS_RADIUS": 1.5}
+        }
+    }
+}
+
+CASES = {
+    # name: (experiment, calib tag, B, H, W, ragged)
+    "dla34_kitti_128x256_b1": ("dd3d_kitti_dla34", "dla34_kitti", 1, 128, 256, False),
+    "dla34_kitti_128x384_b2_ragged": ("dd3d_kitti_dla34", "dla34_kitti", 2, 128, 384, True),
+}
+
+
+def build_reference_model(cfg):
+    ref_shims.install()
+    from tridet.modeling.dd3d.core import DD3D  # the reference's own class
+    model = DD3D(cfg)
+    model.eval()
+    return model
+
+
+def case_inputs(B, H, W, ragged):
+    from dd3d_amd.synthetic import make_inputs
+    inputs = make_inputs(B, H, W)
+    if ragged:
+        inputs[1]["image"] = inputs[1]["image"][:, :H - 13, :W - 22].contiguous()
+        inputs[1]["height"], inputs[1]["width"] = 99, 301
+    return inputs
+
+
+def main():
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_state_dict
+    for name, (exp, tag, B, H, W, ragged) in CASES.items():
+        cfg = get_cfg(exp, TRAINING_ONLY_KEYS)
+        ours = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+        sd = make_state_dict(ours, calib=load_calib(tag))
+        ref = build_reference_model(cfg)
+        missing, unexpected = ref.load_state_dict(sd, strict=True)  # same key set, or this raises
+        inputs = case_inputs(B, H, W, ragged)
+        out = {}
+        with torch.no_grad():
+            # head maps through the reference's own modules (core.py:65-92)
+            from tridet.structures.image_list import ImageList
+            images = [ref.preprocess_image(x["image"].float()) for x in inputs]
+            il = ImageList.from_tensors(images, ref.backbone.size_divisibility, intrinsics=[x["intrinsics"] for x in inputs])
+            feats = ref.backbone(il.tensor)
+            feats = [feats[f] for f in ref.in_features]
+            logits, box2d_reg, centerness, _ = ref.fcos2d_head(feats)
+            quat, ctr, depth, size, conf, _ = ref.fcos3d_head(feats)
+            out["images"] = il.tensor.numpy()
+            for l in range(len(feats)):
+                if l >= 2:  # the fine levels are large; their content is covered by the head maps below
+                    out[f"feat{l}"] = feats[l].numpy()
+                out[f"logits{l}"], out[f"box2d_reg{l}"], out[f"centerness{l}"] = logits[l].numpy(), box2d_reg[l].numpy(), centerness[l].numpy()
+                out[f"quat{l}"], out[f"ctr{l}"], out[f"depth{l}"] = quat[l].numpy(), ctr[l].numpy(), depth[l].numpy()
+                out[f"size{l}"], out[f"conf{l}"] = size[l].numpy(), conf[l].numpy()
+            results = ref(inputs)  # full DD3D.forward incl. NMS / top-k / resize
+        for i, r in enumerate(results):
+            inst = r["instances"]
+            out[f"det{i}_image_size"] = np.array(inst.image_size)
+            out[f"det{i}_boxes"] = inst.pred_boxes.tensor.numpy()
+            out[f"det{i}_scores"] = inst.scores.numpy()
+            out[f"det{i}_scores_3d"] = inst.scores_3d.numpy()
+            out[f"det{i}_classes"] = inst.pred_classes.numpy()
+            out[f"det{i}_levels"] = inst.fpn_levels.numpy()
+            out[f"det{i}_locations"] = inst.locations.numpy()
+            b3 = inst.pred_boxes3d
+            out[f"det{i}_quat"], out[f"det{i}_proj_ctr"] = b3.quat.numpy(), b3.proj_ctr.numpy()
+            out[f"det{i}_depth"], out[f"det{i}_size"] = b3.depth.numpy(), b3.size.numpy()
+            out[f"det{i}_tvec"] = b3.tvec.numpy()
+            out[f"det{i}_vectorize"] = b3.vectorize().numpy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", [len(r["instances"]) for r in results])
+
+
+if __name__ == "__main__":
+    main()

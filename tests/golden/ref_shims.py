@@ -1,0 +1,384 @@
+"""Shims that let the REAL reference modules (/root/reference/tridet/...) be imported in this image.
+
+detectron2 / fvcore / pytorch3d / pyquaternion / mpi4py / cv2 are not installed (and there is no network).  The
+reference's forward path only needs a thin slice of them; this file installs stand-in modules for exactly that slice
+into ``sys.modules`` so that ``tridet.modeling.dd3d.core.DD3D`` -- the reference's own code -- can be constructed
+and run on CPU to produce golden vectors (tests/golden/make_golden.py).
+
+What that pins and what it does not:
+  * pinned: every line of the in-repo path (core.py, fcos2d.py, fcos3d.py, dla.py, normalization.py, boxes3d.py,
+    image_list.py, geometry.py, tensor2d.py) runs as written by the reference authors;
+  * NOT pinned: the third-party pieces below are re-statements of the published behaviour of detectron2 v0.5/0.6,
+    torchvision 0.10 and pytorch3d 0.5/0.6 -- "[ext] parity unpinned".
+
+Test infrastructure only; never imported by dd3d_amd.
+"""
+import functools
+import math
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+REFERENCE_ROOT = os.environ.get("DD3D_REFERENCE_ROOT", "/root/reference")
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    parent, _, child = name.rpartition(".")
+    if parent:
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+# --------------------------------------------------------------------------------------------- detectron2.layers [ext]
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def forward(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, training=False, eps=self.eps)
+
+
+def get_norm(norm, out_channels):
+    if norm is None or (isinstance(norm, str) and len(norm) == 0):
+        return None
+    return {"BN": nn.BatchNorm2d, "FrozenBN": FrozenBatchNorm2d}[norm](out_channels)
+
+
+class Conv2d(nn.Conv2d):
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+class ShapeSpec(tuple):
+    def __new__(cls, channels=None, height=None, width=None, stride=None):
+        self = super().__new__(cls, (channels, height, width, stride))
+        return self
+
+    channels = property(lambda s: s[0])
+    height = property(lambda s: s[1])
+    width = property(lambda s: s[2])
+    stride = property(lambda s: s[3])
+
+
+def cat(tensors, dim=0):
+    if len(tensors) == 1:
+        return tensors[0]
+    return torch.cat(tensors, dim)
+
+
+def _nms(boxes, scores, thr):
+    from oracle.dd3d_oracle import nms
+    return nms(boxes, scores, thr)
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    from oracle.dd3d_oracle import batched_nms as _b
+    return _b(boxes, scores, idxs, iou_threshold)
+
+
+# --------------------------------------------------------------------------------------------- registries / config
+class Registry:
+    def __init__(self, name):
+        self._name, self._obj_map = name, {}
+
+    def register(self, obj=None):
+        if obj is None:
+
+            def deco(f):
+                self._obj_map[f.__name__] = f
+                return f
+
+            return deco
+        self._obj_map[obj.__name__] = obj
+
+    def get(self, name):
+        return self._obj_map[name]
+
+
+def configurable(init_func):
+    """[ext] detectron2.config.configurable for __init__: called with a cfg first -> cls.from_config(cfg, ...)."""
+    @functools.wraps(init_func)
+    def wrapped(self, *args, **kwargs):
+        first = args[0] if args else kwargs.get("cfg")
+        if first is not None and hasattr(first, "keys") and hasattr(type(self), "from_config"):
+            explicit = type(self).from_config(*args, **kwargs)
+            init_func(self, **explicit)
+        else:
+            init_func(self, *args, **kwargs)
+
+    return wrapped
+
+
+# --------------------------------------------------------------------------------------------- backbone / FPN [ext]
+class Backbone(nn.Module):
+    def output_shape(self):
+        return {
+            name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+            for name in self._out_features
+        }
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+
+class LastLevelMaxPool(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.num_levels, self.in_feature = 1, "p5"
+
+    def forward(self, x):
+        return [F.max_pool2d(x, kernel_size=1, stride=2, padding=0)]
+
+
+def _xavier(m):
+    nn.init.kaiming_uniform_(m.weight, a=1)
+    if m.bias is not None:
+        nn.init.constant_(m.bias, 0)
+
+
+class LastLevelP6P7(nn.Module):
+    def __init__(self, in_channels, out_channels, in_feature="res5"):
+        super().__init__()
+        self.num_levels, self.in_feature = 2, in_feature
+        self.p6 = nn.Conv2d(in_channels, out_channels, 3, 2, 1)
+        self.p7 = nn.Conv2d(out_channels, out_channels, 3, 2, 1)
+        _xavier(self.p6), _xavier(self.p7)
+
+    def forward(self, c5):
+        p6 = self.p6(c5)
+        p7 = self.p7(F.relu(p6))
+        return [p6, p7]
+
+
+class FPN(Backbone):
+    def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
+        super().__init__()
+        input_shapes = bottom_up.output_shape()
+        strides = [input_shapes[f].stride for f in in_features]
+        in_channels_per_feature = [input_shapes[f].channels for f in in_features]
+        lateral_convs, output_convs = [], []
+        use_bias = norm == ""
+        for idx, in_channels in enumerate(in_channels_per_feature):
+            lateral_conv = Conv2d(in_channels, out_channels, kernel_size=1, bias=use_bias, norm=get_norm(norm, out_channels))
+            output_conv = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=use_bias,
+                                 norm=get_norm(norm, out_channels))
+            _xavier(lateral_conv), _xavier(output_conv)
+            stage = int(math.log2(strides[idx]))
+            self.add_module("fpn_lateral{}".format(stage), lateral_conv)
+            self.add_module("fpn_output{}".format(stage), output_conv)
+            lateral_convs.append(lateral_conv)
+            output_convs.append(output_conv)
+        self.lateral_convs = lateral_convs[::-1]
+        self.output_convs = output_convs[::-1]
+        self.top_block = top_block
+        self.in_features = tuple(in_features)
+        self.bottom_up = bottom_up
+        self._out_feature_strides = {"p{}".format(int(math.log2(s))): s for s in strides}
+        if self.top_block is not None:
+            for s in range(stage, stage + self.top_block.num_levels):
+                self._out_feature_strides["p{}".format(s + 1)] = 2**(s + 1)
+        self._out_features = list(self._out_feature_strides.keys())
+        self._out_feature_channels = {k: out_channels for k in self._out_features}
+        self._size_divisibility = strides[-1]
+        self._fuse_type = fuse_type
+
+    # plain python lists of registered modules must not be registered twice
+    def __setattr__(self, k, v):
+        if k in ("lateral_convs", "output_convs"):
+            object.__setattr__(self, k, v)
+        else:
+            super().__setattr__(k, v)
+
+    @property
+    def size_divisibility(self):
+        return self._size_divisibility
+
+    def forward(self, x):
+        bottom_up_features = self.bottom_up(x)
+        results = []
+        prev_features = self.lateral_convs[0](bottom_up_features[self.in_features[-1]])
+        results.append(self.output_convs[0](prev_features))
+        for idx, (lateral_conv, output_conv) in enumerate(zip(self.lateral_convs, self.output_convs)):
+            if idx > 0:
+                features = bottom_up_features[self.in_features[-idx - 1]]
+                top_down_features = F.interpolate(prev_features, scale_factor=2.0, mode="nearest")
+                lateral_features = lateral_conv(features)
+                prev_features = lateral_features + top_down_features
+                if self._fuse_type == "avg":
+                    prev_features /= 2
+                results.insert(0, output_conv(prev_features))
+        if self.top_block is not None:
+            if self.top_block.in_feature in bottom_up_features:
+                top_block_in_feature = bottom_up_features[self.top_block.in_feature]
+            else:
+                top_block_in_feature = results[self._out_features.index(self.top_block.in_feature)]
+            results.extend(self.top_block(top_block_in_feature))
+        assert len(self._out_features) == len(results)
+        return {f: res for f, res in zip(self._out_features, results)}
+
+
+def detector_postprocess(results, output_height, output_width, mask_threshold=0.5):
+    from dd3d_amd.structures import Instances
+    scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
+    results = Instances((output_height, output_width), **results.get_fields())
+    boxes = results.pred_boxes
+    boxes.tensor[:, 0::2] *= scale_x
+    boxes.tensor[:, 1::2] *= scale_y
+    h, w = results.image_size
+    boxes.tensor[:, 0].clamp_(min=0, max=w)
+    boxes.tensor[:, 1].clamp_(min=0, max=h)
+    boxes.tensor[:, 2].clamp_(min=0, max=w)
+    boxes.tensor[:, 3].clamp_(min=0, max=h)
+    return results[boxes.nonempty()]
+
+
+# --------------------------------------------------------------------------------------------- pytorch3d [ext]
+class _T3D:
+    def __init__(self, *a, **k):
+        raise NotImplementedError("pytorch3d Transform3d shim: only needed by Boxes3D.corners / BEV NMS")
+
+
+class Quaternion:
+    """[ext] the slice of pyquaternion.Quaternion that tridet/structures/pose.py uses (w, x, y, z; numpy float64)."""
+    def __init__(self, *args, **kwargs):
+        import numpy as np
+        if "matrix" in kwargs:
+            m = np.asarray(kwargs["matrix"], dtype=np.float64)[:3, :3]
+            # pyquaternion._from_matrix: trace method (Shepperd)
+            t = np.trace(m)
+            if t > 0:
+                s = 0.5 / np.sqrt(t + 1.0)
+                q = [0.25 / s, (m[2, 1] - m[1, 2]) * s, (m[0, 2] - m[2, 0]) * s, (m[1, 0] - m[0, 1]) * s]
+            elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+                s = 2.0 * np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2])
+                q = [(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s]
+            elif m[1, 1] > m[2, 2]:
+                s = 2.0 * np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2])
+                q = [(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s]
+            else:
+                s = 2.0 * np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1])
+                q = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
+            self.q = np.asarray(q, dtype=np.float64)
+        elif len(args) == 1 and isinstance(args[0], Quaternion):
+            self.q = args[0].q.copy()
+        elif len(args) == 1:
+            self.q = np.asarray(args[0], dtype=np.float64).reshape(4).copy()
+        elif len(args) == 4:
+            self.q = np.asarray(args, dtype=np.float64)
+        else:
+            self.q = np.array([1.0, 0.0, 0.0, 0.0])
+
+    elements = property(lambda s: s.q)
+
+    def __mul__(self, o):
+        import numpy as np
+        w1, x1, y1, z1 = self.q
+        w2, x2, y2, z2 = o.q
+        return Quaternion(np.array([
+            w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+            w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2
+        ]))
+
+    @property
+    def inverse(self):
+        import numpy as np
+        return Quaternion(self.q * np.array([1.0, -1.0, -1.0, -1.0]) / float(self.q @ self.q))
+
+    @property
+    def rotation_matrix(self):
+        import numpy as np
+        w, x, y, z = self.q / np.linalg.norm(self.q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    @property
+    def transformation_matrix(self):
+        import numpy as np
+        t = np.eye(4)
+        t[:3, :3] = self.rotation_matrix
+        return t
+
+    def rotate(self, v):
+        import numpy as np
+        return self.rotation_matrix @ np.asarray(v, dtype=np.float64)
+
+
+def install():
+    """Install every shim module and make ``tridet`` importable without running its package __init__ chains."""
+    if "detectron2" in sys.modules and getattr(sys.modules["detectron2"], "_dd3d_shim", False):
+        return
+    from dd3d_amd.structures import Boxes, Instances
+    from oracle import dd3d_oracle as O
+    d2 = _mod("detectron2", _dd3d_shim=True)
+    _mod("detectron2.config", configurable=configurable)
+    _mod("detectron2.layers", Conv2d=Conv2d, get_norm=get_norm, FrozenBatchNorm2d=FrozenBatchNorm2d, ShapeSpec=ShapeSpec, cat=cat,
+         batched_nms=batched_nms)
+
+    def _no_rot(*a, **k):
+        raise NotImplementedError("nms_rotated shim")
+
+    _mod("detectron2.layers.nms", batched_nms_rotated=_no_rot)
+    _mod("detectron2.structures", Boxes=Boxes, Instances=Instances, RotatedBoxes=type("RotatedBoxes", (), {}))
+    _mod("detectron2.utils")
+    _mod("detectron2.utils.comm", get_world_size=lambda: 1, get_rank=lambda: 0, is_main_process=lambda: True, synchronize=lambda: None)
+    _mod("detectron2.utils.env", TORCH_VERSION=tuple(int(x) for x in torch.__version__.split(".")[:2]))
+    _mod("detectron2.modeling")
+    _mod("detectron2.modeling.meta_arch")
+    meta = Registry("META_ARCH")
+    bb = Registry("BACKBONE")
+    _mod("detectron2.modeling.meta_arch.build", META_ARCH_REGISTRY=meta)
+    _mod("detectron2.modeling.backbone", BACKBONE_REGISTRY=bb, FPN=FPN, Backbone=Backbone)
+    _mod("detectron2.modeling.backbone.build", BACKBONE_REGISTRY=bb)
+    _mod("detectron2.modeling.backbone.fpn", FPN=FPN, LastLevelMaxPool=LastLevelMaxPool, LastLevelP6P7=LastLevelP6P7)
+    _mod("detectron2.modeling.postprocessing", detector_postprocess=detector_postprocess)
+
+    def c2_msra_fill(m):
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    _mod("fvcore")
+    _mod("fvcore.nn", sigmoid_focal_loss=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("training only")))
+    _mod("fvcore.nn.weight_init", c2_msra_fill=c2_msra_fill, c2_xavier_fill=_xavier)
+    _mod("pytorch3d")
+    _mod("pytorch3d.transforms")
+    _mod("pytorch3d.transforms.rotation_conversions", quaternion_to_matrix=O.quaternion_to_matrix,
+         matrix_to_quaternion=O.matrix_to_quaternion)
+    _mod("pytorch3d.transforms.transform3d", Translate=_T3D, Rotate=_T3D, Transform3d=_T3D)
+    _mod("pyquaternion", Quaternion=Quaternion)
+    _mod("mpi4py", MPI=types.SimpleNamespace(COMM_WORLD=None))
+    _mod("cv2")
+    # tridet packages as bare namespaces (their __init__ chains pull in data / TTA / visualisation code)
+    for pkg in ("tridet", "tridet.modeling", "tridet.modeling.dd3d", "tridet.utils", "tridet.structures"):
+        m = _mod(pkg)
+        m.__path__ = [os.path.join(REFERENCE_ROOT, *pkg.split("."))]
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    return d2

@@ -1,0 +1,119 @@
+"""Pins the oracle: (1) against golden vectors produced by the REAL reference code (tests/golden/make_golden.py ran
+tridet.modeling.dd3d.core.DD3D from /root/reference on CPU, third-party packages shimmed), (2) through
+data-free self-consistency checks of the re-stated third-party arithmetic ([ext]: nms, rotation conversions, norms)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dd3d_oracle as O
+from tests.golden.make_golden import CASES, case_inputs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_golden(kitti_dla34, name):
+    cfg, _, sd = kitti_dla34
+    exp, tag, B, H, W, ragged = CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    inputs = case_inputs(B, H, W, ragged)
+    with torch.no_grad():
+        res, st = O.dd3d_forward(sd, cfg, inputs)
+    t = lambda k: torch.from_numpy(g[k])
+    assert torch.equal(st["images"], t("images"))
+    for l in range(5):
+        if f"feat{l}" in g:
+            assert torch.allclose(st["features"][l], t(f"feat{l}"), rtol=1e-5, atol=1e-5)
+        for k in ("logits", "box2d_reg", "centerness", "quat", "ctr", "depth", "size", "conf"):
+            assert torch.allclose(st[k][l], t(f"{k}{l}"), rtol=1e-5, atol=2e-5), (k, l)
+    for i in range(B):
+        r = res[i]
+        assert len(r["scores"]) == len(g[f"det{i}_scores"]) > 0
+        assert torch.equal(r["pred_classes"], t(f"det{i}_classes")) and torch.equal(r["fpn_levels"], t(f"det{i}_levels"))
+        assert torch.equal(r["locations"], t(f"det{i}_locations"))
+        assert torch.allclose(r["pred_boxes"], t(f"det{i}_boxes"), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(r["scores"], t(f"det{i}_scores"), rtol=1e-5) and torch.allclose(r["scores_3d"], t(f"det{i}_scores_3d"), rtol=1e-5)
+        b = r["pred_boxes3d"]
+        assert torch.allclose(b["quat"], t(f"det{i}_quat"), atol=1e-5)  # same matrix_to_quaternion => same sign
+        assert torch.allclose(b["proj_ctr"], t(f"det{i}_proj_ctr"), rtol=1e-5, atol=1e-4)
+        assert torch.allclose(b["depth"], t(f"det{i}_depth"), rtol=1e-5) and torch.allclose(b["size"], t(f"det{i}_size"), rtol=1e-5)
+        assert torch.allclose(O.boxes3d_tvec(b), t(f"det{i}_tvec"), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(O.boxes3d_vectorize(b), t(f"det{i}_vectorize"), rtol=1e-5, atol=1e-5)
+
+
+def test_rotation_conversions_roundtrip():
+    g = torch.Generator().manual_seed(0)
+    q = F.normalize(torch.randn(500, 4, generator=g), dim=1)
+    R = O.quaternion_to_matrix(q)
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(500, 3, 3), atol=1e-5)
+    assert torch.allclose(torch.linalg.det(R), torch.ones(500), atol=1e-5)
+    q2 = O.matrix_to_quaternion(R)
+    assert torch.allclose(O.quaternion_to_matrix(q2), R, atol=1e-5)  # M(Q(R)) == R
+    assert float(torch.minimum((q - q2).abs().amax(1), (q + q2).abs().amax(1)).max()) < 1e-5  # equal up to sign
+
+
+def test_corners_match_direct_formula():
+    g = torch.Generator().manual_seed(1)
+    q = F.normalize(torch.randn(20, 4, generator=g), dim=1)
+    t, s = torch.randn(20, 3, generator=g), torch.rand(20, 3, generator=g) + 0.5
+    c = O.boxes3d_corners(q, t, s)
+    R = O.quaternion_to_matrix(q)
+    first = torch.einsum("nij,nj->ni", R, 0.5 * s[:, [1, 0, 2]]) + t  # corner 0 = (+l/2, +w/2, +h/2)
+    assert torch.allclose(c[:, 0], first, atol=1e-5)
+    assert torch.allclose(c.mean(1), t, atol=1e-5)  # centroid of the 8 corners is the box centre
+
+
+def test_nms_against_brute_force():
+    g = torch.Generator().manual_seed(2)
+    xy = torch.rand(300, 2, generator=g) * 100
+    wh = torch.rand(300, 2, generator=g) * 40 + 1
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.rand(300, generator=g)
+    keep = O.nms(boxes, scores, 0.5).tolist()
+    order = scores.argsort(descending=True).tolist()
+    alive, ref = set(order), []
+    for i in order:  # O(n^2) greedy on a full IoU matrix
+        if i not in alive:
+            continue
+        ref.append(i)
+        for j in list(alive):
+            if j == i:
+                continue
+            lt, rb = torch.maximum(boxes[i, :2], boxes[j, :2]), torch.minimum(boxes[i, 2:], boxes[j, 2:])
+            inter = (rb - lt).clamp(min=0).prod()
+            a = (boxes[i, 2:] - boxes[i, :2]).prod() + (boxes[j, 2:] - boxes[j, :2]).prod() - inter
+            if inter / a > 0.5 and scores[j] <= scores[i]:
+                alive.discard(j)
+    assert keep == ref
+    # batched: boxes of different classes never suppress each other, in both torchvision branches
+    idxs = torch.randint(0, 3, (300, ), generator=g)
+    k1 = O.batched_nms(boxes, scores, idxs, 0.5)
+    expect = sorted(sum([(torch.where(idxs == c)[0][O.nms(boxes[idxs == c], scores[idxs == c], 0.5)]).tolist() for c in range(3)], []))
+    assert sorted(k1.tolist()) == expect
+    big = torch.cat([boxes] * 4), torch.cat([scores, scores * 0.9, scores * 0.8, scores * 0.7]), torch.cat([idxs, idxs + 3, idxs + 6, idxs + 9])
+    assert big[0].numel() > 4000  # per-class branch
+    k2 = O.batched_nms(*big, 0.5)
+    assert bool((big[1][k2][:-1] >= big[1][k2][1:]).all()) and len(k2) == 4 * len(k1)
+
+
+def test_batch_norm_eval_is_the_folded_affine():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 5, 7, generator=g)
+    sd = {"n.weight": torch.rand(8, generator=g) + 0.5, "n.bias": torch.randn(8, generator=g), "n.running_mean": torch.randn(8, generator=g),
+          "n.running_var": torch.rand(8, generator=g) + 0.5}
+    y = O.batch_norm_eval(sd, "n", x)
+    s = sd["n.weight"] * torch.rsqrt(sd["n.running_var"] + 1e-5)
+    ref = x * s.view(1, -1, 1, 1) + (sd["n.bias"] - sd["n.running_mean"] * s).view(1, -1, 1, 1)
+    assert torch.allclose(y, ref, atol=1e-5)
+
+
+def test_identity_intrinsics_guard(kitti_dla34):
+    from dd3d_amd.synthetic import make_inputs
+    cfg, _, sd = kitti_dla34
+    inputs = make_inputs(1, 128, 128)
+    inputs[0]["intrinsics"] = torch.eye(3)
+    with pytest.raises(ValueError, match="Intrinsics is Identity"):
+        O.dd3d_forward(sd, cfg, inputs)
