@@ -4,24 +4,30 @@
 // GEMM view:  M = B*Ho*Wo output pixels (rows), N = Cout, K = KH*KW*Cin.
 //   A[m,k]   gathered on the fly from the NHWC input (im2col never materialised),
 //   Wp[n,k]  packed filter, k contiguous,
-// both staged per K-tile (BK = 32) through LDS in [row][BK+4] images and read back as
-// ds_read_b128 fragments: lane l supplies row (l&31) and the 4 consecutive k at 8*s + 4*(l>>5),
-// so one 16-byte LDS read feeds four MFMAs.  Each K-tile is (channel-chunk, filter tap), tap
-// fastest, so the nine taps of a 3x3 filter re-read the same input lines back-to-back (L1/L2 hits).
+// both staged per K-tile (BK = 32) through LDS and read back as ds_read_b128 fragments: lane l supplies row (l&31)
+// and the 4 consecutive k at 8*s + 4*(l>>5), so one 16-byte LDS read feeds four MFMAs.  Each K-tile is
+// (channel-chunk, filter tap), tap fastest, so the nine taps of a 3x3 filter re-read the same input lines
+// back-to-back (L1/L2 hits).
 //
-// One launch covers many *segments* (FPN levels x head towers) through a tile table, so the tiny
-// P6/P7 levels ride along with P3 instead of costing their own under-filled launches, and the
-// per-level BatchNorm of the shared towers becomes a per-segment (scale, bias) epilogue.
+// One launch covers many *segments* (FPN levels x head towers) through a tile table, so the tiny P6/P7 levels ride
+// along with P3 instead of costing their own under-filled launches, and the per-level BatchNorm of the shared towers
+// becomes a per-segment (scale, bias) epilogue.
 //
-// Block = 256 threads = 4 wave64; block tile = (TM*32*WM) x (TN*32*WN); double-buffered LDS with
-// register prefetch of the next K-tile; 1-D grid remapped so that blocks that share input rows run
-// on the same XCD (private L2).
+// Two kernels share the tiling, the XCD-aware block remap and the epilogue:
+//   conv_igemm_f32_kernel      register-staged (global -> VGPR -> padded LDS rows).  Handles every Cin (4, 16, 32k);
+//                              used for the Cin < 32 stem layers and, by default, for the 128x128 head-tower tile.
+//   conv_igemm_f32_dma_kernel  LDS-DMA (global_load_lds_dwordx4) into a multi-stage swizzled ring with counted vmcnt
+//                              waits and raw barriers; Cin % 32 == 0 only; used for every other layer.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace dd3d {
 
 constexpr int BK = 32;
-constexpr int LDS_ROW = BK + 4;  // floats per LDS row: 144 B keeps the 16-B slots of 16 rows distinct mod 256 B
+constexpr int LDS_ROW = BK + 4;  // register-staged kernel: 144-B rows keep the 16-B slots of 16 rows distinct mod 256 B
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -36,7 +42,8 @@ struct ConvKArgs {
   int cc_shift;  // log2(CC) when Cin < 32
   int kw_magic;  // (65536 / KW) + 1 : tap / KW == (tap * kw_magic) >> 16 for tap < 64
   int relu, splitk, ws_rows, kt_per_split;
-  int N4;  // round_up(N, 4): row stride of the split-K workspace
+  int N4;              // round_up(N, 4): row stride of the split-K workspace
+  const float* zeros;  // >= 128 B of zeros (source of padded taps for the LDS-DMA kernel)
 };
 
 // Global-address-space views: the segment descriptor is loaded from memory, so without these casts the compiler
@@ -44,11 +51,67 @@ struct ConvKArgs {
 typedef const float __attribute__((address_space(1))) * gcfp;
 typedef float __attribute__((address_space(1))) * gfp;
 typedef const f32x4 __attribute__((address_space(1))) * gcf4p;
-typedef f32x4 __attribute__((address_space(1))) * gf4p;
 __device__ __forceinline__ gcfp as_g(const float* p) { return (gcfp)p; }
 __device__ __forceinline__ gfp as_g(float* p) { return (gfp)p; }
 
-template <int TM, int TN, int WM, int WN, bool SMALLC>
+// XCD-aware block remap (bijective): blocks dispatched to the same XCD (bid % 8) get a contiguous range of logical
+// tiles, n fastest, so the n-tiles that share an A row band hit the same (private, per-XCD) L2.
+__device__ __forceinline__ int remap_block(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Epilogue shared by both kernels.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+//   out = max(lo, acc*scale + bias (+ residual));  one lane owns one output channel per 32-wide column block.
+// Split-K launches store the raw partial sums to the workspace instead.
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                              int wm, int wn, int lane) {
+  const gcfp g_res = as_g(s.res);
+  const gfp g_out = as_g(s.out);
+  const gfp g_ws = as_g(a.ws);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    if (n >= a.N) continue;
+    float sc = 1.f, bi = 0.f, lo = -INFINITY;
+    if (a.splitk == 1) {
+      sc = as_g(s.scale)[n];
+      bi = as_g(s.bias)[n];
+      if (s.lo) lo = as_g(s.lo)[n];
+      if (a.relu) lo = fmaxf(lo, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+      if (a.splitk > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < s.M) g_ws[((long)blockIdx.y * a.ws_rows + s.ws_row0 + m) * a.N4 + n] = acc[i][j][r];
+        }
+      } else {
+        float rv[16];  // residuals first, all 16 loads in flight together (they must not queue behind the stores)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          rv[r] = (s.res_mode == 1 && m < s.M) ? g_res[(long)m * s.res_pitch + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < s.M) g_out[(long)m * s.out_pitch + n] = fmaxf(acc[i][j][r] * sc + bi + rv[r], lo);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Register-staged kernel.  Block = 256 threads = 4 wave64; block tile = (TM*32*WM) x (TN*32*WN); double-buffered LDS.
+// PIPE 0: one staging register set (load kt+1 -> MFMA kt -> LDS store kt+1 -> barrier).
+// PIPE 2: two staging sets, prefetch distance 2, raw barriers (global loads stay in flight across them).
+template <int TM, int TN, int WM, int WN, bool SMALLC, int PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) {
   constexpr int BM = TM * 32 * WM;
   constexpr int BN = TN * 32 * WN;
@@ -63,14 +126,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
   const int wm = wave / WN;
   const int wn = wave - wm * WN;
 
-  // ---- XCD-aware block remap (bijective): blocks dispatched to the same XCD (bid % 8) get a contiguous range of
-  //      logical tiles, n fastest, so the n-tiles that share an A row band hit the same L2.
-  const int nwg = a.ntiles * a.nn;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
+  const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
   const int mt = bid / a.nn;
   const int nt = bid - mt * a.nn;
   const int seg_id = a.tiles[2 * mt];
@@ -113,10 +169,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
     }
   }
 
-  f32x4 ra[AP], rb[BP];
+  // Staging registers.  All loads are unconditional (invalid taps / rows read a safe address and are zeroed at LDS-store
+  // time) so the compiler can keep exact vmcnt counts instead of draining the queue at every branch.
+  constexpr int NSET = PIPE == 2 ? 2 : 1;
+  f32x4 ra[NSET][AP], rb[NSET][BP];
+  unsigned amask[NSET];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     int dh, dw, tap_ok = 1;
     long koff;
     if (SMALLC) {  // Cin in {4,16}: one K-tile spans several taps -> per-thread tap
@@ -134,27 +195,38 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
       dw = tap - dh * a.KW;
       koff = ((long)dh * s.W + dw) * s.in_pitch + chunk * BK + avec * 4;
     }
+    unsigned mask = 0;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool ok = tap_ok && (unsigned)(a_hi0[p] + dh) < (unsigned)s.H && (unsigned)(a_wi0[p] + dw) < (unsigned)s.W;
-      ra[p] = zero4;
-      if (ok) ra[p] = *(gcf4p)(g_in + a_base[p] + koff);
+      mask |= (unsigned)ok << p;
+      ra[S][p] = *(gcf4p)(g_in + (ok ? a_base[p] + koff : (long)(avec * 4)));
     }
+    amask[S] = mask;
 #pragma unroll
     for (int p = 0; p < BP; ++p) {
-      const int n = n0 + p * 32 + arow;
-      rb[p] = zero4;
-      if (n < a.Npad) rb[p] = *(gcf4p)(g_w + (long)n * a.Kpad + kt * BK + avec * 4);
+      const int n = min(n0 + p * 32 + arow, a.Npad - 1);  // rows past Npad feed columns >= N, which are never stored
+      rb[S][p] = *(gcf4p)(g_w + (long)n * a.Kpad + kt * BK + avec * 4);
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     float* As = smem + buf * (BM + BN) * LDS_ROW;
     float* Bs = As + BM * LDS_ROW;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(As + (p * 32 + arow) * LDS_ROW + avec * 4) = ra[p];
+    for (int p = 0; p < AP; ++p)
+      *reinterpret_cast<f32x4*>(As + (p * 32 + arow) * LDS_ROW + avec * 4) = ((amask[S] >> p) & 1u) ? ra[S][p] : zero4;
 #pragma unroll
-    for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(Bs + (p * 32 + arow) * LDS_ROW + avec * 4) = rb[p];
+    for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(Bs + (p * 32 + arow) * LDS_ROW + avec * 4) = rb[S][p];
+  };
+  constexpr std::integral_constant<int, 0> SET0{};
+  constexpr std::integral_constant<int, NSET - 1> SET1{};
+  // barrier that leaves global loads in flight: LDS traffic of this wave done, then s_barrier (no vmcnt drain)
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   };
 
   f32x16 acc[TM][TN];
@@ -168,73 +240,282 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
   const int lrow = lane & 31;
   const int lk = (lane >> 5) * 4;
 
+  auto compute_tile = [&](int cur) {
+    const float* As = smem + cur * (BM + BN) * LDS_ROW + (wm * TM * 32 + lrow) * LDS_ROW + lk;
+    const float* Bs = smem + cur * (BM + BN) * LDS_ROW + BM * LDS_ROW + (wn * TN * 32 + lrow) * LDS_ROW + lk;
+#pragma unroll
+    for (int s4 = 0; s4 < BK / 8; ++s4) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_ROW + s4 * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_ROW + s4 * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+  };
+
   if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int cur = (kt - kt_begin) & 1;
-      const bool more = kt + 1 < kt_end;
-      if (more) load_tile(kt + 1);  // global -> registers, in flight under the MFMAs below
-      const float* As = smem + cur * (BM + BN) * LDS_ROW + (wm * TM * 32 + lrow) * LDS_ROW + lk;
-      const float* Bs = smem + cur * (BM + BN) * LDS_ROW + BM * LDS_ROW + (wn * TN * 32 + lrow) * LDS_ROW + lk;
-#pragma unroll
-      for (int s4 = 0; s4 < BK / 8; ++s4) {
-        f32x4 af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_ROW + s4 * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_ROW + s4 * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-      }
-      if (more) store_tile(cur ^ 1);
+    if (PIPE == 0) {
+      load_tile(kt_begin, SET0);
+      store_tile(0, SET0);
       __syncthreads();
+      for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1, SET0);  // global -> registers, in flight under the MFMAs below
+        compute_tile(cur);
+        if (more) store_tile(cur ^ 1, SET0);
+        __syncthreads();
+      }
+    } else {
+      // Every load / LDS store below is unconditional (indices are clamped to the last K-tile, the surplus data lands
+      // in a buffer nobody reads) so that the compiler keeps exact vmcnt counts.
+      const int kt_last = kt_end - 1;
+      load_tile(kt_begin, SET0);
+      load_tile(min(kt_begin + 1, kt_last), SET1);
+      store_tile(0, SET0);
+      load_tile(min(kt_begin + 2, kt_last), SET0);
+      lds_barrier();
+      for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        store_tile(1, SET1);
+        load_tile(min(kt + 3, kt_last), SET1);
+        compute_tile(0);
+        lds_barrier();
+        if (kt + 1 >= kt_end) break;
+        store_tile(0, SET0);
+        load_tile(min(kt + 4, kt_last), SET0);
+        compute_tile(1);
+        lds_barrier();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must not outlive the staging registers
     }
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-  //      out = max(lo, acc*scale + bias (+ residual)); one lane owns one output channel per 32-wide column block.
-  const gcfp g_res = as_g(s.res);
-  const gfp g_out = as_g(s.out);
-  const gfp g_ws = as_g(a.ws);
+  conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA kernel (Cin % 32 == 0): the K-tiles are streamed L2/HBM -> LDS with global_load_lds_dwordx4 (no staging VGPRs,
+// no ds_write pass) into a ring of NS stages; U tiles are consumed per raw barrier, NS-U tiles are in flight, and the
+// wait before the barrier is a COUNTED vmcnt (never a drain inside the loop).
+//
+// LDS image of a stage: rows of 32 floats (128 B, unpadded because the DMA writes lane-linear: one wave instruction =
+// 8 rows x 128 B = 1 KiB), 16-byte slots XOR-swizzled with (row & 7): slot s of row r holds k-chunk s ^ (r & 7).  The
+// permutation is applied on the per-lane SOURCE address of the DMA and again on the ds_read_b128 address (same
+// involution).  Out-of-image taps and rows >= M read a zero page.
+//
+// WK = 1: 4 waves, each owns a (TM*32)x(TN*32) output sub-tile.  WK = 2: 8 waves; waves w and w+4 own the SAME sub-tile
+// and split every K-tile's four k-steps between them (partial sums merged through LDS at the end), so that the
+// small-tile layers (<= 256 blocks, one block per CU) still put two waves on every SIMD.
+template <int TM, int TN, int WM, int WN, int NS, int U, int WK>
+__global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const ConvKArgs a) {
+  constexpr int BM = TM * 32 * WM;
+  constexpr int BN = TN * 32 * WN;
+  constexpr int STAGE = (BM + BN) * BK;  // floats per stage
+  constexpr int NW = 4 * WK;             // waves per block
+  constexpr int PA = BM / (8 * NW);      // 1-KiB A pieces (8 rows x 128 B) this wave issues per K-tile
+  constexpr int PB = BN / (8 * NW);
+  constexpr int P = PA + PB;
+  constexpr int D = NS - U;              // prefetch distance in K-tiles
+  constexpr int STEPS = (BK / 8) / WK;   // k-steps of a K-tile this wave computes
+  static_assert(WM * WN == 4 && NS >= 2 * U && PA >= 1 && PB >= 1, "tile / ring shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef float __attribute__((address_space(3))) * ldsfp;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 3;   // which output sub-tile
+  const int kg = wave >> 2;  // which half of the k-steps (WK == 2)
+  const int wm = wq / WN;
+  const int wn = wq - wm * WN;
+
+  const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
+  const int mt = bid / a.nn;
+  const int nt = bid - mt * a.nn;
+  const int seg_id = a.tiles[2 * mt];
+  const int m0 = a.tiles[2 * mt + 1];
+  const int n0 = nt * BN;
+  const dd3d_conv_seg s = a.segs[seg_id];
+  const gcfp g_in = as_g(s.in);
+  const gcfp g_w = as_g(s.w);
+  const gcfp g_zero = as_g(a.zeros);
+
+  const int nk = a.Kpad / BK;
+  int kt_begin = 0, kt_end = nk;
+  if (a.splitk > 1) {
+    kt_begin = blockIdx.y * a.kt_per_split;
+    kt_end = min(nk, kt_begin + a.kt_per_split);
+  }
+
+  // ---- DMA geometry: piece q of this wave = tile rows (q*NW + wave)*8 .. +8; lane -> (row = lane>>3, LDS slot = lane&7)
+  const int prow = lane >> 3;
+  const int srcchunk = (lane & 7) ^ prow;  // k-chunk this lane fetches (source-side swizzle)
+  long a_base[PA];
+  int a_hi0[PA], a_wi0[PA];
+  gcfp b_src[PB];
+  {
+    const int howo = s.Ho * s.Wo;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-    if (n >= a.N) continue;
-    float sc = 1.f, bi = 0.f, lo = -INFINITY;
-    if (a.splitk == 1) {
-      sc = as_g(s.scale)[n];
-      bi = as_g(s.bias)[n];
-      if (s.lo) lo = as_g(s.lo)[n];
-      if (a.relu) lo = fmaxf(lo, 0.f);
+    for (int q = 0; q < PA; ++q) {
+      const int m = m0 + (q * NW + wave) * 8 + prow;
+      if (m < s.M) {
+        const int b = m / howo;
+        const int r = m - b * howo;
+        const int ho = r / s.Wo;
+        const int wo = r - ho * s.Wo;
+        a_hi0[q] = ho * a.stride - a.pad;
+        a_wi0[q] = wo * a.stride - a.pad;
+        a_base[q] = (((long)b * s.H + a_hi0[q]) * s.W + a_wi0[q]) * s.in_pitch + srcchunk * 4;
+      } else {
+        a_hi0[q] = -(1 << 28);
+        a_wi0[q] = 0;
+        a_base[q] = 0;
+      }
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+    for (int q = 0; q < PB; ++q) {
+      const int n = min(n0 + (q * NW + wave) * 8 + prow, a.Npad - 1);
+      b_src[q] = g_w + (long)n * a.Kpad + srcchunk * 4;
+    }
+  }
+
+  // One 1-KiB DMA piece: p < PA -> A rows, else B rows.  (dh, dw, koff) describe the K-tile being fetched.
+  auto issue_piece = [&](int p, int kt, int dh, int dw, long koff, float* st) {
+    if (p < PA) {
+      const bool ok = (unsigned)(a_hi0[p] + dh) < (unsigned)s.H && (unsigned)(a_wi0[p] + dw) < (unsigned)s.W;
+      const gcfp src = ok ? g_in + a_base[p] + koff : g_zero + (lane & 7) * 4;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (ldsfp)(st + p * NW * 8 * BK), 16, 0, 0);
+    } else {
+      const int q = p - PA;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(b_src[q] + kt * BK),
+                                       (ldsfp)(st + BM * BK + q * NW * 8 * BK), 16, 0, 0);
+    }
+  };
+  auto issue_tile = [&](int kt, int stage) {
+    const int chunk = kt / a.T;
+    const int tap = kt - chunk * a.T;
+    const int dh = (tap * a.kw_magic) >> 16;
+    const int dw = tap - dh * a.KW;
+    const long koff = ((long)dh * s.W + dw) * s.in_pitch + chunk * BK;
+    float* st = smem + stage * STAGE + wave * 8 * BK;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m >= s.M) continue;
-        if (a.splitk > 1) {
-          g_ws[((long)blockIdx.y * a.ws_rows + s.ws_row0 + m) * a.N4 + n] = acc[i][j][r];
-        } else {
-          float v = acc[i][j][r] * sc + bi;
-          if (s.res_mode == 1) v += g_res[(long)m * s.res_pitch + n];
-          g_out[(long)m * s.out_pitch + n] = fmaxf(v, lo);
+    for (int p = 0; p < P; ++p) issue_piece(p, kt, dh, dw, koff, st);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31;
+  const int kh = lane >> 5;
+  int slot_off[STEPS];  // float offset of this wave's k-step t inside the lane's row (read-side swizzle)
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) slot_off[t] = ((2 * (kg * STEPS + t) + kh) ^ (lrow & 7)) * 4;
+
+  // MFMAs of the tile in `stage`, with this wave's DMA pieces of tile `kt_next` (-> stage `fill`) issued right behind
+  // an MFMA so that their issue cost hides under the matrix pipe instead of delaying it.
+  auto tile_step = [&](int stage, int kt_next, int fill) {
+    const float* As = smem + stage * STAGE + (wm * TM * 32 + lrow) * BK;
+    const float* Bs = smem + stage * STAGE + BM * BK + (wn * TN * 32 + lrow) * BK;
+    const int chunk = kt_next / a.T;
+    const int tap = kt_next - chunk * a.T;
+    const int dh = (tap * a.kw_magic) >> 16;
+    const int dw = tap - dh * a.KW;
+    const long koff = ((long)dh * s.W + dw) * s.in_pitch + chunk * BK;
+    float* st = smem + fill * STAGE + wave * 8 * BK;
+    f32x4 af[2][TM], bf[2][TN];  // fragments double-buffered: the LDS reads of k-step t+1 fly under the MFMAs of t
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + slot_off[0]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + slot_off[0]);
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+      if (t + 1 < STEPS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[(t + 1) & 1][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + slot_off[t + 1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[(t + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + slot_off[t + 1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][i][e], bf[t & 1][j][e], acc[i][j], 0, 0, 0);
+        if (e == 0) {
+#pragma unroll
+          for (int p = (t * P) / STEPS; p < ((t + 1) * P) / STEPS; ++p) issue_piece(p, kt_next, dh, dw, koff, st);
         }
       }
     }
+  };
+
+  if (kt_begin < kt_end) {
+    const int kt_last = kt_end - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue_tile(min(kt_begin + d, kt_last), d);
+    int base = 0;  // ring stage of tile kt
+    for (int kt = kt_begin; kt < kt_end; kt += U) {
+      // this wave's pieces of tiles kt .. kt+U-1 have landed once at most D-U newer tiles are still in flight
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * (D - U)) : "memory");
+      __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone is done with the U stages read last time
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int stage = base + u;
+        stage = stage >= NS ? stage - NS : stage;
+        int fill = base + u + D;  // == stage of tile kt + u - U, freed by the barrier above
+        fill = fill >= NS ? fill - NS : fill;
+        // every iteration issues exactly U tiles of DMA (clamped past the end) so the counted wait stays exact
+        if (kt + u < kt_end) tile_step(stage, min(kt + D + u, kt_last), fill);
+        else issue_tile(kt_last, fill);
+      }
+      base += U;
+      base = base >= NS ? base - NS : base;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is re-used / released
   }
+
+  if (WK == 2) {
+    // merge the two K-halves: waves 4..7 park their accumulators in LDS ([sub-tile][block][reg][lane]), waves 0..3 add them
+    __syncthreads();  // every wave is done reading the ring and no DMA is in flight
+    float* red = smem + (wq * TM * TN) * 16 * 64 + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 64];
+  }
+
+  conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
 }
 
-// Split-K second pass: sum the partial slabs and apply the epilogue.  grid = (m-tiles, BM / 8): one block per 8 output rows,
-// 16 B per lane, so even a 30-tile layer spreads over the whole chip.
+// ------------------------------------------------------------------------------------------------------------------
+// Split-K second pass: sum the partial slabs and apply the epilogue.  grid = (m-tiles, BM / 8): one block per 8 output
+// rows, 16 B per lane, so even a 30-tile layer spreads over the whole chip.
 constexpr int RED_ROWS = 8;
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKArgs a) {
   const int seg_id = a.tiles[2 * blockIdx.x];
@@ -264,29 +545,68 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ host
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <int TM, int TN, int WM, int WN, bool SMALLC, int PIPE>
+static void launch_reg(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
+  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(float);
+  auto k = conv_igemm_f32_kernel<TM, TN, WM, WN, SMALLC, PIPE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256, 1, 1), lds, st, ka);
+}
+
+template <int TM, int TN, int WM, int WN, int NS, int U, int WK>
+static void launch_dma(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
+  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
+  const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
+  auto k = conv_igemm_f32_dma_kernel<TM, TN, WM, WN, NS, U, WK>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256 * WK, 1, 1), lds, st, ka);
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(float);
-  dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1), block(256, 1, 1);
-  if (smallc) {
-    auto k = conv_igemm_f32_kernel<TM, TN, WM, WN, true>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
+  dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
+  // A/B knobs; the defaults are what measured best on MI355X (profiles/).
+  static const int use_dma = env_int("DD3D_CONV_DMA", 1);      // LDS-DMA kernel for Cin % 32 == 0
+  static const int dma_big = env_int("DD3D_CONV_DMA_BIG", 0);  // ... also for the 128x128 tile (register-staged is faster)
+  static const int wk2 = env_int("DD3D_CONV_DMA_WK2", 1);      // 8 waves (K split inside the block) for the small tiles
+  static const int pipe2 = env_int("DD3D_CONV_PIPE", 2);       // register-staged kernel: 2 staging sets unless 0
+  if (!smallc && use_dma && ka.zeros != nullptr && (TM * TN != 4 || dma_big)) {
+    if constexpr (TM * TN == 4) {
+      launch_dma<TM, TN, WM, WN, 2, 1, 1>(ka, grid, st);
+    } else if constexpr (BM >= 64 && BN >= 64) {
+      if (wk2) launch_dma<TM, TN, WM, WN, 6, 2, 2>(ka, grid, st);
+      else launch_dma<TM, TN, WM, WN, 6, 2, 1>(ka, grid, st);
+    } else {
+      launch_dma<TM, TN, WM, WN, 6, 2, 1>(ka, grid, st);
     }
-    hipLaunchKernelGGL(k, grid, block, lds, st, ka);
   } else {
-    auto k = conv_igemm_f32_kernel<TM, TN, WM, WN, false>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
+    // the 128x128 tile keeps one staging set (two would push it past 256 VGPRs and halve its occupancy)
+    const int pipe = (TM * TN == 4) ? 0 : pipe2;
+    if (smallc) {
+      if (pipe == 0) launch_reg<TM, TN, WM, WN, true, 0>(ka, grid, st);
+      else launch_reg<TM, TN, WM, WN, true, 2>(ka, grid, st);
+    } else {
+      if (pipe == 0) launch_reg<TM, TN, WM, WN, false, 0>(ka, grid, st);
+      else launch_reg<TM, TN, WM, WN, false, 2>(ka, grid, st);
     }
-    hipLaunchKernelGGL(k, grid, block, lds, st, ka);
   }
-  int rc = check_launch("conv_igemm_f32_kernel");
+  int rc = check_launch("conv_igemm_f32 kernel");
   if (rc != DD3D_OK) return rc;
   if (ka.splitk > 1) {
     hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ka.ntiles, BM / RED_ROWS), dim3(256), 0, st, ka);
@@ -333,6 +653,7 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.splitk = L->splitk;
   ka.ws_rows = L->ws_rows;
   ka.N4 = (L->N + 3) / 4 * 4;
+  ka.zeros = L->zero_page;
   const int nk = L->Kpad / 32;
   ka.kt_per_split = ceil_div(nk, L->splitk);
   const bool smallc = L->Cin < 32;

@@ -158,6 +158,7 @@ class ConvOp:
         L.KH, L.KW, L.stride, L.pad = meta["KH"], meta["KW"], stride, pad
         L.Cin, L.N, L.Kpad, L.Npad = meta["Cin"], meta["N"], meta["Kpad"], meta["Npad"]
         L.relu, L.splitk, L.ws_rows, L.tile_cfg = int(relu), sk, ws_rows, cfg
+        L.zero_page = plan.zero_page.data_ptr()
         self.L = L
         self.macs = sum(m_list) * meta["N"] * meta["KH"] * meta["KW"] * meta["Cin"]
         self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), splitk=sk,
@@ -190,6 +191,7 @@ class PlanBase:
         self.bufs = {}
         self.graph = None
         self.world_size = 1
+        self.zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)  # padded-tap source of the DMA conv
 
     # ------------------------------------------------------------------ helpers
     def buf(self, name, B, H, W, Cc):

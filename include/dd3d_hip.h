@@ -88,6 +88,8 @@ typedef struct dd3d_conv_launch {  /* host memory */
   int32_t splitk;    /* >= 1 */
   int32_t ws_rows;   /* rows per split in the workspace */
   int32_t tile_cfg;  /* DD3D_TILE_* */
+  const float* zero_page; /* device, >= 128 B of zeros, 16-B aligned: source of padded taps for the LDS-DMA kernel
+                             (NULL selects the register-staged kernel) */
 } dd3d_conv_launch;
 
 #define DD3D_TILE_128x128 0
