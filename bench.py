@@ -46,8 +46,10 @@ def parse_args():
     return ap.parse_args()
 
 
-def kernel_time_us(plan, op, iters=20):
-    """Mean duration of one op's launch(es), HIP events recorded on the launch stream (= torch's current stream)."""
+def kernel_time_us(plan, op, iters=5, burst=8):
+    """Mean duration of one launch of ``op``: HIP events recorded on the launch stream (= torch's current stream) around a
+    burst of back-to-back launches, so the figure is the kernel's own duration (as rocprofv3 reports it), not the
+    host-side launch gap of a lone eager launch."""
     from dd3d_amd import hip
     st = hip.current_stream()
     for _ in range(3):
@@ -57,11 +59,12 @@ def kernel_time_us(plan, op, iters=20):
     for _ in range(iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        op(plan.lib, st)
+        for _ in range(burst):
+            op(plan.lib, st)
         e1.record()
         e1.synchronize()
         t += e0.elapsed_time(e1)
-    return t / iters * 1e3
+    return t / (iters * burst) * 1e3
 
 
 def main():

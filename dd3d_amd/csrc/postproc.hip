@@ -95,24 +95,38 @@ __global__ __launch_bounds__(PT) void fcos_select_decode_kernel(const SelectK P)
   __shared__ int sh_bucket, sh_kk, sh_flag;
 
   // ---- phase 1: score, threshold, ordered compaction  (fcos2d.py:274-300)
+  // Each thread owns VPT consecutive (location, class) elements per round, so the block needs one scan per 4096 elements
+  // (the scan's two barriers, not the loads, set the pace of this phase).
+  constexpr int VPT = 4;
   int running = 0;
-  for (int base = 0; base < n_el; base += PT) {
-    const int e = base + tid;
-    int pass = 0;
-    float score = 0.f;
-    if (e < n_el) {
-      const int loc = e / C;
-      const int c = e - loc * C;
-      const float sc = sigmoidf(cls[(pix0 + loc) * a.cls_pitch + c]);
-      const float ct = sigmoidf(b2d[(pix0 + loc) * a.b2d_pitch + 4]);
-      score = sc * ct;
-      pass = a.thresh_with_ctr ? (score > a.pre_nms_thresh) : (sc > a.pre_nms_thresh);
+  for (int base = 0; base < n_el; base += PT * VPT) {
+    const int e0 = base + tid * VPT;
+    float score[VPT];
+    int passbits = 0, cnt = 0;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int e = e0 + v;
+      score[v] = 0.f;
+      if (e < n_el) {
+        const int loc = e / C;
+        const int c = e - loc * C;
+        const float sc = sigmoidf(cls[(pix0 + loc) * a.cls_pitch + c]);
+        const float ct = sigmoidf(b2d[(pix0 + loc) * a.b2d_pitch + 4]);
+        score[v] = sc * ct;
+        const int pass = a.thresh_with_ctr ? (score[v] > a.pre_nms_thresh) : (sc > a.pre_nms_thresh);
+        passbits |= pass << v;
+        cnt += pass;
+      }
     }
     int total;
-    const int pos = running + block_excl_scan(pass, wsum, total);
-    if (pass) {
-      sidx[pos] = e;
-      sscore[pos] = score;
+    int pos = running + block_excl_scan(cnt, wsum, total);
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      if ((passbits >> v) & 1) {
+        sidx[pos] = e0 + v;
+        sscore[pos] = score[v];
+        ++pos;
+      }
     }
     running += total;
   }
@@ -364,7 +378,25 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   __syncthreads();
   mx = red[0];
   for (int w = 1; w < PT / 64; ++w) mx = fmaxf(mx, red[w]);
-  if (suppress) block_bitonic_sort(keys, vals, Pn);
+  if (suppress) {
+    if (n <= PT) {
+      // rank sort: one candidate per thread, rank = number of candidates that sort before it (n LDS broadcasts)
+      const float ki = tid < n ? keys[tid] : 0.f;
+      const int vi = tid < n ? vals[tid] : 0;
+      int rank = 0;
+      if (tid < n) {
+#pragma unroll 16
+        for (int j = 0; j < n; ++j) rank += sorts_before(keys[j], vals[j], ki, vi);  // unrolled: LDS reads pipelined
+      }
+      __syncthreads();
+      if (tid < n) {
+        keys[rank] = ki;
+        vals[rank] = vi;
+      }
+    } else {
+      block_bitonic_sort(keys, vals, Pn);
+    }
+  }
   __syncthreads();
   const int mode = !suppress ? NMS_NONE : (4 * n > 4000 ? NMS_PER_CLASS : NMS_TRICK);  // torchvision 0.10 batched_nms
   if (tid == 0) {
@@ -454,10 +486,20 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
     for (int i = tid; i < NCAP_MAX / 64; i += PT) removed[i] = 0;
     if (tid == 0) sh_nkeep = 0;
     __syncthreads();
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(tkeys);  // [64][nwords] mask words of this block row
     for (int rb = 0; rb < nwords; ++rb) {
+      // stage the 64 mask rows of this block row (words rb .. nwords-1) in LDS: one parallel, coalesced read instead of
+      // dependent global loads inside the serial part
+      const int nwr = nwords - rb;
+      for (int idx = tid; idx < 64 * nwr; idx += PT) {
+        const int j = idx / nwr, w = idx - j * nwr;
+        const int i = rb * 64 + j;
+        stage[j * nwords + w] = i < n ? mask[(long)i * nw + rb + w] : 0ull;
+      }
+      __syncthreads();
       if (tid < 64) {  // wave 0: resolve the 64 candidates of this block row sequentially (diagonal word only)
         const int i = rb * 64 + tid;
-        const unsigned long long diag = i < n ? mask[(long)i * nw + rb] : 0ull;
+        const unsigned long long diag = stage[tid * nwords];
         unsigned long long rem = removed[rb];
         unsigned long long keepbits = 0;
         const int lim = min(64, n - rb * 64);
@@ -483,7 +525,7 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
         while (bitsleft) {
           const int j = __ffsll((long long)bitsleft) - 1;
           bitsleft &= bitsleft - 1;
-          acc |= mask[(long)(rb * 64 + j) * nw + cw];
+          acc |= stage[j * nwords + (cw - rb)];
         }
         removed[cw] = acc;
       }
@@ -496,16 +538,34 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const float* score2d = cand + 4 * NS;
   float thr = -INFINITY;
   if (a.do_nms && a.post_topk > 0 && nkeep > a.post_topk) {
-    int Pn = 1;
-    while (Pn < nkeep) Pn <<= 1;
-    for (int i = tid; i < Pn; i += PT) {
-      tkeys[i] = i < nkeep ? score2d[sort_idx[kept[i]]] : -INFINITY;
-      tvals[i] = i;
+    if (nkeep <= PT) {
+      // one kept detection per thread: it is the k-th largest iff (#greater < k <= #greater-or-equal)
+      const float my = tid < nkeep ? score2d[sort_idx[kept[tid]]] : 0.f;
+      if (tid < nkeep) tkeys[tid] = my;
+      __syncthreads();
+      if (tid < nkeep) {
+        int gt = 0, ge = 0;
+#pragma unroll 16
+        for (int j = 0; j < nkeep; ++j) {
+          const float v = tkeys[j];
+          gt += v > my;
+          ge += v >= my;
+        }
+        if (gt < a.post_topk && a.post_topk <= ge) sh_thr = my;  // every thread that gets here holds the same value
+      }
+      __syncthreads();
+    } else {
+      int Pn = 1;
+      while (Pn < nkeep) Pn <<= 1;
+      for (int i = tid; i < Pn; i += PT) {
+        tkeys[i] = i < nkeep ? score2d[sort_idx[kept[i]]] : -INFINITY;
+        tvals[i] = i;
+      }
+      __syncthreads();
+      block_bitonic_sort(tkeys, tvals, Pn);
+      if (tid == 0) sh_thr = tkeys[a.post_topk - 1];
+      __syncthreads();
     }
-    __syncthreads();
-    block_bitonic_sort(tkeys, tvals, Pn);
-    if (tid == 0) sh_thr = tkeys[a.post_topk - 1];
-    __syncthreads();
     thr = sh_thr;
   }
 

@@ -100,7 +100,9 @@ def choose_tiling(m_list, N, Kpad):
                 continue
             per = -(-nk // sk)
             cost = -(-blocks * sk // NUM_CU) * bm * bn * per * 32
-            cost *= 1.0 + 0.02 * (128 * 128 / (bm * bn) - 1)  # small tiles re-read operands more often
+            # measured matrix-pipe efficiency of each tile shape once the chip is full (profiles/r01b_conv_ops.txt):
+            # 128x128 ~119 TF/s, 128x64 ~95, 64x64 ~74, 128x32 (N <= 32 pads the 32-wide MFMA) ~45
+            cost /= {(128, 128): 1.0, (128, 64): 0.80, (64, 128): 0.80, (64, 64): 0.63, (128, 32): 0.40}[(bm, bn)]
             if sk > 1:
                 # second launch (~2 us) + partial-sum round trip (sk*M*N*8 B at ~3 TB/s), in per-CU MAC units
                 # (one CU retires 157.3e12 / 2 / 256 = 3.07e11 MAC/s)
