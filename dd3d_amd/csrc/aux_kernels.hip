@@ -85,6 +85,95 @@ __global__ __launch_bounds__(256) void upsample2x_add_nhwc_kernel(float* __restr
   }
 }
 
+// 3x3 stride-2 max pooling without padding, ceil_mode=True (windows may overhang the bottom / right edge).
+__global__ __launch_bounds__(256) void maxpool3x3s2_ceil_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                                     int Ho, int Wo, int C4, int in_pitch, int out_pitch) {
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long t = i / C4;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    f32x4 o = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = 2 * ho + dy;
+      if (y >= H) break;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = 2 * wo + dx;
+        if (x >= W) break;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((long)b * H + y) * W + x) * in_pitch + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], v[e]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + (((long)b * Ho + ho) * Wo + wo) * out_pitch + c) = o;
+  }
+}
+
+// Global average pool, pass 1: partial[b][rs][c] = sum over the rs-th slice of the H*W rows (deterministic: no atomics).
+// block = 256 threads = 16 row lanes x 16 float4 columns (64 channels); grid = (C/64, RS, B).
+__global__ __launch_bounds__(256) void gap_partial_nhwc_kernel(const float* __restrict__ in, float* __restrict__ partial, int HW, int C,
+                                                               int pitch, int RS) {
+  const int cg = blockIdx.x, rs = blockIdx.y, b = blockIdx.z;
+  const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+  const int c = cg * 64 + cl * 4;
+  const int rows_per = (HW + RS - 1) / RS;
+  const int r0 = rs * rows_per, r1 = min(HW, r0 + rows_per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 16) acc += *reinterpret_cast<const f32x4*>(in + ((long)b * HW + r) * pitch + c);
+  __shared__ f32x4 red[16][16];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    f32x4 s = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][cl];
+    *reinterpret_cast<f32x4*>(partial + ((long)b * RS + rs) * C + c) = s;
+  }
+}
+
+// eSE gate: g[b][co] = hsigmoid( fc_w[co][:] . mean[b][:] + fc_b[co] ),  mean = sum of the RS partials / HW.
+// grid = (C/4, B), block = 256 = 4 waves, one output channel per wave, lanes stride over the input channels.
+__global__ __launch_bounds__(256) void ese_gate_kernel(const float* __restrict__ partial, const float* __restrict__ fc_w,
+                                                       const float* __restrict__ fc_b, float* __restrict__ gate, int C, int RS, float inv_hw) {
+  const int b = blockIdx.y;
+  const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  if (co < C) {
+    for (int ci = lane; ci < C; ci += 64) {
+      float m = 0.f;
+      for (int r = 0; r < RS; ++r) m += partial[((long)b * RS + r) * C + ci];
+      acc += fc_w[(long)co * C + ci] * (m * inv_hw);
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane == 0 && co < C) {
+    const float v = acc + fc_b[co];
+    gate[(long)b * C + co] = fminf(fmaxf(v + 3.0f, 0.f), 6.0f) / 6.0f;  // F.relu6(x + 3) / 6
+  }
+}
+
+// out[b, y, x, :] = x[b, y, x, :] * gate[b, :] (+ identity[b, y, x, :])
+__global__ __launch_bounds__(256) void scale_add_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                             const float* __restrict__ identity, float* __restrict__ out, int B, int HW, int C4,
+                                                             int x_pitch, int id_pitch, int out_pitch) {
+  const long total = (long)B * HW * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long m = i / C4;
+    const int b = (int)(m / HW);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + m * x_pitch + c) * *reinterpret_cast<const f32x4*>(gate + (long)b * C4 * 4 + c);
+    if (identity) v += *reinterpret_cast<const f32x4*>(identity + m * id_pitch + c);
+    *reinterpret_cast<f32x4*>(out + m * out_pitch + c) = v;
+  }
+}
+
 // General 3x3 inverse by cofactors (the reference calls torch.inverse on the stacked intrinsics).
 __global__ void invert3x3_kernel(const float* __restrict__ K, float* __restrict__ invK, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,6 +238,42 @@ extern "C" int dd3d_upsample2x_add_nhwc(float* fine, const float* coarse, int32_
   hipLaunchKernelGGL(upsample2x_add_nhwc_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), fine, coarse, B, H, W, C / 4,
                      fine_pitch, coarse_pitch);
   return check_launch("upsample2x_add_nhwc_kernel");
+}
+
+extern "C" int dd3d_maxpool3x3s2_ceil_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                                           int32_t out_pitch, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(in && out && B > 0 && H >= 3 && W >= 3, "dd3d_maxpool3x3s2_ceil_nhwc: bad arguments");
+  DD3D_REQUIRE((C % 4) == 0 && (in_pitch % 4) == 0 && (out_pitch % 4) == 0, "dd3d_maxpool3x3s2_ceil_nhwc: C / pitches must be multiples of 4");
+  int Ho = (H - 3 + 1) / 2 + 1, Wo = (W - 3 + 1) / 2 + 1;  // ceil((H-3)/2) + 1
+  if ((Ho - 1) * 2 >= H) --Ho;                              // last window must start inside the input (PyTorch rule)
+  if ((Wo - 1) * 2 >= W) --Wo;
+  const long total = (long)B * Ho * Wo * (C / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(maxpool3x3s2_ceil_nhwc_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in, out, B, H, W, Ho, Wo,
+                     C / 4, in_pitch, out_pitch);
+  return check_launch("maxpool3x3s2_ceil_nhwc_kernel");
+}
+
+extern "C" int dd3d_ese_nhwc(const float* x, const float* identity, float* out, const float* fc_w, const float* fc_b, float* partial,
+                             float* gate, int32_t B, int32_t HW, int32_t C, int32_t x_pitch, int32_t id_pitch, int32_t out_pitch,
+                             int32_t rsplit, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(x && out && fc_w && fc_b && partial && gate && B > 0 && HW > 0, "dd3d_ese_nhwc: bad arguments");
+  DD3D_REQUIRE((C % 4) == 0 && (x_pitch % 4) == 0 && (out_pitch % 4) == 0 && (!identity || (id_pitch % 4) == 0),
+               "dd3d_ese_nhwc: C / pitches must be multiples of 4");
+  DD3D_REQUIRE(rsplit >= 1 && rsplit <= 1024, "dd3d_ese_nhwc: rsplit=%d", rsplit);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gap_partial_nhwc_kernel, dim3((C + 63) / 64, rsplit, B), dim3(256), 0, st, x, partial, HW, C, x_pitch, rsplit);
+  int rc = check_launch("gap_partial_nhwc_kernel");
+  if (rc != DD3D_OK) return rc;
+  hipLaunchKernelGGL(ese_gate_kernel, dim3((C + 3) / 4, B), dim3(256), 0, st, partial, fc_w, fc_b, gate, C, rsplit, 1.0f / (float)HW);
+  rc = check_launch("ese_gate_kernel");
+  if (rc != DD3D_OK) return rc;
+  const long total = (long)B * HW * (C / 4);
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(scale_add_nhwc_kernel, dim3(grid), dim3(256), 0, st, x, gate, identity, out, B, HW, C / 4, x_pitch, id_pitch, out_pitch);
+  return check_launch("scale_add_nhwc_kernel");
 }
 
 extern "C" int dd3d_invert_intrinsics(const float* K, float* inv_K, int32_t B, void* stream) {

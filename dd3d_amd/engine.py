@@ -317,8 +317,7 @@ class ForwardPlan(PlanBase):
         if isinstance(bb.bottom_up, DLA):
             feats = self._dla(bb.bottom_up, img.view())
         else:
-            from dd3d_amd.modeling.vovnet_plan import build_vovnet_plan
-            feats = build_vovnet_plan(self, bb.bottom_up, img.view())
+            feats = self._vovnet(bb.bottom_up, img.view())
         self.bottom_up = feats
         self.features = self._fpn(bb, feats)  # list of views, finest first
         self.strides = [s.stride for s in model.backbone_output_shape]
@@ -399,6 +398,83 @@ class ForwardPlan(PlanBase):
             x = self._tree(getattr(dla, f"level{lvl}"), x, f"level{lvl}")
             outs[f"level{lvl}"] = x
         return {k: outs[k] for k in dla._out_features}
+
+    # ------------------------------------------------------------------ VoVNet-V2 (vovnet.py:218-238,357-367)
+    def _vovnet(self, vov, img):
+        """OSA modules with the torch.cat realised by channel placement: each module owns one NHWC buffer
+        [x | layer0 | ... | layer4]; its input slice is written in place by the producer (stem conv, stage max-pool or the
+        previous module's eSE + identity kernel)."""
+        from dd3d_amd.modeling.vovnet import seq_conv, seq_norm
+        B = img.B
+        x = img
+        stages = [getattr(vov, n) for n in vov.stage_names]
+        mods0 = list(stages[0].children())
+
+        def cat_width(m):
+            return m.in_ch + len(m.layers) * m.stage_ch
+
+        cat = None
+        for idx, (cname, nname) in enumerate(vov.stem_seqs):
+            conv, norm = getattr(vov.stem, cname), getattr(vov.stem, nname)
+            Ho, Wo = (x.H + 2 - 3) // conv.stride + 1, (x.W + 2 - 3) // conv.stride + 1
+            if idx == len(vov.stem_seqs) - 1:
+                cat = self.buf("stage2.OSA2_1.cat", B, Ho, Wo, cat_width(mods0[0]))
+                y = cat.view(0, conv.out_channels)
+            else:
+                y = self.buf(f"stem.{idx}", B, Ho, Wo, conv.out_channels).view()
+            self.conv_module(conv, x, y, relu=True, norm=norm, name=cname)
+            x = y
+        outs, prev = {}, None
+        for si, (sname, stage) in enumerate(zip(vov.stage_names, stages)):
+            mods = [(n, m) for n, m in stage.named_children()]
+            if stage.has_pool:
+                Hp = -(-(prev.H - 3) // 2) + 1
+                Wp = -(-(prev.W - 3) // 2) + 1
+                Hp -= (Hp - 1) * 2 >= prev.H
+                Wp -= (Wp - 1) * 2 >= prev.W
+                cat = self.buf(f"{sname}.{mods[0][0]}.cat", B, Hp, Wp, cat_width(mods[0][1]))
+                dstv = cat.view(0, mods[0][1].in_ch)
+
+                def _pool(lib, st, vin=prev, vout=dstv):
+                    hip.check(lib.dd3d_maxpool3x3s2_ceil_nhwc(vin.ptr, vout.ptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, st), "pool3")
+
+                self.ops.append(CallOp(_pool, f"{sname}.pool"))
+            H, W = cat.H, cat.W
+            for k, (mname, m) in enumerate(mods):
+                src = cat.view(0, m.in_ch)
+                for i, layer in enumerate(m.layers):
+                    dst = cat.view(m.in_ch + i * m.stage_ch, m.stage_ch)
+                    self.conv_module(seq_conv(layer), src, dst, relu=True, norm=seq_norm(layer), name=f"{mname}.{i}")
+                    src = dst
+                xt = self.buf(f"{sname}.{mname}.xt", B, H, W, m.concat_ch).view()
+                self.conv_module(seq_conv(m.concat), cat.view(), xt, relu=True, norm=seq_norm(m.concat), name=f"{mname}.concat")
+                if k + 1 < len(mods):
+                    nxt = self.buf(f"{sname}.{mods[k + 1][0]}.cat", B, H, W, cat_width(mods[k + 1][1]))
+                    dst = nxt.view(0, m.concat_ch)
+                else:
+                    nxt = None
+                    dst = self.buf(f"{sname}.out", B, H, W, m.concat_ch).view()
+                self.ese(xt, cat.view(0, m.in_ch) if m.identity else None, dst, m.ese.fc, name=f"{mname}.ese")
+                cat = nxt
+            outs[sname] = prev = dst
+        return {k: outs[k] for k in vov._out_features}
+
+    def ese(self, x, identity, out, fc, name="ese"):
+        Cc, HW = x.C, x.H * x.W
+        rs = max(1, min(64, HW // 256))
+        w = self._vec(fc.weight.reshape(Cc, Cc))
+        b = self._vec(fc.bias)
+        partial = torch.zeros((x.B, rs, Cc), dtype=torch.float32, device=self.device)
+        gate = torch.zeros((x.B, Cc), dtype=torch.float32, device=self.device)
+
+        def _f(lib, st):
+            hip.check(
+                lib.dd3d_ese_nhwc(x.ptr, identity.ptr if identity is not None else None, out.ptr, w.data_ptr(), b.data_ptr(), partial.data_ptr(),
+                                  gate.data_ptr(), x.B, HW, Cc, x.pitch, identity.pitch if identity is not None else 0, out.pitch, rs, st),
+                name
+            )
+
+        self.ops.append(CallOp(_f, name))
 
     # ------------------------------------------------------------------ FPN ([ext] detectron2 FPN.forward)
     def _fpn(self, fpn, feats):

@@ -68,7 +68,7 @@ class NmsArgs(C.Structure):
 
 EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
-    "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
+    "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
     "dd3d_invert_intrinsics", "dd3d_nms_finalize"
 ]
 
@@ -103,6 +103,8 @@ def lib():
     ]
     L.dd3d_maxpool2x2_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
     L.dd3d_upsample2x_add_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    L.dd3d_maxpool3x3s2_ceil_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]
+    L.dd3d_ese_nhwc.argtypes = [C.c_void_p] * 7 + [C.c_int32] * 7 + [C.c_void_p]
     L.dd3d_fcos_select_decode.argtypes = [C.POINTER(SelectArgs), C.c_void_p]
     L.dd3d_invert_intrinsics.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.dd3d_nms_finalize.argtypes = [C.POINTER(NmsArgs), C.c_void_p]

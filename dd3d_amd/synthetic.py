@@ -60,9 +60,9 @@ def make_state_dict(model, seed=0, calib=None):
                     sd[name + ".bias"].add_(bias)
         elif isinstance(mod, (BatchNorm2d, FrozenBatchNorm2d)):
             n = mod.num_features
-            m0, s0 = calib.get(name, [0.0, 1.0])
-            sd[name + ".weight"].copy_(torch.rand(n, generator=g) + 0.5)
-            sd[name + ".bias"].copy_(torch.randn(n, generator=g) * 0.1)
+            m0, s0, gain = (list(calib.get(name, [0.0, 1.0])) + [1.0])[:3]  # gain: per-level equalisation of the logits
+            sd[name + ".weight"].copy_((torch.rand(n, generator=g) + 0.5) * gain)
+            sd[name + ".bias"].copy_(torch.randn(n, generator=g) * 0.1 * gain)
             sd[name + ".running_mean"].copy_(m0 + torch.randn(n, generator=g) * 0.1 * s0)
             sd[name + ".running_var"].copy_((torch.rand(n, generator=g) + 0.5) * s0 * s0)
     return sd

@@ -118,6 +118,19 @@ int dd3d_preprocess_u8_nhwc4(const uint8_t* src, const int32_t* sizes, float* ds
 int dd3d_maxpool2x2_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
                          int32_t out_pitch, void* stream);
 
+/* 3x3 stride-2 max pooling, no padding, ceil_mode=True.  Replaces nn.MaxPool2d(3, 2, ceil_mode=True) in front of
+ * VoVNet stages 3-5 (tridet/modeling/feature_extractor/vovnet.py:248-249).  Output size = ceil((H-3)/2)+1 (PyTorch rule). */
+int dd3d_maxpool3x3s2_ceil_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                                int32_t out_pitch, void* stream);
+
+/* effective Squeeze-Excitation + OSA identity: out = x * hsigmoid(fc(mean_hw(x))) (+ identity).
+ * Replaces eSEModule.forward and the identity add of _OSA_module.forward (vovnet.py:180-185,233-236).
+ *   x [B*HW][x_pitch] (C channels), fc_w [C][C] row-major (= the 1x1 conv weight), fc_b [C],
+ *   workspaces: partial [B][rsplit][C], gate [B][C].  Deterministic (two-pass sum, no atomics). */
+int dd3d_ese_nhwc(const float* x, const float* identity, float* out, const float* fc_w, const float* fc_b, float* partial,
+                  float* gate, int32_t B, int32_t HW, int32_t C, int32_t x_pitch, int32_t id_pitch, int32_t out_pitch,
+                  int32_t rsplit, void* stream);
+
 /* fine[b,y,x,:] += coarse[b,y/2,x/2,:].  Replaces the FPN top-down step of detectron2 FPN.forward [ext]:
  * prev = lateral + F.interpolate(prev, scale_factor=2, mode="nearest").  H, W (of `fine`) even; C % 4 == 0. */
 int dd3d_upsample2x_add_nhwc(float* fine, const float* coarse, int32_t B, int32_t H, int32_t W, int32_t C,

@@ -44,6 +44,20 @@ def main(experiment, tag, H=384, W=1280, dataset="kitti", target_frac=0.01):
             towers["box2d"].append(O._tower(sd, "fcos2d_head.box2d_tower", f, l, cfg.DD3D.FCOS2D.NUM_BOX_CONVS))
             towers["box3d"].append(O._tower(sd, "fcos3d_head.box3d_tower", f, l, n3))
 
+        # equalise the spread of the class logits over the levels (the last cls-tower norm of level l gets a gain; ReLU is
+        # positively homogeneous, so the level's logits scale with it) -- otherwise one level takes every candidate
+        last = cfg.DD3D.FCOS2D.NUM_CLS_CONVS - 1
+        w_cls = sd["fcos2d_head.cls_logits.weight"]
+        stds = [float(F.conv2d(t, w_cls, None, padding=1).std()) for t in towers["cls"]]
+        pooled = sum(stds) / len(stds)
+        for l, s_l in enumerate(stds):
+            key = f"fcos2d_head.cls_tower.{last}.norm.{l}"
+            gain = pooled / s_l
+            calib[key] = calib[key][:2] + [gain]
+            sd[key + ".weight"] = sd[key + ".weight"] * gain
+            sd[key + ".bias"] = sd[key + ".bias"] * gain
+            towers["cls"][l] = towers["cls"][l] * gain
+
         def raw(name, tower):
             outs = [F.conv2d(t, sd[name + ".weight"], None, padding=1).permute(0, 2, 3, 1).reshape(-1, sd[name + ".weight"].shape[0])
                     for t in towers[tower]]
@@ -87,7 +101,7 @@ def main(experiment, tag, H=384, W=1280, dataset="kitti", target_frac=0.01):
 
     os.makedirs(os.path.dirname(calib_path(tag)), exist_ok=True)
     with open(calib_path(tag), "w") as f:
-        json.dump({k: [round(v[0], 6), round(v[1], 6)] for k, v in calib.items()}, f, indent=0, sort_keys=True)
+        json.dump({k: [round(x, 6) for x in v] for k, v in calib.items()}, f, indent=0, sort_keys=True)
     # verify with the public generator
     sd2 = make_state_dict(model, seed=0, calib=json.load(open(calib_path(tag))))
     with torch.no_grad():

@@ -31,6 +31,7 @@ CASES = {
     # name: (experiment, calib tag, B, H, W, ragged)
     "dla34_kitti_128x256_b1": ("dd3d_kitti_dla34", "dla34_kitti", 1, 128, 256, False),
     "dla34_kitti_128x384_b2_ragged": ("dd3d_kitti_dla34", "dla34_kitti", 2, 128, 384, True),
+    "v99_kitti_128x256_b1": ("dd3d_kitti_v99", "v99_kitti", 1, 128, 256, False),
 }
 
 

@@ -169,16 +169,17 @@ def test_error_behaviour(hiplib, kitti_dla34):
         model(inputs)
 
 
-@pytest.mark.parametrize("name", ["dla34_kitti_128x256_b1", "dla34_kitti_128x384_b2_ragged"])
-def test_hip_matches_reference_golden(hiplib, kitti_dla34, name):
+@pytest.mark.parametrize("name", ["dla34_kitti_128x256_b1", "dla34_kitti_128x384_b2_ragged", "v99_kitti_128x256_b1"])
+def test_hip_matches_reference_golden(hiplib, name):
     """HIP path vs the committed golden vectors (produced by the reference's own DD3D.forward, tests/golden/make_golden.py):
     head maps within float tolerance end-to-end; with the golden head maps as input, the HIP post-processing reproduces the
     reference's detections (classes / levels / locations bit-exact, floats within 1e-3 rel)."""
     import os
     import numpy as np
     from tests.golden.make_golden import CASES, case_inputs
-    cfg, _, sd = kitti_dla34
-    _, _, B, H, W, ragged = CASES[name]
+    from tests.util import bundle
+    exp, tag, B, H, W, ragged = CASES[name]
+    cfg, sd = bundle(exp, tag)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     t = lambda k: torch.from_numpy(g[k])
     model = gpu_model(cfg, sd, use_graph=False)
@@ -206,3 +207,27 @@ def test_hip_matches_reference_golden(hiplib, kitti_dla34, name):
         assert rel_err(o.scores_3d, t(f"det{i}_scores_3d")) < REL_TOL and rel_err(o.pred_boxes3d.depth, t(f"det{i}_depth")) < REL_TOL
         assert rel_err(o.pred_boxes3d.size, t(f"det{i}_size")) < REL_TOL and quat_err(o.pred_boxes3d.quat, t(f"det{i}_quat")) < REL_TOL
         assert max_abs(o.pred_boxes3d.vectorize()[:, 4:], t(f"det{i}_vectorize")[:, 4:]) < REL_TOL * max(1.0, float(t(f"det{i}_vectorize").abs().max()))
+
+
+def test_v99_forward_matches_oracle(hiplib):
+    """DD3D-V2-99 (VoVNet-99-eSE + FPN P2..P6, BASELINE.json configs[2] architecture) at fp32: OSA concat-by-placement,
+    ceil-mode 3x3 max-pool, eSE gate and identity add against the oracle; integer parity on identical head maps."""
+    from dd3d_amd.synthetic import make_inputs
+    from tests.util import bundle
+    cfg, sd = bundle("dd3d_kitti_v99", "v99_kitti")
+    model = gpu_model(cfg, sd, use_graph=False)
+    inputs = make_inputs(2, 192, 320)
+    ref, st = _oracle(cfg, sd, inputs)
+    plan, image_sizes = model.stage_inputs(inputs)
+    plan.run()
+    torch.cuda.synchronize()
+    C = cfg.DD3D.NUM_CLASSES
+    for k, v in st["bottom_up"].items():
+        assert max_abs(plan.bottom_up[k].nchw(), v) < 1e-4 * max(1.0, float(v.abs().max())), k
+    _check_head_maps(plan, st, C)
+    oracle_heads_to_plan(plan, st, C)
+    plan.launch(first=len(plan.ops) - 2)
+    torch.cuda.synchronize()
+    out = model.collect(plan, inputs, image_sizes)
+    for i in range(2):
+        _check_final(out[i], ref[i])

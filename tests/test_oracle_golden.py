@@ -15,9 +15,10 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_oracle_matches_reference_golden(kitti_dla34, name):
-    cfg, _, sd = kitti_dla34
+def test_oracle_matches_reference_golden(name):
+    from tests.util import bundle
     exp, tag, B, H, W, ragged = CASES[name]
+    cfg, sd = bundle(exp, tag)
     g = np.load(os.path.join(GOLD, name + ".npz"))
     inputs = case_inputs(B, H, W, ragged)
     with torch.no_grad():

@@ -2,6 +2,22 @@
 import torch
 
 
+_BUNDLES = {}
+
+
+def bundle(experiment, tag):
+    """(cfg, synthetic CPU state_dict) of one of the reference experiments, cached per session."""
+    key = (experiment, tag)
+    if key not in _BUNDLES:
+        import dd3d_amd.modeling  # noqa: F401
+        from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+        from dd3d_amd.synthetic import load_calib, make_state_dict
+        cfg = get_cfg(experiment)
+        model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+        _BUNDLES[key] = (cfg, make_state_dict(model, calib=load_calib(tag)))
+    return _BUNDLES[key]
+
+
 def rel_err(a, b, floor=1e-3):
     """max |a-b| / max(|b|, floor*max|b|): relative error that does not blow up on near-zero entries."""
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
