@@ -230,9 +230,22 @@ __global__ __launch_bounds__(PT) void fcos_select_decode_kernel(const SelectK P)
     cand[7 * NS + tid] = __int_as_float(e);
     cand[8 * NS + tid] = lx;
     cand[9 * NS + tid] = ly;
+    {  // nuScenes extras on the cls tower (nuscenes_dd3d.py:268-296): argmax attribute, speed
+      const float* pc = cls + (pix0 + loc) * a.cls_pitch;
+      int best = 0;
+      if (a.num_attr > 0) {
+        float bv = pc[a.attr_off];
+        for (int t = 1; t < a.num_attr; ++t) {
+          const float v = pc[a.attr_off + t];
+          if (v > bv) bv = v, best = t;  // first maximum, as torch.argmax
+        }
+      }
+      cand[20 * NS + tid] = __int_as_float(best);
+      cand[21 * NS + tid] = a.speed_off >= 0 ? pc[a.speed_off] : 0.f;
+    }
     if (b3d == nullptr) {
       cand[5 * NS + tid] = score;
-      for (int f = 10; f < DD3D_CAND_FIELDS; ++f) cand[f * NS + tid] = 0.f;
+      for (int f = 10; f < 20; ++f) cand[f * NS + tid] = 0.f;
     } else {
       const int C3 = a.class_agnostic_3d ? 1 : C;
       const int c3 = a.class_agnostic_3d ? 0 : c;
@@ -599,11 +612,402 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
       d[6] = (float)__float_as_int(cand[6 * NS + slot]);
       d[7] = (float)(slot / a.topk);
 #pragma unroll
-      for (int f = 8; f < DD3D_DET_FIELDS; ++f) d[f] = cand[f * NS + slot];
+      for (int f = 8; f < 20; ++f) d[f] = cand[f * NS + slot];
+      d[20] = (float)__float_as_int(cand[20 * NS + slot]);
+      d[21] = cand[21 * NS + slot];
+#pragma unroll
+      for (int f = 22; f < DD3D_DET_FIELDS; ++f) d[f] = 0.f;
     }
     running += total;
   }
   if (tid == 0) a.det_count[g] = running;
+}
+
+
+// ================================================================================================ BEV rotated NMS
+// nuScenes sample aggregation (tridet/modeling/dd3d/postprocessing.py:22-108, tridet/layers/bev_nms.py:51-133):
+// camera-frame boxes -> global frame with the image's pose, top-face corners -> BEV rotated boxes, class- and
+// sample-aware rotated-IoU NMS ([ext] detectron2 batched_nms_rotated / box_iou_rotated), optional cap on the number of
+// kept boxes, survivors written back per image in their original order.  All images of the batch form ONE problem, as
+// in the reference (one batched_nms_rotated call over the concatenated instances).
+struct BevK {
+  dd3d_bev_args a;
+  int ncap;   // round_up(G*det_cap, 64)
+  int ncap2;  // LDS sort capacity (power of two)
+};
+
+struct V2 {
+  float x, y;
+};
+__device__ __forceinline__ float cross2(V2 a, V2 b) { return a.x * b.y - b.x * a.y; }
+__device__ __forceinline__ float dot2(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ V2 sub2(V2 a, V2 b) { return V2{a.x - b.x, a.y - b.y}; }
+
+// [ext] get_rotated_vertices
+__device__ void rotated_vertices(float cx, float cy, float w, float h, float a, V2* p) {
+  const double theta = (double)a * 0.01745329251;
+  const float c = (float)cos(theta) * 0.5f, s = (float)sin(theta) * 0.5f;
+  p[0] = V2{cx - s * h - c * w, cy + c * h - s * w};
+  p[1] = V2{cx + s * h - c * w, cy - c * h - s * w};
+  p[2] = V2{2 * cx - p[0].x, 2 * cy - p[0].y};
+  p[3] = V2{2 * cx - p[1].x, 2 * cy - p[1].y};
+}
+
+// [ext] single_box_iou_rotated: intersection polygon = edge crossings + contained vertices, Graham hull, fan area
+__device__ float rotated_iou(const float* b1, const float* b2) {
+  const float area1 = b1[2] * b1[3], area2 = b2[2] * b2[3];
+  if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
+  const float sx = (b1[0] + b2[0]) / 2.0f, sy = (b1[1] + b2[1]) / 2.0f;
+  V2 p1[4], p2[4], v1[4], v2[4], q[24];
+  rotated_vertices(b1[0] - sx, b1[1] - sy, b1[2], b1[3], b1[4], p1);
+  rotated_vertices(b2[0] - sx, b2[1] - sy, b2[2], b2[3], b2[4], p2);
+  const float EPS = 1e-5f;
+  int num = 0;
+  for (int i = 0; i < 4; ++i) {
+    v1[i] = sub2(p1[(i + 1) & 3], p1[i]);
+    v2[i] = sub2(p2[(i + 1) & 3], p2[i]);
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const float det = cross2(v2[j], v1[i]);
+      if (fabsf(det) <= 1e-14f) continue;
+      const V2 v12 = sub2(p2[j], p1[i]);
+      const float t1 = cross2(v2[j], v12) / det, t2 = cross2(v1[i], v12) / det;
+      if (t1 > -EPS && t1 < 1.0f + EPS && t2 > -EPS && t2 < 1.0f + EPS) q[num++] = V2{p1[i].x + v1[i].x * t1, p1[i].y + v1[i].y * t1};
+    }
+  {
+    const V2 AB = v2[0], DA = v2[3];
+    const float ABdotAB = dot2(AB, AB), ADdotAD = dot2(DA, DA);
+    for (int i = 0; i < 4; ++i) {
+      const V2 AP = sub2(p1[i], p2[0]);
+      const float APdotAB = dot2(AP, AB), APdotAD = -dot2(AP, DA);
+      if (APdotAB > -EPS && APdotAD > -EPS && APdotAB < ABdotAB + EPS && APdotAD < ADdotAD + EPS) q[num++] = p1[i];
+    }
+  }
+  {
+    const V2 AB = v1[0], DA = v1[3];
+    const float ABdotAB = dot2(AB, AB), ADdotAD = dot2(DA, DA);
+    for (int i = 0; i < 4; ++i) {
+      const V2 AP = sub2(p2[i], p1[0]);
+      const float APdotAB = dot2(AP, AB), APdotAD = -dot2(AP, DA);
+      if (APdotAB > -EPS && APdotAD > -EPS && APdotAB < ABdotAB + EPS && APdotAD < ADdotAD + EPS) q[num++] = p2[i];
+    }
+  }
+  if (num <= 2) return 0.f;
+  // convex_hull_graham
+  int t = 0;
+  for (int i = 1; i < num; ++i)
+    if (q[i].y < q[t].y || (q[i].y == q[t].y && q[i].x < q[t].x)) t = i;
+  const V2 start = q[t];
+  for (int i = 0; i < num; ++i) q[i] = sub2(q[i], start);
+  {
+    const V2 tmp = q[0];
+    q[0] = q[t];
+    q[t] = tmp;
+  }
+  float dist[24];
+  for (int i = 0; i < num; ++i) dist[i] = dot2(q[i], q[i]);
+  for (int i = 1; i < num - 1; ++i)
+    for (int j = i + 1; j < num; ++j) {
+      const float cp = cross2(q[i], q[j]);
+      if (cp < -1e-6f || (fabsf(cp) < 1e-6f && dist[i] > dist[j])) {
+        const V2 tq = q[i];
+        q[i] = q[j];
+        q[j] = tq;
+        const float td = dist[i];
+        dist[i] = dist[j];
+        dist[j] = td;
+      }
+    }
+  int k = 1;
+  while (k < num && dist[k] <= 1e-8f) ++k;
+  if (k == num) return 0.f;
+  q[1] = q[k];
+  int m = 2;
+  for (int i = k + 1; i < num; ++i) {
+    while (m > 1 && cross2(sub2(q[i], q[m - 2]), sub2(q[m - 1], q[m - 2])) >= 0.f) --m;
+    q[m++] = q[i];
+  }
+  if (m <= 2) return 0.f;
+  float inter = 0.f;
+  for (int i = 1; i < m - 1; ++i) inter += fabsf(cross2(sub2(q[i], q[0]), sub2(q[i + 1], q[0])));
+  inter /= 2.0f;
+  return inter / (area1 + area2 - inter);
+}
+
+__device__ __forceinline__ void quat_to_mat(const float* q, float* R) {  // [ext] pytorch3d quaternion_to_matrix
+  const float r = q[0], i = q[1], j = q[2], k = q[3];
+  const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+  R[0] = 1 - two_s * (j * j + k * k), R[1] = two_s * (i * j - k * r), R[2] = two_s * (i * k + j * r);
+  R[3] = two_s * (i * j + k * r), R[4] = 1 - two_s * (i * i + k * k), R[5] = two_s * (j * k - i * r);
+  R[6] = two_s * (i * k - j * r), R[7] = two_s * (j * k + i * r), R[8] = 1 - two_s * (i * i + j * j);
+}
+
+__device__ __forceinline__ void mat_to_quat(const float* m, float* q) {  // [ext] pytorch3d 0.5/0.6 matrix_to_quaternion
+  const float t0 = 1.f + m[0] + m[4] + m[8], t1 = 1.f + m[0] - m[4] - m[8], t2 = 1.f - m[0] + m[4] - m[8], t3 = 1.f - m[0] - m[4] + m[8];
+  const float a0 = t0 > 0.f ? sqrtf(t0) : 0.f, a1 = t1 > 0.f ? sqrtf(t1) : 0.f, a2 = t2 > 0.f ? sqrtf(t2) : 0.f, a3 = t3 > 0.f ? sqrtf(t3) : 0.f;
+  int best = 0;
+  float am = a0;
+  if (a1 > am) best = 1, am = a1;
+  if (a2 > am) best = 2, am = a2;
+  if (a3 > am) best = 3, am = a3;
+  const float den = 2.0f * fmaxf(am, 0.1f);
+  if (best == 0) q[0] = a0 * a0, q[1] = m[7] - m[5], q[2] = m[2] - m[6], q[3] = m[3] - m[1];
+  else if (best == 1) q[0] = m[7] - m[5], q[1] = a1 * a1, q[2] = m[3] + m[1], q[3] = m[2] + m[6];
+  else if (best == 2) q[0] = m[2] - m[6], q[1] = m[3] + m[1], q[2] = a2 * a2, q[3] = m[5] + m[7];
+  else q[0] = m[3] - m[1], q[1] = m[6] + m[2], q[2] = m[7] + m[5], q[3] = a3 * a3;
+  q[0] /= den, q[1] /= den, q[2] /= den, q[3] /= den;
+}
+
+// 1 block: global boxes, BEV rotated boxes, coordinate range, stable sort by score_3d; writes the sorted work arrays.
+__global__ __launch_bounds__(PT) void bev_prepare_kernel(const BevK P) {
+  const dd3d_bev_args& a = P.a;
+  const int tid = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  float* keys = reinterpret_cast<float*>(dyn_lds);
+  int* vals = reinterpret_cast<int*>(dyn_lds) + P.ncap2;
+  __shared__ int offs[1025];
+  __shared__ float redmax[PT / 64], redmin[PT / 64];
+  if (tid == 0) {
+    int acc = 0;
+    for (int g = 0; g < a.G; ++g) {
+      offs[g] = acc;
+      acc += min(a.count_in[g], a.det_cap);
+    }
+    offs[a.G] = acc;
+  }
+  __syncthreads();
+  const int n = offs[a.G];
+  const int ok = n <= P.ncap2;
+  if (tid == 0) {
+    a.meta[0] = ok ? n : 0;
+    a.meta[1] = ok ? 0 : 1;  // overflow flag
+  }
+  if (!ok) return;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int i = tid; i < n; i += PT) {
+    int g = 0;
+    while (g + 1 < a.G && i >= offs[g + 1]) ++g;
+    const float* d = a.det_in + ((long)g * a.det_cap + (i - offs[g])) * DD3D_DET_FIELDS;
+    const float* K = a.inv_K + 9 * (g - a.first_local < 0 || g - a.first_local >= a.num_local ? 0 : g - a.first_local);
+    // camera-frame box: tvec = K^-1 [proj_ctr, 1] * depth  (boxes3d.py:169-173)
+    const float u = d[14], v = d[15], dep = d[16];
+    const float tS[3] = {(K[0] * u + K[1] * v + K[2]) * dep, (K[3] * u + K[4] * v + K[5]) * dep, (K[6] * u + K[7] * v + K[8]) * dep};
+    float R_SO[9], R_WS[9], R_WO[9], qW[4], tW[3], R[9];
+    quat_to_mat(d + 10, R_SO);
+    const float* ps = a.pose + 7 * g;
+    quat_to_mat(ps, R_WS);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) R_WO[3 * r + c] = R_WS[3 * r] * R_SO[c] + R_WS[3 * r + 1] * R_SO[3 + c] + R_WS[3 * r + 2] * R_SO[6 + c];
+      tW[r] = R_WS[3 * r] * tS[0] + R_WS[3 * r + 1] * tS[1] + R_WS[3 * r + 2] * tS[2] + ps[4 + r];
+    }
+    mat_to_quat(R_WO, qW);
+    quat_to_mat(qW, R);
+    // top-face corners 0 (+,+,+), 1 (+,-,+), 5 (-,-,+), 4 (-,+,+) of (l, w, h) = (size[1], size[0], size[2])  (boxes3d.py:12-16,47-64)
+    const float hl = 0.5f * d[18], hw = 0.5f * d[17], hh = 0.5f * d[19];
+    const float sgl[4] = {1.f, 1.f, -1.f, -1.f}, sgw[4] = {1.f, -1.f, -1.f, 1.f};
+    V2 bev[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float ox = sgl[c] * hl, oy = sgw[c] * hw, oz = hh;
+      const float X = R[0] * ox + R[1] * oy + R[2] * oz + tW[0];
+      const float Y = R[3] * ox + R[4] * oy + R[5] * oz + tW[1];
+      bev[c] = V2{-Y, -X};  // VEHICLE_TO_BEV_ROTATION (bev_nms.py:42-47)
+    }
+    const V2 fwd = sub2(bev[0], bev[3]), sid = sub2(bev[0], bev[1]);
+    const float length = sqrtf(fwd.x * fwd.x + fwd.y * fwd.y), width = sqrtf(sid.x * sid.x + sid.y * sid.y);
+    const float cx = (bev[0].x + bev[2].x) / 2.0f, cy = (bev[0].y + bev[2].y) / 2.0f;
+    const float ang = 57.29577951308232f * atan2f(fwd.x, fwd.y);
+    float* w = a.work + (long)i * 16;  // 0-4 rotated box, 5 category, 6-9 global quat, 10-12 global tvec
+    w[0] = cx, w[1] = cy, w[2] = width, w[3] = length, w[4] = ang;
+    w[5] = __int_as_float((int)d[6] + a.group[g] * a.num_classes);
+    w[6] = qW[0], w[7] = qW[1], w[8] = qW[2], w[9] = qW[3], w[10] = tW[0], w[11] = tW[1], w[12] = tW[2];
+    keys[i] = d[5];
+    vals[i] = i;
+    const float ext = fmaxf(width, length) / 2.0f;
+    mx = fmaxf(mx, fmaxf(cx, cy) + ext);
+    mn = fminf(mn, fminf(cx, cy) - ext);
+  }
+  int Pn = 1;
+  while (Pn < n) Pn <<= 1;
+  for (int i = n + tid; i < Pn; i += PT) keys[i] = -INFINITY, vals[i] = 0x7fffffff;
+  for (int dlt = 32; dlt > 0; dlt >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, dlt, 64));
+    mn = fminf(mn, __shfl_xor(mn, dlt, 64));
+  }
+  if ((tid & 63) == 0) redmax[tid >> 6] = mx, redmin[tid >> 6] = mn;
+  __syncthreads();
+  mx = redmax[0], mn = redmin[0];
+  for (int wv = 1; wv < PT / 64; ++wv) mx = fmaxf(mx, redmax[wv]), mn = fminf(mn, redmin[wv]);
+  if (n <= PT) {
+    const float ki = tid < n ? keys[tid] : 0.f;
+    const int vi = tid < n ? vals[tid] : 0;
+    int rank = 0;
+    if (tid < n) {
+#pragma unroll 16
+      for (int j = 0; j < n; ++j) rank += sorts_before(keys[j], vals[j], ki, vi);
+    }
+    __syncthreads();
+    if (tid < n) keys[rank] = ki, vals[rank] = vi;
+  } else {
+    block_bitonic_sort(keys, vals, Pn);
+  }
+  __syncthreads();
+  const float unit = mx - mn + 1.0f;  // [ext] batched_nms_rotated offset unit
+  for (int p = tid; p < n; p += PT) {
+    const int i = vals[p];
+    const float* w = a.work + (long)i * 16;
+    const int cat = __float_as_int(w[5]);
+    const float off = (float)cat * unit;
+    float* sb = a.sbox + (long)p * 8;
+    sb[0] = w[0] + off, sb[1] = w[1] + off, sb[2] = w[2], sb[3] = w[3], sb[4] = w[4];
+    sb[5] = __int_as_float(cat);
+    sb[6] = __int_as_float(i);
+  }
+}
+
+__global__ __launch_bounds__(64) void bev_mask_kernel(const BevK P) {
+  const dd3d_bev_args& a = P.a;
+  const int rb = blockIdx.y, cb = blockIdx.x, lane = threadIdx.x;
+  const int n = a.meta[0];
+  if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+  __shared__ float cbox[64][6];
+  const int cj = cb * 64 + lane;
+  if (cj < n) {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) cbox[lane][f] = a.sbox[(long)cj * 8 + f];
+  }
+  __syncthreads();
+  const int i = rb * 64 + lane;
+  if (i >= n) return;
+  float mine[6];
+#pragma unroll
+  for (int f = 0; f < 6; ++f) mine[f] = a.sbox[(long)i * 8 + f];
+  unsigned long long bits = 0;
+  const int jmax = min(64, n - cb * 64);
+  for (int j = 0; j < jmax; ++j) {
+    if (cb * 64 + j <= i) continue;
+    if (__float_as_int(cbox[j][5]) != __float_as_int(mine[5])) continue;  // other categories are offset out of reach
+    if (rotated_iou(mine, cbox[j]) > a.iou_thresh) bits |= 1ull << j;
+  }
+  a.mask[(long)i * (P.ncap / 64) + cb] = bits;
+}
+
+// 1 block: greedy reduce, cap, per-image ordered write-out (optionally with the resize / clip / non-empty filter).
+__global__ __launch_bounds__(PT) void bev_finalize_kernel(const BevK P) {
+  const dd3d_bev_args& a = P.a;
+  const int tid = threadIdx.x;
+  const int n = a.meta[0];
+  const int nw = P.ncap / 64;
+  const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(a.mask);
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  unsigned long long* removed = reinterpret_cast<unsigned long long*>(dyn_lds);          // [NCAP_MAX/64]
+  unsigned long long* stage = removed + NCAP_MAX / 64;                                  // [64][nwords] <= 64 KiB
+  int* keepflag = reinterpret_cast<int*>(stage + (size_t)64 * (P.ncap2 / 64));           // [ncap2] by ORIGINAL index
+  __shared__ int wsum[PT / 64];
+  __shared__ int offs[1025], imgbase[1025];
+  __shared__ unsigned long long sh_keepbits;
+  __shared__ int sh_nkeep;
+  if (tid == 0) {
+    int acc = 0;
+    for (int g = 0; g < a.G; ++g) {
+      offs[g] = acc;
+      acc += min(a.count_in[g], a.det_cap);
+    }
+    offs[a.G] = acc;
+    sh_nkeep = 0;
+  }
+  for (int i = tid; i < NCAP_MAX / 64; i += PT) removed[i] = 0;
+  for (int i = tid; i < P.ncap2; i += PT) keepflag[i] = 0;
+  __syncthreads();
+  if (a.meta[1]) {  // more boxes than the sorter holds: report, keep nothing
+    if (tid < a.G) a.count_out[tid] = -1;
+    return;
+  }
+  const int nwords = (n + 63) / 64;
+  const int cap = a.max_dets > 0 ? a.max_dets : 0x7fffffff;
+  for (int rb = 0; rb < nwords; ++rb) {
+    const int nwr = nwords - rb;
+    for (int idx = tid; idx < 64 * nwr; idx += PT) {
+      const int j = idx / nwr, w = idx - j * nwr;
+      const int i = rb * 64 + j;
+      stage[j * nwords + w] = i < n ? mask[(long)i * nw + rb + w] : 0ull;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int i = rb * 64 + tid;
+      const unsigned long long diag = stage[tid * nwords];
+      unsigned long long rem = removed[rb];
+      unsigned long long keepbits = 0;
+      const int lim = min(64, n - rb * 64);
+      for (int j = 0; j < lim; ++j) {
+        const unsigned long long dj = __shfl(diag, j, 64);
+        if (!((rem >> j) & 1ull)) {
+          keepbits |= 1ull << j;
+          rem |= dj;
+        }
+      }
+      if (tid == 0) sh_keepbits = keepbits;
+      const int base = sh_nkeep;
+      // keep[:max_dets] truncates the score-ordered keep list of the WHOLE batch (postprocessing.py:93-94)
+      if (((keepbits >> tid) & 1ull) && base + __popcll(keepbits & ((1ull << tid) - 1ull)) < cap)
+        keepflag[__float_as_int(a.sbox[(long)i * 8 + 6])] = 1;
+      if (tid == 0) sh_nkeep = base + __popcll(keepbits);
+    }
+    __syncthreads();
+    const unsigned long long kb = sh_keepbits;
+    for (int cw = rb + 1 + tid; cw < nwords; cw += PT) {
+      unsigned long long acc = removed[cw];
+      unsigned long long bitsleft = kb;
+      while (bitsleft) {
+        const int j = __ffsll((long long)bitsleft) - 1;
+        bitsleft &= bitsleft - 1;
+        acc |= stage[j * nwords + (cw - rb)];
+      }
+      removed[cw] = acc;
+    }
+    __syncthreads();
+  }
+  // survivors, image by image, in their original order
+  int running = 0;
+  for (int g = 0; g < a.G; ++g) {
+    const float* osz = a.out_size + 4 * g;
+    const float sx = osz[3] / osz[1], sy = osz[2] / osz[0];
+    int img_run = 0;
+    for (int base = offs[g]; base < offs[g + 1]; base += PT) {
+      const int i = base + tid;
+      int pass = 0;
+      const float* d = nullptr;
+      float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+      if (i < offs[g + 1]) {
+        d = a.det_in + ((long)g * a.det_cap + (i - offs[g])) * DD3D_DET_FIELDS;
+        pass = keepflag[i];
+        x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3];
+        if (a.do_postprocess) {
+          x1 = fminf(fmaxf(x1 * sx, 0.f), osz[3]), x2 = fminf(fmaxf(x2 * sx, 0.f), osz[3]);
+          y1 = fminf(fmaxf(y1 * sy, 0.f), osz[2]), y2 = fminf(fmaxf(y2 * sy, 0.f), osz[2]);
+          pass = pass && (x2 - x1) > 0.f && (y2 - y1) > 0.f;
+        }
+      }
+      int total;
+      const int pos = img_run + block_excl_scan(pass, wsum, total);
+      if (pass) {
+        float* o = a.det_out + ((long)g * a.det_cap + pos) * DD3D_DET_FIELDS;
+        o[0] = x1, o[1] = y1, o[2] = x2, o[3] = y2;
+#pragma unroll
+        for (int f = 4; f < 22; ++f) o[f] = d[f];
+        const float* w = a.work + (long)i * 16;
+#pragma unroll
+        for (int f = 0; f < 7; ++f) o[22 + f] = a.write_global ? w[6 + f] : 0.f;
+        o[29] = o[30] = o[31] = 0.f;
+      }
+      img_run += total;
+    }
+    if (tid == 0) a.count_out[g] = img_run;
+    running += img_run;
+  }
 }
 
 }  // namespace dd3d
@@ -656,4 +1060,39 @@ extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
   if (rc != DD3D_OK) return rc;
   hipLaunchKernelGGL(nms_finalize_kernel, dim3(args->G), dim3(PT), lds_fin, st, P);
   return check_launch("nms_finalize_kernel");
+}
+
+extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(args, "dd3d_bev_nms_aggregate: null args");
+  DD3D_REQUIRE(args->G > 0 && args->G <= 1024 && args->det_cap > 0, "dd3d_bev_nms_aggregate: G=%d det_cap=%d", args->G, args->det_cap);
+  DD3D_REQUIRE(args->det_in && args->count_in && args->inv_K && args->pose && args->group && args->out_size && args->work && args->sbox &&
+                   args->mask && args->meta && args->det_out && args->count_out,
+               "dd3d_bev_nms_aggregate: null buffer");
+  DD3D_REQUIRE(args->num_local > 0 && args->first_local >= 0, "dd3d_bev_nms_aggregate: first_local/num_local");
+  BevK P;
+  P.a = *args;
+  const long ntot = (long)args->G * args->det_cap;
+  P.ncap = (int)((ntot + 63) / 64 * 64);
+  P.ncap2 = 64;
+  while (P.ncap2 < ntot && P.ncap2 < NCAP_MAX) P.ncap2 <<= 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t lds_prep = (size_t)P.ncap2 * 8;
+  const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)64 * (P.ncap2 / 64) * 8 + (size_t)P.ncap2 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bev_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bev_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              NCAP_MAX / 64 * 8 + NCAP_MAX * 8 + NCAP_MAX * 4);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(bev_prepare_kernel, dim3(1), dim3(PT), lds_prep, st, P);
+  int rc = check_launch("bev_prepare_kernel");
+  if (rc != DD3D_OK) return rc;
+  const int nb = min(P.ncap, P.ncap2) / 64;
+  hipLaunchKernelGGL(bev_mask_kernel, dim3(nb, nb), dim3(64), 0, st, P);
+  rc = check_launch("bev_mask_kernel");
+  if (rc != DD3D_OK) return rc;
+  hipLaunchKernelGGL(bev_finalize_kernel, dim3(1), dim3(PT), lds_fin, st, P);
+  return check_launch("bev_finalize_kernel");
 }

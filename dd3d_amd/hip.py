@@ -13,8 +13,8 @@ _LIB_PATH = os.path.join(os.path.dirname(__file__), "lib", "libdd3d_hip.so")
 _lib = None
 
 MAX_LEVELS = 8
-CAND_FIELDS = 20
-DET_FIELDS = 20
+CAND_FIELDS = 22
+DET_FIELDS = 32
 
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_64x128 = 0, 1, 2, 3, 4
 TILE_SHAPES = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_128x32: (128, 32),
@@ -47,7 +47,8 @@ class SelectArgs(C.Structure):
         ("H", C.c_int32 * MAX_LEVELS), ("W", C.c_int32 * MAX_LEVELS), ("stride", C.c_int32 * MAX_LEVELS),
         ("cls_pitch", C.c_int32), ("b2d_pitch", C.c_int32), ("b3d_pitch", C.c_int32), ("num_levels", C.c_int32),
         ("B", C.c_int32), ("num_classes", C.c_int32), ("class_agnostic_3d", C.c_int32), ("loc_offset_half", C.c_int32),
-        ("thresh_with_ctr", C.c_int32), ("topk", C.c_int32), ("pre_nms_thresh", C.c_float), ("min_depth", C.c_float),
+        ("thresh_with_ctr", C.c_int32), ("topk", C.c_int32), ("attr_off", C.c_int32), ("num_attr", C.c_int32),
+        ("speed_off", C.c_int32), ("pre_nms_thresh", C.c_float), ("min_depth", C.c_float),
         ("max_depth", C.c_float), ("focal_factor", C.c_float), ("scale_depth_by_focal", C.c_int32), ("allocentric", C.c_int32),
         ("depth_is_distance", C.c_int32), ("inv_K", C.c_void_p), ("canon_sizes", C.c_void_p), ("scratch_idx", C.c_void_p),
         ("scratch_score", C.c_void_p), ("scratch_off", C.c_int64 * MAX_LEVELS), ("scratch_img_stride", C.c_int64),
@@ -66,10 +67,21 @@ class NmsArgs(C.Structure):
     ]
 
 
+class BevArgs(C.Structure):
+    """`dd3d_bev_args`."""
+    _fields_ = [
+        ("det_in", C.c_void_p), ("count_in", C.c_void_p), ("inv_K", C.c_void_p), ("pose", C.c_void_p), ("group", C.c_void_p),
+        ("out_size", C.c_void_p), ("G", C.c_int32), ("det_cap", C.c_int32), ("num_classes", C.c_int32), ("first_local", C.c_int32),
+        ("num_local", C.c_int32), ("iou_thresh", C.c_float), ("max_dets", C.c_int32), ("write_global", C.c_int32),
+        ("do_postprocess", C.c_int32), ("work", C.c_void_p), ("sbox", C.c_void_p), ("mask", C.c_void_p), ("meta", C.c_void_p),
+        ("det_out", C.c_void_p), ("count_out", C.c_void_p)
+    ]
+
+
 EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
-    "dd3d_invert_intrinsics", "dd3d_nms_finalize"
+    "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate"
 ]
 
 
@@ -108,6 +120,7 @@ def lib():
     L.dd3d_fcos_select_decode.argtypes = [C.POINTER(SelectArgs), C.c_void_p]
     L.dd3d_invert_intrinsics.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.dd3d_nms_finalize.argtypes = [C.POINTER(NmsArgs), C.c_void_p]
+    L.dd3d_bev_nms_aggregate.argtypes = [C.POINTER(BevArgs), C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the .so is stale
     assert L.dd3d_abi_version() == 1, "libdd3d_hip.so ABI version mismatch; rebuild"

@@ -245,3 +245,70 @@ class Boxes3D(GenericBoxes3D):
 
     def to(self, *a, **k):
         return Boxes3D(*[getattr(self, f).to(*a, **k) for f in self._FIELDS])
+
+
+class _Quat:
+    """Minimal unit-quaternion (w, x, y, z) used by ``Pose`` (the reference uses pyquaternion, not installed here)."""
+    def __init__(self, q):
+        import numpy as np
+        self.elements = np.asarray(q.elements if hasattr(q, "elements") else q, dtype=np.float64).reshape(4).copy()
+
+    def __mul__(self, o):
+        import numpy as np
+        w1, x1, y1, z1 = self.elements
+        w2, x2, y2, z2 = o.elements
+        return _Quat(np.array([
+            w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+            w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2
+        ]))
+
+    @property
+    def inverse(self):
+        import numpy as np
+        return _Quat(self.elements * np.array([1.0, -1.0, -1.0, -1.0]) / float(self.elements @ self.elements))
+
+    @property
+    def rotation_matrix(self):
+        import numpy as np
+        w, x, y, z = self.elements / np.linalg.norm(self.elements)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def rotate(self, v):
+        import numpy as np
+        return self.rotation_matrix @ np.asarray(v, dtype=np.float64)
+
+
+class Pose:
+    """SE(3) pose, the slice of tridet/structures/pose.py:6-164 the forward path needs on the host: a rotation quaternion
+    (``.quat.elements`` = w,x,y,z) and a translation (``.tvec``); composition, inverse, 4x4 matrix.  Any object with those
+    two attributes (e.g. the reference's own Pose) is accepted wherever a pose is expected."""
+    def __init__(self, wxyz=(1.0, 0.0, 0.0, 0.0), tvec=(0.0, 0.0, 0.0)):
+        import numpy as np
+        self.quat = _Quat(wxyz)
+        assert abs(1.0 - np.linalg.norm(self.quat.elements)) < 1.0e-3
+        self.tvec = np.asarray(tvec, dtype=np.float64).reshape(3)
+
+    def __mul__(self, other):
+        if isinstance(other, Pose):
+            return Pose((self.quat * other.quat).elements, self.quat.rotate(other.tvec) + self.tvec)
+        return NotImplemented
+
+    def inverse(self):
+        qinv = self.quat.inverse
+        return Pose(qinv.elements, qinv.rotate(-self.tvec))
+
+    @property
+    def matrix(self):
+        import numpy as np
+        m = np.eye(4)
+        m[:3, :3] = self.quat.rotation_matrix
+        m[:3, 3] = self.tvec
+        return m
+
+    @classmethod
+    def from_yaw(cls, yaw_deg, tvec=(0.0, 0.0, 0.0)):
+        import math
+        h = math.radians(yaw_deg) / 2.0
+        return cls((math.cos(h), 0.0, 0.0, math.sin(h)), tvec)

@@ -83,5 +83,15 @@ def make_inputs(B=1, H=384, W=1280, dataset="kitti", seed=1000, out_hw=None, dev
              "file_name": f"synthetic_{seed + i}.png"}
         if out_hw is not None:
             d["height"], d["width"] = out_hw
+        if dataset != "kitti":
+            # nuScenes-shaped extras (dataset_mapper.py:155-165): 6 cameras per sample (yaw 0, +-55, +-110, 180 deg around the
+            # vertical axis of the ego frame, composed with the camera-to-vehicle axis swap) times one ego pose per sample
+            from dd3d_amd.structures import Pose
+            cam, sample = i % 6, i // 6
+            yaw = [0.0, 55.0, -55.0, 110.0, -110.0, 180.0][cam]
+            cam_to_vehicle = Pose((0.5, -0.5, 0.5, -0.5), (1.5, 0.2 * (cam - 2.5), 1.6))  # z fwd, x right, y down -> x fwd, y left, z up
+            ego = Pose.from_yaw(17.0 * sample + 5.0, (410.0 + 13.0 * sample, 1180.0 - 7.0 * sample, 0.0))
+            d["pose"] = ego * Pose.from_yaw(yaw) * cam_to_vehicle
+            d["sample_token"] = f"s{sample}"
         out.append(d)
     return out

@@ -33,8 +33,8 @@ extern "C" {
 #define DD3D_E_UNSUPPORTED (-3)
 
 #define DD3D_MAX_LEVELS 8
-#define DD3D_CAND_FIELDS 20 /* SoA fields of a decoded candidate, see dd3d_fcos_select_decode */
-#define DD3D_DET_FIELDS 20  /* AoS fields of a final detection, see dd3d_nms_finalize */
+#define DD3D_CAND_FIELDS 22 /* SoA fields of a decoded candidate, see dd3d_fcos_select_decode */
+#define DD3D_DET_FIELDS 32  /* AoS fields of a final detection, see dd3d_nms_finalize / dd3d_bev_nms_aggregate */
 
 int dd3d_abi_version(void);
 const char* dd3d_last_error(void);
@@ -151,6 +151,7 @@ int dd3d_upsample2x_add_nhwc(float* fine, const float* coarse, int32_t B, int32_
  * Output (per image b): cand[b][f][level*topk + j], f < DD3D_CAND_FIELDS:
  *   0-3 box x1,y1,x2,y2 | 4 score=sqrt(cls*ctr) | 5 score_3d | 6 class (int bits) | 7 loc*C+class (int bits)
  *   8-9 location x,y | 10-13 quat wxyz (egocentric) | 14-15 proj_ctr | 16 depth | 17-19 size WLH
+ *   20 argmax attribute (int bits) | 21 speed      (nuScenes; NuscenesInference, nuscenes_dd3d.py:268-296)
  * counts[b][level] = number of valid slots (<= topk); npass[b][level] = #scores over threshold.
  * Candidate order inside a level = ascending (loc, class), i.e. torch.nonzero order.
  * ------------------------------------------------------------------------------------------------ */
@@ -165,6 +166,8 @@ typedef struct dd3d_select_args {  /* host memory */
   int32_t loc_offset_half;       /* DD3D.FEATURE_LOCATIONS_OFFSET == "half" */
   int32_t thresh_with_ctr;       /* DD3D.FCOS2D.INFERENCE.THRESH_WITH_CTR */
   int32_t topk;                  /* PRE_NMS_TOPK */
+  int32_t attr_off, num_attr;    /* nuScenes: cls-map channels [attr_off, attr_off+num_attr) = attribute logits (0 attrs: none) */
+  int32_t speed_off;             /* nuScenes: cls-map channel of relu(speed), or -1 */
   float pre_nms_thresh;
   float min_depth, max_depth, focal_factor;
   int32_t scale_depth_by_focal, allocentric, depth_is_distance;
@@ -192,7 +195,8 @@ int dd3d_invert_intrinsics(const float* K, float* inv_K, int32_t B, void* stream
  *   out_size [G][4] = (in_h, in_w, out_h, out_w) float, device
  *   det [G][det_cap][DD3D_DET_FIELDS]:
  *     0-3 box | 4 score | 5 score_3d | 6 class | 7 fpn level | 8-9 location | 10-13 quat | 14-15 proj_ctr
- *     | 16 depth | 17-19 size            (class / level stored as float-valued integers)
+ *     | 16 depth | 17-19 size | 20 attribute | 21 speed | 22-25 global quat | 26-28 global tvec (filled by
+ *     dd3d_bev_nms_aggregate) | 29-31 unused       (class / level / attribute stored as float-valued integers)
  *   det_count [G]; order = descending score_3d (torchvision keep order).
  * Workspaces (device): sort_idx int32 [G][ncap], sbox float [G][ncap][4], scls int32 [G][ncap],
  *   mask uint64 [G][ncap][ncap/64], nvalid int32 [G][2], where ncap = round_up(num_levels*topk, 64).
@@ -217,6 +221,45 @@ typedef struct dd3d_nms_args {  /* host memory */
   int32_t det_cap;
 } dd3d_nms_args;
 int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * nuScenes sample aggregation = camera->global box transform + BEV rotated-box NMS.
+ * Replaces nuscenes_sample_aggregate / sample_bev_nms (tridet/modeling/dd3d/postprocessing.py:22-108),
+ * boxes3d_to_rotated_boxes / bev_nms (tridet/layers/bev_nms.py:51-133), GenericBoxes3D.corners
+ * (tridet/structures/boxes3d.py:47-64), pytorch3d Transform3d / rotation conversions [ext] and detectron2
+ * batched_nms_rotated -> nms_rotated / box_iou_rotated [ext].
+ *   det_in [G][det_cap][DD3D_DET_FIELDS], count_in [G]      as written by dd3d_nms_finalize
+ *   inv_K [num_local][9]  inverse intrinsics of images first_local .. first_local+num_local-1 (the images this
+ *                         rank decoded; with the RCCL gather every rank holds all G images' detections)
+ *   pose [G][7] (quat wxyz, tvec) camera->global; group [G] sample index of each image (category id =
+ *   class + group*num_classes); out_size as in dd3d_nms_finalize (used when do_postprocess)
+ *   max_dets: cap on the batch-global, score-ordered keep list (0 = none; the reference truncates the whole batch,
+ *   postprocessing.py:93-94).  det_out / count_out: survivors per image in their original order, fields 22-28 = the
+ *   global-frame box when write_global.  count_out = -1 everywhere if more than 8192 boxes arrive.
+ * Workspaces (device): work float [G*det_cap][16], sbox float [G*det_cap][8], mask uint64 [ncap][ncap/64]
+ *   (ncap = round_up(G*det_cap, 64)), meta int32 [4].
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dd3d_bev_args {  /* host memory */
+  const float* det_in;
+  const int32_t* count_in;
+  const float* inv_K;
+  const float* pose;
+  const int32_t* group;
+  const float* out_size;
+  int32_t G, det_cap, num_classes;
+  int32_t first_local, num_local;
+  float iou_thresh;
+  int32_t max_dets;
+  int32_t write_global;
+  int32_t do_postprocess;
+  float* work;
+  float* sbox;
+  uint64_t* mask;
+  int32_t* meta;
+  float* det_out;
+  int32_t* count_out;
+} dd3d_bev_args;
+int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream);
 
 #ifdef __cplusplus
 }
