@@ -789,7 +789,7 @@ __global__ __launch_bounds__(PT) void bev_prepare_kernel(const BevK P) {
     int g = 0;
     while (g + 1 < a.G && i >= offs[g + 1]) ++g;
     const float* d = a.det_in + ((long)g * a.det_cap + (i - offs[g])) * DD3D_DET_FIELDS;
-    const float* K = a.inv_K + 9 * (g - a.first_local < 0 || g - a.first_local >= a.num_local ? 0 : g - a.first_local);
+    const float* K = a.inv_K + 9 * g;
     // camera-frame box: tvec = K^-1 [proj_ctr, 1] * depth  (boxes3d.py:169-173)
     const float u = d[14], v = d[15], dep = d[16];
     const float tS[3] = {(K[0] * u + K[1] * v + K[2]) * dep, (K[3] * u + K[4] * v + K[5]) * dep, (K[6] * u + K[7] * v + K[8]) * dep};
@@ -1069,7 +1069,6 @@ extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
   DD3D_REQUIRE(args->det_in && args->count_in && args->inv_K && args->pose && args->group && args->out_size && args->work && args->sbox &&
                    args->mask && args->meta && args->det_out && args->count_out,
                "dd3d_bev_nms_aggregate: null buffer");
-  DD3D_REQUIRE(args->num_local > 0 && args->first_local >= 0, "dd3d_bev_nms_aggregate: first_local/num_local");
   BevK P;
   P.a = *args;
   const long ntot = (long)args->G * args->det_cap;

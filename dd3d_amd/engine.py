@@ -638,6 +638,10 @@ class ForwardPlan(PlanBase):
         a.loc_offset_half = int(cfg.DD3D.FEATURE_LOCATIONS_OFFSET == "half")
         a.thresh_with_ctr = int(bool(inf2.THRESH_WITH_CTR))
         a.topk, a.pre_nms_thresh = topk, float(inf2.PRE_NMS_THRESH)
+        a.attr_off, a.num_attr, a.speed_off = 0, 0, -1
+        if hasattr(model, "attr_logits"):  # nuScenes extras ride on the cls map (see _heads)
+            a.attr_off, a.num_attr = C_, model.attr_logits.out_channels
+            a.speed_off = C_ + model.attr_logits.out_channels
         if self.b3d_maps is not None:
             c3 = cfg.DD3D.FCOS3D
             a.class_agnostic_3d = int(bool(c3.CLASS_AGNOSTIC_BOX3D))
@@ -689,7 +693,11 @@ class ForwardPlan(PlanBase):
         n.G, n.num_levels, n.topk = G, L, topk
         n.do_nms, n.use_score3d = int(bool(inf.DO_NMS)), int(self.b3d_maps is not None)
         n.nms_thresh, n.post_topk = float(inf2.NMS_THRESH), int(inf2.POST_NMS_TOPK)
-        n.do_postprocess = int(bool(inf.DO_POSTPROCESS))
+        # BEV stages (core.py:135-150, nuscenes_dd3d.py:423-465) run after the 2D NMS; the resize / clip / non-empty filter
+        # of detector_postprocess sits between them, so it moves into whichever kernel comes at that point.
+        bev_single = bool(inf.DO_BEV_NMS) and self.b3d_maps is not None
+        bev_sample = bool(getattr(model, "aggregates_samples", False)) and bool(inf.DO_POSTPROCESS) and self.b3d_maps is not None
+        n.do_postprocess = int(bool(inf.DO_POSTPROCESS) and not bev_single)
         n.out_size = self.outsize_all.data_ptr()
         n.sort_idx, n.sbox, n.scls = self.sort_idx.data_ptr(), self.sbox.data_ptr(), self.scls.data_ptr()
         n.mask, n.nvalid = self.mask.data_ptr(), self.nvalid.data_ptr()
@@ -697,6 +705,57 @@ class ForwardPlan(PlanBase):
         self.nms_args = n
         self.nms_op = CallOp(lambda lib, st: hip.check(lib.dd3d_nms_finalize(C.byref(n), st), "nms_finalize"), "nms_finalize")
         self.ops.append(self.nms_op)
+        self.pose_all = self.group_all = self.invK_all = None
+        self.has_global_boxes = False
+        if bev_single or bev_sample:
+            self.in_pose = torch.zeros((B, 7), dtype=torch.float32, device=dev)
+            self.in_pose[:, 0] = 1.0
+            self.in_group = torch.zeros((B, ), dtype=torch.int32, device=dev)
+            if world_size > 1:
+                self.pose_all = torch.zeros((G, 7), dtype=torch.float32, device=dev)
+                self.group_all = torch.zeros((G, ), dtype=torch.int32, device=dev)
+                self.invK_all = torch.zeros((G, 9), dtype=torch.float32, device=dev)
+            else:
+                self.pose_all, self.group_all, self.invK_all = self.in_pose, self.in_group, self.inv_K
+            ntot = G * self.det_cap
+            if ntot > 8192:
+                raise NotImplementedError(f"BEV NMS over {G} images x {self.det_cap} detections exceeds the 8192-box LDS sorter")
+            ncapb = (ntot + 63) // 64 * 64
+            self.bev_work = torch.zeros((ntot, 16), dtype=torch.float32, device=dev)
+            self.bev_sbox = torch.zeros((ntot, 8), dtype=torch.float32, device=dev)
+            self.bev_mask = torch.zeros((ncapb, ncapb // 64), dtype=torch.int64, device=dev)
+            self.bev_meta = torch.zeros((4, ), dtype=torch.int32, device=dev)
+            self.own_group = torch.arange(G, dtype=torch.int32, device=dev)  # dummy_group_idxs = {i: [i]} (core.py:137)
+            self.bev_args = []
+
+            def stage(group, max_dets, write_global, do_pp, name):
+                b = hip.BevArgs()
+                det_out = torch.zeros_like(self.det)
+                cnt_out = torch.zeros_like(self.det_count)
+                b.det_in, b.count_in = self.det.data_ptr(), self.det_count.data_ptr()
+                b.inv_K, b.pose, b.group = self.invK_all.data_ptr(), self.pose_all.data_ptr(), group.data_ptr()
+                b.out_size = self.outsize_all.data_ptr()
+                b.G, b.det_cap, b.num_classes = G, self.det_cap, C_
+                b.iou_thresh, b.max_dets = float(inf.BEV_NMS_IOU_THRESH), int(max_dets)
+                b.write_global, b.do_postprocess = int(write_global), int(do_pp)
+                b.work, b.sbox, b.mask, b.meta = self.bev_work.data_ptr(), self.bev_sbox.data_ptr(), self.bev_mask.data_ptr(), self.bev_meta.data_ptr()
+                b.det_out, b.count_out = det_out.data_ptr(), cnt_out.data_ptr()
+                self.bev_args.append(b)
+                self.ops.append(CallOp(lambda lib, st, b=b: hip.check(lib.dd3d_bev_nms_aggregate(C.byref(b), st), name), name))
+                self.det, self.det_count = det_out, cnt_out  # what collect() reads
+
+            if bev_single:
+                stage(self.own_group, 0, False, bool(inf.DO_POSTPROCESS), "bev_nms")
+            if bev_sample:
+                stage(self.group_all, int(model.max_num_dets_per_sample), True, False, "nusc_sample_aggregate")
+                self.has_global_boxes = True
+
+    def gather_pairs(self):
+        """(local, global) tensors the multi-GPU step all-gathers between select/decode and the NMS stages."""
+        pairs = [(self.cand, self.cand_all), (self.counts, self.counts_all), (self.in_outsize, self.outsize_all)]
+        if self.pose_all is not None:
+            pairs += [(self.inv_K, self.invK_all), (self.in_pose, self.pose_all), (self.in_group, self.group_all)]
+        return pairs
 
 
 

@@ -71,8 +71,8 @@ class BevArgs(C.Structure):
     """`dd3d_bev_args`."""
     _fields_ = [
         ("det_in", C.c_void_p), ("count_in", C.c_void_p), ("inv_K", C.c_void_p), ("pose", C.c_void_p), ("group", C.c_void_p),
-        ("out_size", C.c_void_p), ("G", C.c_int32), ("det_cap", C.c_int32), ("num_classes", C.c_int32), ("first_local", C.c_int32),
-        ("num_local", C.c_int32), ("iou_thresh", C.c_float), ("max_dets", C.c_int32), ("write_global", C.c_int32),
+        ("out_size", C.c_void_p), ("G", C.c_int32), ("det_cap", C.c_int32), ("num_classes", C.c_int32),
+        ("iou_thresh", C.c_float), ("max_dets", C.c_int32), ("write_global", C.c_int32),
         ("do_postprocess", C.c_int32), ("work", C.c_void_p), ("sbox", C.c_void_p), ("mask", C.c_void_p), ("meta", C.c_void_p),
         ("det_out", C.c_void_p), ("count_out", C.c_void_p)
     ]

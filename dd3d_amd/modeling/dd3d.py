@@ -11,7 +11,7 @@ from torch import nn
 from dd3d_amd.engine import ForwardPlan
 from dd3d_amd.modeling.heads import FCOS2DHead, FCOS3DHead
 from dd3d_amd.registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY
-from dd3d_amd.structures import Boxes, Boxes3D, Instances, ShapeSpec
+from dd3d_amd.structures import Boxes, Boxes3D, GenericBoxes3D, Instances, ShapeSpec
 
 
 def build_feature_extractor(cfg, input_shape=None):
@@ -83,6 +83,7 @@ class DD3D(nn.Module):
         into the config the plan is built from."""
         inf = self.cfg.DD3D.INFERENCE
         inf.DO_POSTPROCESS, inf.DO_NMS = bool(self.postprocess_in_inference), bool(self.do_nms)
+        inf.DO_BEV_NMS, inf.BEV_NMS_IOU_THRESH = bool(self.do_bev_nms), float(self.bev_nms_iou_thresh)
         return (bool(self.postprocess_in_inference), bool(self.do_nms), bool(self.do_bev_nms))
 
     def get_plan(self, B, Hp, Wp, world_size=1):
@@ -128,7 +129,19 @@ class DD3D(nn.Module):
         plan.in_sizes.copy_(sizes, non_blocking=True)
         plan.in_K.copy_(K.reshape(B, 9), non_blocking=True)
         plan.in_outsize.copy_(outsz, non_blocking=True)
+        if getattr(plan, "pose_all", None) is not None:  # BEV stages need camera->global poses and sample membership
+            plan.in_pose.copy_(torch.tensor([self._pose_vec(x) for x in batched_inputs], dtype=torch.float32), non_blocking=True)
+            plan.in_group.copy_(torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32), non_blocking=True)
         return plan, image_sizes
+
+    @staticmethod
+    def _pose_vec(x):
+        """core.py:138-141: 'pose' if present, else 'extrinsics'; (quat wxyz, tvec) as postprocessing.py:34 reads them."""
+        pose = x["pose"] if "pose" in x else x["extrinsics"]
+        return [float(v) for v in pose.quat.elements] + [float(v) for v in pose.tvec]
+
+    def _sample_groups(self, batched_inputs):
+        return list(range(len(batched_inputs)))
 
     def collect(self, plan, batched_inputs, image_sizes, first=0):
         """Detection buffer -> List[{"instances": Instances}] with the reference's fields (core.py:153-164)."""
@@ -159,13 +172,15 @@ class DD3D(nn.Module):
                     inv_K[i][None].expand(n, 3, 3)
                 )
                 r.scores_3d = d[:, 5].contiguous()
+            self._collect_extra(r, d, plan)
             results.append({"instances": r})
         return results
 
+    def _collect_extra(self, r, d, plan):
+        pass
+
     @torch.no_grad()
     def forward(self, batched_inputs):
-        if self.do_bev_nms:
-            raise NotImplementedError("DD3D.INFERENCE.DO_BEV_NMS is not part of this round (default False, dd3d.yaml:15)")
         plan, image_sizes = self.stage_inputs(batched_inputs)
         plan.run()
         return self.collect(plan, batched_inputs, image_sizes)

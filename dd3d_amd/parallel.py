@@ -40,12 +40,12 @@ def owner_of_image(g, B):
     return g // B
 
 
-def gather_candidates(cand, counts, out_size, cand_all, counts_all, out_size_all, group=None):
-    """The step's only exchange: all_gather the local candidate buffer [B,F,NS], its per-level counts [B,L] and the
-    resize targets [B,4] into the rank-major global buffers [W*B, ...]."""
-    dist.all_gather_into_tensor(cand_all, cand, group=group)
-    dist.all_gather_into_tensor(counts_all, counts, group=group)
-    dist.all_gather_into_tensor(out_size_all, out_size, group=group)
+def gather_candidates(pairs, group=None):
+    """The step's only exchange: all_gather the local candidate buffer [B,F,NS], its per-level counts [B,L], the resize
+    targets [B,4] (and, for the nuScenes BEV stages, inverse intrinsics / poses / sample ids) into the rank-major global
+    buffers [W*B, ...].  `pairs` = ForwardPlan.gather_pairs()."""
+    for local, glob in pairs:
+        dist.all_gather_into_tensor(glob, local, group=group)
 
 
 class DistributedForward:
@@ -78,7 +78,7 @@ class DistributedForward:
             self.pre_graph.replay()
         else:
             p.launch(0, p.num_pre_nms_ops)
-        gather_candidates(p.cand, p.counts, p.in_outsize, p.cand_all, p.counts_all, p.outsize_all)
+        gather_candidates(p.gather_pairs())
         if self.post_graph is not None:
             self.post_graph.replay()
         else:

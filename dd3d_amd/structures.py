@@ -90,6 +90,9 @@ except Exception:
         def has(self, name):
             return name in self._fields
 
+        def remove(self, name):
+            del self._fields[name]
+
         def get(self, name):
             return self._fields[name]
 

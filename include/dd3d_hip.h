@@ -229,8 +229,7 @@ int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream);
  * (tridet/structures/boxes3d.py:47-64), pytorch3d Transform3d / rotation conversions [ext] and detectron2
  * batched_nms_rotated -> nms_rotated / box_iou_rotated [ext].
  *   det_in [G][det_cap][DD3D_DET_FIELDS], count_in [G]      as written by dd3d_nms_finalize
- *   inv_K [num_local][9]  inverse intrinsics of images first_local .. first_local+num_local-1 (the images this
- *                         rank decoded; with the RCCL gather every rank holds all G images' detections)
+ *   inv_K [G][9] inverse intrinsics (as written by dd3d_invert_intrinsics)
  *   pose [G][7] (quat wxyz, tvec) camera->global; group [G] sample index of each image (category id =
  *   class + group*num_classes); out_size as in dd3d_nms_finalize (used when do_postprocess)
  *   max_dets: cap on the batch-global, score-ordered keep list (0 = none; the reference truncates the whole batch,
@@ -247,7 +246,6 @@ typedef struct dd3d_bev_args {  /* host memory */
   const int32_t* group;
   const float* out_size;
   int32_t G, det_cap, num_classes;
-  int32_t first_local, num_local;
   float iou_thresh;
   int32_t max_dets;
   int32_t write_global;

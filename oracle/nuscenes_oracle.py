@@ -230,6 +230,7 @@ def nuscenes_dd3d_forward(sd, cfg, batched_inputs):
     """nuscenes_dd3d.py:337-469, inference branch.  Inputs carry 'pose' = (quat wxyz, tvec) and 'sample_token'."""
     stages = {}
     x, image_sizes, intrinsics = O.preprocess(sd, batched_inputs, O.size_divisibility(cfg))
+    stages["images"] = x
     features, strides, _ = O.dd3d_backbone(sd, cfg, x)
     locations = [
         O.compute_features_locations(f.shape[-2], f.shape[-1], s, cfg["DD3D"]["FEATURE_LOCATIONS_OFFSET"])

@@ -23,7 +23,8 @@ TRAINING_ONLY_KEYS = {  # keys the reference constructor reads for its loss / ta
             "LOSS": {"SMOOTH_L1_BETA": 0.05, "MAX_LOSS_PER_GROUP_DISENT": 20.0, "CONF_3D_TEMPERATURE": 1.0, "WEIGHT_BOX3D": 2.0,
                      "WEIGHT_CONF3D": 1.0},
             "PREPARE_TARGET": {"CENTER_SAMPLE": True, "POS_RADIUS": 1.5}
-        }
+        },
+        "NUSC": {"LOSS": {"WEIGHT_ATTR": 0.2, "WEIGHT_SPEED": 0.2}}
     }
 }
 
@@ -32,37 +33,72 @@ CASES = {
     "dla34_kitti_128x256_b1": ("dd3d_kitti_dla34", "dla34_kitti", 1, 128, 256, False),
     "dla34_kitti_128x384_b2_ragged": ("dd3d_kitti_dla34", "dla34_kitti", 2, 128, 384, True),
     "v99_kitti_128x256_b1": ("dd3d_kitti_v99", "v99_kitti", 1, 128, 256, False),
+    # one nuScenes sample = 6 cameras -> NuscenesDD3D incl. attribute / speed and the cross-camera BEV aggregation
+    "dla34_nusc_128x224_b6": ("dd3d_nusc_dla34", "dla34_nusc", 6, 128, 224, False),
+    # DD3D.INFERENCE.DO_BEV_NMS on top (per-image BEV NMS before the resize, core.py:135-150)
+    "dla34_nusc_128x224_b6_bevnms": ("dd3d_nusc_dla34", "dla34_nusc", 6, 128, 224, False),
 }
+# the 128x224 images yield few candidates at the default threshold; lower it so that the BEV stages have work to do.  The
+# second case also trips the per-sample cap (nuscenes_dd3d.py:333, postprocessing.py:93-94).
+EXTRA_OVERRIDES = {
+    "dla34_nusc_128x224_b6": {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}}},
+    "dla34_nusc_128x224_b6_bevnms": {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}, "INFERENCE": {"DO_BEV_NMS": True},
+                                              "NUSC": {"INFERENCE": {"MAX_NUM_DETS_PER_SAMPLE": 60}}}},
+}
+DETECTIONS_ONLY = {"dla34_nusc_128x224_b6_bevnms"}  # same head maps as the case above
 
 
 def build_reference_model(cfg):
     ref_shims.install()
-    from tridet.modeling.dd3d.core import DD3D  # the reference's own class
-    model = DD3D(cfg)
+    if cfg.MODEL.META_ARCHITECTURE == "NuscenesDD3D":
+        from tridet.modeling.dd3d.nuscenes_dd3d import NuscenesDD3D as cls  # the reference's own class
+    else:
+        from tridet.modeling.dd3d.core import DD3D as cls
+    model = cls(cfg)
     model.eval()
     return model
 
 
-def case_inputs(B, H, W, ragged):
+def case_inputs(B, H, W, ragged, dataset="kitti", reference_pose=False):
     from dd3d_amd.synthetic import make_inputs
-    inputs = make_inputs(B, H, W)
+    inputs = make_inputs(B, H, W, dataset=dataset)
+    if dataset != "kitti":
+        if reference_pose:  # the reference reads pose.quat.elements / pose.tvec of ITS Pose class (postprocessing.py:34)
+            from tridet.structures.pose import Pose as RefPose
+            for x in inputs:
+                x["pose"] = RefPose(wxyz=x["pose"].quat.elements, tvec=x["pose"].tvec)
+        for x in inputs:  # a resize target different from the network input, so the resize before the aggregation matters
+            x["height"], x["width"] = 2 * H + 4, 2 * W
     if ragged:
         inputs[1]["image"] = inputs[1]["image"][:, :H - 13, :W - 22].contiguous()
         inputs[1]["height"], inputs[1]["width"] = 99, 301
     return inputs
 
 
-def main():
+def _merge(a, b):
+    out = dict(a)
+    for k, v in b.items():
+        out[k] = _merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+    return out
+
+
+def main(only=None):
     import dd3d_amd.modeling  # noqa: F401
     from dd3d_amd import META_ARCH_REGISTRY, get_cfg
     from dd3d_amd.synthetic import load_calib, make_state_dict
     for name, (exp, tag, B, H, W, ragged) in CASES.items():
-        cfg = get_cfg(exp, TRAINING_ONLY_KEYS)
+        if only and name not in only:
+            continue
+        over = dict(TRAINING_ONLY_KEYS)
+        for k, v in EXTRA_OVERRIDES.get(name, {}).items():
+            over = _merge(over, {k: v})
+        cfg = get_cfg(exp, over)
         ours = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
         sd = make_state_dict(ours, calib=load_calib(tag))
         ref = build_reference_model(cfg)
         missing, unexpected = ref.load_state_dict(sd, strict=True)  # same key set, or this raises
-        inputs = case_inputs(B, H, W, ragged)
+        nusc = "nusc" in exp
+        inputs = case_inputs(B, H, W, ragged, "nusc" if nusc else "kitti", reference_pose=True)
         out = {}
         with torch.no_grad():
             # head maps through the reference's own modules (core.py:65-92)
@@ -73,8 +109,12 @@ def main():
             feats = [feats[f] for f in ref.in_features]
             logits, box2d_reg, centerness, _ = ref.fcos2d_head(feats)
             quat, ctr, depth, size, conf, _ = ref.fcos3d_head(feats)
+            if nusc and name not in DETECTIONS_ONLY:
+                _, _, _, extra = ref.fcos2d_head(feats)
+                for l, t in enumerate(extra["cls_tower_out"]):
+                    out[f"attr{l}"], out[f"speed{l}"] = ref.attr_logits(t).numpy(), ref.speed(t).numpy()
             out["images"] = il.tensor.numpy()
-            for l in range(len(feats)):
+            for l in range(len(feats) if name not in DETECTIONS_ONLY else 0):
                 if l >= 2:  # the fine levels are large; their content is covered by the head maps below
                     out[f"feat{l}"] = feats[l].numpy()
                 out[f"logits{l}"], out[f"box2d_reg{l}"], out[f"centerness{l}"] = logits[l].numpy(), box2d_reg[l].numpy(), centerness[l].numpy()
@@ -95,10 +135,13 @@ def main():
             out[f"det{i}_depth"], out[f"det{i}_size"] = b3.depth.numpy(), b3.size.numpy()
             out[f"det{i}_tvec"] = b3.tvec.numpy()
             out[f"det{i}_vectorize"] = b3.vectorize().numpy()
+            if nusc:
+                out[f"det{i}_attributes"], out[f"det{i}_speeds"] = inst.pred_attributes.numpy(), inst.pred_speeds.numpy()
+                out[f"det{i}_global"] = inst.pred_boxes3d_global.vectorize().numpy()
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", [len(r["instances"]) for r in results])
 
 
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))

@@ -259,9 +259,136 @@ def detector_postprocess(results, output_height, output_width, mask_threshold=0.
 
 
 # --------------------------------------------------------------------------------------------- pytorch3d [ext]
-class _T3D:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("pytorch3d Transform3d shim: only needed by Boxes3D.corners / BEV NMS")
+class Transform3d:
+    """[ext] pytorch3d.transforms.Transform3d, the slice postprocessing.py / bev_nms.py / boxes3d.py use: row-vector
+    convention (points @ M), 4x4 matrices batched on dim 0, ``compose`` = apply self first, then the others."""
+    def __init__(self, dtype=torch.float32, device="cpu", matrix=None):
+        if matrix is None:
+            self._matrix = torch.eye(4, dtype=dtype, device=device).view(1, 4, 4)
+        else:
+            self._matrix = matrix.view(-1, 4, 4)
+        self._others = []
+
+    def compose(self, *others):
+        out = Transform3d(matrix=self._matrix)
+        out._others = self._others + list(others)
+        return out
+
+    def get_matrix(self):
+        m = self._matrix
+        for o in self._others:
+            m = torch.matmul(m, o.get_matrix())  # broadcast over the batch
+        return m
+
+    def transform_points(self, points):
+        p = points if points.dim() == 3 else points[None]
+        ones = torch.ones(p.shape[0], p.shape[1], 1, dtype=p.dtype, device=p.device)
+        out = torch.bmm(torch.cat([p, ones], dim=2), self.get_matrix().expand(p.shape[0], 4, 4))
+        out = out[..., :3] / out[..., 3:]
+        return out if points.dim() == 3 else out[0]
+
+
+class Translate(Transform3d):
+    def __init__(self, x, y=None, z=None, dtype=torch.float32, device="cpu"):
+        xyz = x if y is None else torch.stack([torch.as_tensor(x), torch.as_tensor(y), torch.as_tensor(z)], -1)
+        xyz = xyz.view(-1, 3)
+        m = torch.eye(4, dtype=xyz.dtype, device=xyz.device).view(1, 4, 4).repeat(xyz.shape[0], 1, 1)
+        m[:, 3, :3] = xyz
+        super().__init__(matrix=m)
+
+
+class Rotate(Transform3d):
+    def __init__(self, R, dtype=torch.float32, device="cpu", orthogonal_tol=1e-5):
+        R = R.view(-1, 3, 3)
+        m = torch.eye(4, dtype=R.dtype, device=R.device).view(1, 4, 4).repeat(R.shape[0], 1, 1)
+        m[:, :3, :3] = R
+        super().__init__(matrix=m)
+
+
+class RotatedBoxes:
+    """[ext] detectron2.structures.RotatedBoxes: (cx, cy, w, h, angle_deg CCW) rows."""
+    def __init__(self, tensor):
+        self.tensor = tensor.reshape(-1, 5).to(torch.float32)
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+
+def _poly_clip_area(b1, b2):
+    """Intersection area of two rotated rectangles by Sutherland-Hodgman clipping in float64 -- deliberately NOT the
+    detectron2 algorithm the oracle restates, so that the goldens cross-check it."""
+    import math
+
+    def verts(b):
+        cx, cy, w, h, a = [float(v) for v in b]
+        th = math.radians(a)
+        c, s = math.cos(th), math.sin(th)
+        # detectron2 convention (box_iou_rotated_utils.h get_rotated_vertices): vertex = centre + R(theta) (dx, dy)
+        return [(cx + c * dx - s * dy, cy + s * dx + c * dy) for dx, dy in ((-w / 2, -h / 2), (w / 2, -h / 2), (w / 2, h / 2), (-w / 2, h / 2))]
+
+    def area(p):
+        return 0.5 * sum(p[i][0] * p[(i + 1) % len(p)][1] - p[(i + 1) % len(p)][0] * p[i][1] for i in range(len(p)))
+
+    subj, clip = verts(b1), verts(b2)
+    if area(clip) < 0:
+        clip = clip[::-1]
+    for i in range(4):
+        a, b = clip[i], clip[(i + 1) % 4]
+        inside = lambda p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]) >= 0
+        out = []
+        for j in range(len(subj)):
+            p, q = subj[j], subj[(j + 1) % len(subj)]
+            ip, iq = inside(p), inside(q)
+            if ip != iq:
+                d1 = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+                d2 = (b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0])
+                t = d1 / (d1 - d2)
+                x = (p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1]))
+                if ip:
+                    out += [x]
+                else:
+                    out += [x, q]
+            elif ip:
+                out.append(q)
+        subj = out
+        if len(subj) < 3:
+            return 0.0
+    return abs(area(subj))
+
+
+def _nms_rotated(boxes, scores, thr):
+    order = torch.argsort(scores, descending=True, stable=True).tolist()
+    b = boxes.double().tolist()
+    keep, dead = [], set()
+    for ii, i in enumerate(order):
+        if i in dead:
+            continue
+        keep.append(i)
+        ai = b[i][2] * b[i][3]
+        for j in order[ii + 1:]:
+            if j in dead:
+                continue
+            aj = b[j][2] * b[j][3]
+            if max(abs(b[i][0] - b[j][0]), abs(b[i][1] - b[j][1])) > 0.5 * (math.hypot(b[i][2], b[i][3]) + math.hypot(b[j][2], b[j][3])):
+                continue
+            inter = _poly_clip_area(b[i], b[j])
+            if inter / max(ai + aj - inter, 1e-30) > thr:
+                dead.add(j)
+    return torch.tensor(keep, dtype=torch.int64)
+
+
+def batched_nms_rotated(boxes, scores, idxs, iou_threshold):
+    """[ext] detectron2.layers.nms.batched_nms_rotated: offset the centres per category, one nms_rotated call."""
+    assert boxes.shape[-1] == 5
+    if boxes.numel() == 0:
+        return torch.empty((0, ), dtype=torch.int64)
+    boxes = boxes.float()
+    max_coordinate = (torch.max(boxes[:, 0], boxes[:, 1]) + torch.max(boxes[:, 2], boxes[:, 3]) / 2).max()
+    min_coordinate = (torch.min(boxes[:, 0], boxes[:, 1]) - torch.max(boxes[:, 2], boxes[:, 3]) / 2).min()
+    offsets = idxs.to(boxes) * (max_coordinate - min_coordinate + 1)
+    b = boxes.clone()
+    b[:, :2] += offsets[:, None]
+    return _nms_rotated(b, scores, iou_threshold)
 
 
 class Quaternion:
@@ -341,11 +468,8 @@ def install():
     _mod("detectron2.layers", Conv2d=Conv2d, get_norm=get_norm, FrozenBatchNorm2d=FrozenBatchNorm2d, ShapeSpec=ShapeSpec, cat=cat,
          batched_nms=batched_nms)
 
-    def _no_rot(*a, **k):
-        raise NotImplementedError("nms_rotated shim")
-
-    _mod("detectron2.layers.nms", batched_nms_rotated=_no_rot)
-    _mod("detectron2.structures", Boxes=Boxes, Instances=Instances, RotatedBoxes=type("RotatedBoxes", (), {}))
+    _mod("detectron2.layers.nms", batched_nms_rotated=batched_nms_rotated)
+    _mod("detectron2.structures", Boxes=Boxes, Instances=Instances, RotatedBoxes=RotatedBoxes)
     _mod("detectron2.utils")
     _mod("detectron2.utils.comm", get_world_size=lambda: 1, get_rank=lambda: 0, is_main_process=lambda: True, synchronize=lambda: None)
     _mod("detectron2.utils.env", TORCH_VERSION=tuple(int(x) for x in torch.__version__.split(".")[:2]))
@@ -371,7 +495,9 @@ def install():
     _mod("pytorch3d.transforms")
     _mod("pytorch3d.transforms.rotation_conversions", quaternion_to_matrix=O.quaternion_to_matrix,
          matrix_to_quaternion=O.matrix_to_quaternion)
-    _mod("pytorch3d.transforms.transform3d", Translate=_T3D, Rotate=_T3D, Transform3d=_T3D)
+    t3d = _mod("pytorch3d.transforms.transform3d", Translate=Translate, Rotate=Rotate, Transform3d=Transform3d)
+    sys.modules["pytorch3d.transforms"].transform3d = t3d
+    _mod("fvcore.nn.smooth_l1_loss", smooth_l1_loss=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("training only")))
     _mod("pyquaternion", Quaternion=Quaternion)
     _mod("mpi4py", MPI=types.SimpleNamespace(COMM_WORLD=None))
     _mod("cv2")
@@ -379,6 +505,9 @@ def install():
     for pkg in ("tridet", "tridet.modeling", "tridet.modeling.dd3d", "tridet.utils", "tridet.structures"):
         m = _mod(pkg)
         m.__path__ = [os.path.join(REFERENCE_ROOT, *pkg.split("."))]
+    for pkg in ("tridet.data", "tridet.data.datasets", "tridet.data.datasets.nuscenes"):
+        _mod(pkg)
+    _mod("tridet.data.datasets.nuscenes.build", MAX_NUM_ATTRIBUTES=3)  # tridet/data/datasets/nuscenes/build.py:77 (needs the devkit)
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     return d2

@@ -9,7 +9,8 @@ import torch
 import torch.nn.functional as F
 
 from oracle import dd3d_oracle as O
-from tests.golden.make_golden import CASES, case_inputs
+from oracle import nuscenes_oracle as N
+from tests.golden.make_golden import CASES, DETECTIONS_ONLY, EXTRA_OVERRIDES, case_inputs
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -18,21 +19,24 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 def test_oracle_matches_reference_golden(name):
     from tests.util import bundle
     exp, tag, B, H, W, ragged = CASES[name]
-    cfg, sd = bundle(exp, tag)
+    nusc = "nusc" in exp
+    cfg, sd = bundle(exp, tag, EXTRA_OVERRIDES.get(name))
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    inputs = case_inputs(B, H, W, ragged)
+    inputs = case_inputs(B, H, W, ragged, "nusc" if nusc else "kitti")
     with torch.no_grad():
-        res, st = O.dd3d_forward(sd, cfg, inputs)
+        res, st = N.nuscenes_dd3d_forward(sd, cfg, inputs) if nusc else O.dd3d_forward(sd, cfg, inputs)
     t = lambda k: torch.from_numpy(g[k])
     assert torch.equal(st["images"], t("images"))
-    for l in range(5):
+    for l in range(5 if name not in DETECTIONS_ONLY else 0):
+        if nusc:
+            assert torch.allclose(st["attr"][l], t(f"attr{l}"), rtol=1e-5, atol=2e-5) and torch.allclose(st["speed"][l], t(f"speed{l}"), rtol=1e-5, atol=2e-5)
         if f"feat{l}" in g:
             assert torch.allclose(st["features"][l], t(f"feat{l}"), rtol=1e-5, atol=1e-5)
         for k in ("logits", "box2d_reg", "centerness", "quat", "ctr", "depth", "size", "conf"):
             assert torch.allclose(st[k][l], t(f"{k}{l}"), rtol=1e-5, atol=2e-5), (k, l)
     for i in range(B):
         r = res[i]
-        assert len(r["scores"]) == len(g[f"det{i}_scores"]) > 0
+        assert len(r["scores"]) == len(g[f"det{i}_scores"]) > 0, (i, len(r["scores"]), len(g[f"det{i}_scores"]))
         assert torch.equal(r["pred_classes"], t(f"det{i}_classes")) and torch.equal(r["fpn_levels"], t(f"det{i}_levels"))
         assert torch.equal(r["locations"], t(f"det{i}_locations"))
         assert torch.allclose(r["pred_boxes"], t(f"det{i}_boxes"), rtol=1e-5, atol=1e-4)
@@ -43,6 +47,11 @@ def test_oracle_matches_reference_golden(name):
         assert torch.allclose(b["depth"], t(f"det{i}_depth"), rtol=1e-5) and torch.allclose(b["size"], t(f"det{i}_size"), rtol=1e-5)
         assert torch.allclose(O.boxes3d_tvec(b), t(f"det{i}_tvec"), rtol=1e-5, atol=1e-5)
         assert torch.allclose(O.boxes3d_vectorize(b), t(f"det{i}_vectorize"), rtol=1e-5, atol=1e-5)
+        if nusc:
+            assert torch.equal(r["pred_attributes"], t(f"det{i}_attributes")) and torch.allclose(r["pred_speeds"], t(f"det{i}_speeds"), rtol=1e-5, atol=1e-6)
+            gl, gg = r["pred_boxes3d_global"], t(f"det{i}_global")
+            assert torch.allclose(gl[:, 4:], gg[:, 4:], rtol=1e-5, atol=2e-4)  # tvec ~ 1e3 m (world frame), size
+            assert float(torch.minimum((gl[:, :4] - gg[:, :4]).abs().amax(1), (gl[:, :4] + gg[:, :4]).abs().amax(1)).max()) < 1e-5
 
 
 def test_rotation_conversions_roundtrip():

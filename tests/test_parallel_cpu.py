@@ -26,7 +26,7 @@ def _worker(rank, world, port, B, F, NS, L, ret):
     counts = torch.randint(0, 50, (B, L), generator=g, dtype=torch.int32)
     outsz = torch.full((B, 4), float(rank))
     cand_all, counts_all, outsz_all = torch.zeros(world * B, F, NS), torch.zeros(world * B, L, dtype=torch.int32), torch.zeros(world * B, 4)
-    gather_candidates(cand, counts, outsz, cand_all, counts_all, outsz_all)
+    gather_candidates([(cand, cand_all), (counts, counts_all), (outsz, outsz_all)])
     ok = True
     for src in range(world):  # every rank can regenerate every other rank's payload
         g2 = torch.Generator().manual_seed(100 + src)
@@ -41,7 +41,7 @@ def _worker(rank, world, port, B, F, NS, L, ret):
 
 
 def test_gather_candidates_gloo_world2():
-    world, B, F, NS, L = 2, 3, 20, 40, 5
+    world, B, F, NS, L = 2, 3, 22, 40, 5
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), B, F, NS, L, ret), nprocs=world, join=True)

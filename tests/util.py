@@ -5,14 +5,14 @@ import torch
 _BUNDLES = {}
 
 
-def bundle(experiment, tag):
+def bundle(experiment, tag, overrides=None):
     """(cfg, synthetic CPU state_dict) of one of the reference experiments, cached per session."""
-    key = (experiment, tag)
+    key = (experiment, tag, repr(overrides))
     if key not in _BUNDLES:
         import dd3d_amd.modeling  # noqa: F401
         from dd3d_amd import META_ARCH_REGISTRY, get_cfg
         from dd3d_amd.synthetic import load_calib, make_state_dict
-        cfg = get_cfg(experiment)
+        cfg = get_cfg(experiment, overrides)
         model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
         _BUNDLES[key] = (cfg, make_state_dict(model, calib=load_calib(tag)))
     return _BUNDLES[key]
