@@ -283,7 +283,7 @@ class PlanBase:
 
 class ForwardPlan(PlanBase):
     """Static launch plan of DD3D.forward (inference) for one (B, Hp, Wp)."""
-    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False):
+    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0):
         super().__init__(device or model.device, dry_run=dry_run)
         self.model = model
         self.B, self.Hp, self.Wp = B, Hp, Wp
@@ -324,7 +324,7 @@ class ForwardPlan(PlanBase):
 
         # ---- heads + post-processing
         self._heads(model, self.features)
-        self._postprocess(model, world_size)
+        self._postprocess(model, world_size, rank)
         self._finalize_workspace()
 
     # ------------------------------------------------------------------ DLA-34 (dla.py:170-355)
@@ -617,7 +617,7 @@ class ForwardPlan(PlanBase):
             self.b3d_maps, self.b3d_pitch = fused_predictor("box3d_map", preds, 2, s3, b3, None)
 
     # ------------------------------------------------------------------ selection / decode / NMS
-    def _postprocess(self, model, world_size):
+    def _postprocess(self, model, world_size, rank=0):
         cfg, dev, B = model.cfg, self.device, self.B
         L = len(self.features)
         inf2 = cfg.DD3D.FCOS2D.INFERENCE
@@ -705,57 +705,52 @@ class ForwardPlan(PlanBase):
         self.nms_args = n
         self.nms_op = CallOp(lambda lib, st: hip.check(lib.dd3d_nms_finalize(C.byref(n), st), "nms_finalize"), "nms_finalize")
         self.ops.append(self.nms_op)
-        self.pose_all = self.group_all = self.invK_all = None
-        self.has_global_boxes = False
+        self.has_bev_inputs = self.has_global_boxes = False
         if bev_single or bev_sample:
+            # The images that meet in a BEV stage (one image, or the 6 cameras of a sample) are always on the rank that
+            # decoded them (InferenceGroupSampler hands out whole samples, tridet/data/samplers.py), so with W ranks the
+            # stages run over this rank's slice [rank*B, (rank+1)*B) of the gathered detection buffers.
+            first = rank * B
+            self.has_bev_inputs = True
             self.in_pose = torch.zeros((B, 7), dtype=torch.float32, device=dev)
             self.in_pose[:, 0] = 1.0
             self.in_group = torch.zeros((B, ), dtype=torch.int32, device=dev)
-            if world_size > 1:
-                self.pose_all = torch.zeros((G, 7), dtype=torch.float32, device=dev)
-                self.group_all = torch.zeros((G, ), dtype=torch.int32, device=dev)
-                self.invK_all = torch.zeros((G, 9), dtype=torch.float32, device=dev)
-            else:
-                self.pose_all, self.group_all, self.invK_all = self.in_pose, self.in_group, self.inv_K
-            ntot = G * self.det_cap
+            ntot = B * self.det_cap
             if ntot > 8192:
-                raise NotImplementedError(f"BEV NMS over {G} images x {self.det_cap} detections exceeds the 8192-box LDS sorter")
+                raise NotImplementedError(f"BEV NMS over {B} images x {self.det_cap} detections exceeds the 8192-box LDS sorter")
             ncapb = (ntot + 63) // 64 * 64
             self.bev_work = torch.zeros((ntot, 16), dtype=torch.float32, device=dev)
             self.bev_sbox = torch.zeros((ntot, 8), dtype=torch.float32, device=dev)
             self.bev_mask = torch.zeros((ncapb, ncapb // 64), dtype=torch.int64, device=dev)
             self.bev_meta = torch.zeros((4, ), dtype=torch.int32, device=dev)
-            self.own_group = torch.arange(G, dtype=torch.int32, device=dev)  # dummy_group_idxs = {i: [i]} (core.py:137)
+            self.own_group = torch.arange(B, dtype=torch.int32, device=dev)  # dummy_group_idxs = {i: [i]} (core.py:137)
             self.bev_args = []
 
             def stage(group, max_dets, write_global, do_pp, name):
                 b = hip.BevArgs()
                 det_out = torch.zeros_like(self.det)
                 cnt_out = torch.zeros_like(self.det_count)
-                b.det_in, b.count_in = self.det.data_ptr(), self.det_count.data_ptr()
-                b.inv_K, b.pose, b.group = self.invK_all.data_ptr(), self.pose_all.data_ptr(), group.data_ptr()
-                b.out_size = self.outsize_all.data_ptr()
-                b.G, b.det_cap, b.num_classes = G, self.det_cap, C_
+                b.det_in, b.count_in = self.det[first:].data_ptr(), self.det_count[first:].data_ptr()
+                b.inv_K, b.pose, b.group = self.inv_K.data_ptr(), self.in_pose.data_ptr(), group.data_ptr()
+                b.out_size = self.in_outsize.data_ptr()
+                b.G, b.det_cap, b.num_classes = B, self.det_cap, C_
                 b.iou_thresh, b.max_dets = float(inf.BEV_NMS_IOU_THRESH), int(max_dets)
                 b.write_global, b.do_postprocess = int(write_global), int(do_pp)
                 b.work, b.sbox, b.mask, b.meta = self.bev_work.data_ptr(), self.bev_sbox.data_ptr(), self.bev_mask.data_ptr(), self.bev_meta.data_ptr()
-                b.det_out, b.count_out = det_out.data_ptr(), cnt_out.data_ptr()
+                b.det_out, b.count_out = det_out[first:].data_ptr(), cnt_out[first:].data_ptr()
                 self.bev_args.append(b)
                 self.ops.append(CallOp(lambda lib, st, b=b: hip.check(lib.dd3d_bev_nms_aggregate(C.byref(b), st), name), name))
-                self.det, self.det_count = det_out, cnt_out  # what collect() reads
+                self.det, self.det_count = det_out, cnt_out  # what collect() reads (this rank's slice only when W > 1)
 
             if bev_single:
                 stage(self.own_group, 0, False, bool(inf.DO_POSTPROCESS), "bev_nms")
             if bev_sample:
-                stage(self.group_all, int(model.max_num_dets_per_sample), True, False, "nusc_sample_aggregate")
+                stage(self.in_group, int(model.max_num_dets_per_sample), True, False, "nusc_sample_aggregate")
                 self.has_global_boxes = True
 
     def gather_pairs(self):
         """(local, global) tensors the multi-GPU step all-gathers between select/decode and the NMS stages."""
-        pairs = [(self.cand, self.cand_all), (self.counts, self.counts_all), (self.in_outsize, self.outsize_all)]
-        if self.pose_all is not None:
-            pairs += [(self.inv_K, self.invK_all), (self.in_pose, self.pose_all), (self.in_group, self.group_all)]
-        return pairs
+        return [(self.cand, self.cand_all), (self.counts, self.counts_all), (self.in_outsize, self.outsize_all)]
 
 
 

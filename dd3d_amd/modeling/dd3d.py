@@ -86,11 +86,11 @@ class DD3D(nn.Module):
         inf.DO_BEV_NMS, inf.BEV_NMS_IOU_THRESH = bool(self.do_bev_nms), float(self.bev_nms_iou_thresh)
         return (bool(self.postprocess_in_inference), bool(self.do_nms), bool(self.do_bev_nms))
 
-    def get_plan(self, B, Hp, Wp, world_size=1):
-        key = (B, Hp, Wp, world_size) + self._sync_flags()
+    def get_plan(self, B, Hp, Wp, world_size=1, rank=0):
+        key = (B, Hp, Wp, world_size, rank) + self._sync_flags()
         plan = self._plans.get(key)
         if plan is None:
-            plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size)
+            plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank)
             if self.use_graph and world_size == 1:
                 plan.capture()
             self._plans[key] = plan
@@ -129,7 +129,7 @@ class DD3D(nn.Module):
         plan.in_sizes.copy_(sizes, non_blocking=True)
         plan.in_K.copy_(K.reshape(B, 9), non_blocking=True)
         plan.in_outsize.copy_(outsz, non_blocking=True)
-        if getattr(plan, "pose_all", None) is not None:  # BEV stages need camera->global poses and sample membership
+        if plan.has_bev_inputs:  # BEV stages need camera->global poses and sample membership
             plan.in_pose.copy_(torch.tensor([self._pose_vec(x) for x in batched_inputs], dtype=torch.float32), non_blocking=True)
             plan.in_group.copy_(torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32), non_blocking=True)
         return plan, image_sizes

@@ -42,8 +42,7 @@ def owner_of_image(g, B):
 
 def gather_candidates(pairs, group=None):
     """The step's only exchange: all_gather the local candidate buffer [B,F,NS], its per-level counts [B,L], the resize
-    targets [B,4] (and, for the nuScenes BEV stages, inverse intrinsics / poses / sample ids) into the rank-major global
-    buffers [W*B, ...].  `pairs` = ForwardPlan.gather_pairs()."""
+    targets [B,4] into the rank-major global buffers [W*B, ...].  `pairs` = ForwardPlan.gather_pairs()."""
     for local, glob in pairs:
         dist.all_gather_into_tensor(glob, local, group=group)
 
@@ -56,7 +55,7 @@ class DistributedForward:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         model.use_graph = use_graph
-        self.plan = p = model.get_plan(B, Hp, Wp, world_size=self.world)  # world 1: the whole forward is one hipGraph
+        self.plan = p = model.get_plan(B, Hp, Wp, world_size=self.world, rank=self.rank)  # world 1: the whole forward is one hipGraph
         self.B = B
         self.pre_graph = self.post_graph = None
         if use_graph and self.world > 1:

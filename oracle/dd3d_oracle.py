@@ -583,9 +583,13 @@ def dd3d_forward(sd, cfg, batched_inputs, hook=None, stop_after_heads=False):
         return None, stages
     inv_intrinsics = intrinsics.inverse()  # core.py:93
     stages["inv_intrinsics"] = inv_intrinsics
-    results, stages2 = dd3d_postprocess_from_heads(
-        cfg, stages, locations, inv_intrinsics, image_sizes, batched_inputs
-    )
+    if cfg["DD3D"]["INFERENCE"]["DO_BEV_NMS"]:  # core.py:135-150 lives with the other BEV code
+        from oracle.nuscenes_oracle import nuscenes_postprocess_from_heads
+        results, stages2 = nuscenes_postprocess_from_heads(
+            cfg, stages, locations, inv_intrinsics, image_sizes, batched_inputs, sample_aggregate=False
+        )
+    else:
+        results, stages2 = dd3d_postprocess_from_heads(cfg, stages, locations, inv_intrinsics, image_sizes, batched_inputs)
     stages.update(stages2)
     return results, stages
 

@@ -249,14 +249,20 @@ def nuscenes_dd3d_forward(sd, cfg, batched_inputs):
     return results, stages
 
 
-def nuscenes_postprocess_from_heads(cfg, heads, locations, inv_K, image_sizes, batched_inputs):
+def nuscenes_postprocess_from_heads(cfg, heads, locations, inv_K, image_sizes, batched_inputs, sample_aggregate=True):
+    """The post-head part of NuscenesDD3D.forward; with sample_aggregate=False and no attr/speed maps it is DD3D.forward's
+    (core.py:114-164) including the DO_BEV_NMS branch."""
     L, B = len(heads["logits"]), len(image_sizes)
-    pred = []
+    pred, infos = [], []
     for l in range(L):
         r, info = O.fcos2d_inference_level(heads["logits"][l], heads["box2d_reg"][l], heads["centerness"][l], locations[l], cfg)
         for inst in r:
             inst["fpn_levels"] = torch.ones(len(inst["scores"]), dtype=torch.long) * l
         O.fcos3d_inference_level(heads["quat"][l], heads["ctr"][l], heads["depth"][l], heads["size"][l], heads["conf"][l], inv_K, r, info, cfg)
+        infos.append(info)
+        if "attr" not in heads:
+            pred.append(r)
+            continue
         # NuscenesInference (nuscenes_dd3d.py:268-296)
         a = heads["attr"][l].permute(0, 2, 3, 1).reshape(B, -1, MAX_NUM_ATTRIBUTES)
         s = heads["speed"][l].permute(0, 2, 3, 1).reshape(B, -1)
@@ -269,11 +275,12 @@ def nuscenes_postprocess_from_heads(cfg, heads, locations, inv_K, image_sizes, b
             r[i]["pred_speeds"] = s_i
         pred.append(r)
     per_image = [O._cat_instances([pred[l][i] for l in range(L)]) for i in range(B)]
-    stages = {"candidates": per_image}
+    stages = {"candidates": per_image, "level_info": infos}
     inf = cfg["DD3D"]["INFERENCE"]
     if inf["DO_NMS"]:
         per_image = [O.nms_and_top_k(x, cfg, "scores_3d") for x in per_image]
-    poses = [_pose_tuple(x["pose"]) for x in batched_inputs]
+    if inf["DO_BEV_NMS"] or (sample_aggregate and inf["DO_POSTPROCESS"]):
+        poses = [_pose_tuple(x["pose"] if "pose" in x else x["extrinsics"]) for x in batched_inputs]  # core.py:138-141
     if inf["DO_BEV_NMS"]:
         per_image, _ = nuscenes_sample_aggregate(
             per_image, OrderedDict((i, [i]) for i in range(B)), cfg["DD3D"]["NUM_CLASSES"], poses, inf["BEV_NMS_IOU_THRESH"],
@@ -286,6 +293,8 @@ def nuscenes_postprocess_from_heads(cfg, heads, locations, inv_K, image_sizes, b
         for inst, inp, isz in zip(per_image, batched_inputs, image_sizes)
     ]
     stages["before_aggregate"] = per_image
+    if not sample_aggregate:
+        return per_image, stages
     nus = cfg["DD3D"]["NUSC"]["INFERENCE"]
     groups = get_group_idxs([x["sample_token"] for x in batched_inputs], nus["NUM_IMAGES_PER_SAMPLE"])
     out, agg = nuscenes_sample_aggregate(

@@ -96,7 +96,7 @@ def test_forward_matches_oracle(hiplib, kitti_dla34, H, W, B):
             assert rel_err(o.scores_3d[io], r["scores_3d"][ir]) < REL_TOL
     # integer-exact part: identical head maps in, identical candidates / detections out
     oracle_heads_to_plan(plan, st, C)
-    plan.launch(first=len(plan.ops) - 2)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
     torch.cuda.synchronize()
     for i in range(B):
         c, rc = candidates_from_plan(plan, i), st["candidates"][i]
@@ -123,7 +123,7 @@ def test_topk_and_per_class_nms_paths(hiplib, kitti_dla34):
     plan, image_sizes = model.stage_inputs(inputs)
     plan.run()
     oracle_heads_to_plan(plan, st, cfg.DD3D.NUM_CLASSES)
-    plan.launch(first=len(plan.ops) - 2)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
     torch.cuda.synchronize()
     assert plan.npass[0].cpu().tolist() == npass
     c, rc = candidates_from_plan(plan, 0), st["candidates"][0]
@@ -169,33 +169,43 @@ def test_error_behaviour(hiplib, kitti_dla34):
         model(inputs)
 
 
-@pytest.mark.parametrize("name", ["dla34_kitti_128x256_b1", "dla34_kitti_128x384_b2_ragged", "v99_kitti_128x256_b1"])
+@pytest.mark.parametrize(
+    "name", ["dla34_kitti_128x256_b1", "dla34_kitti_128x384_b2_ragged", "v99_kitti_128x256_b1", "dla34_nusc_128x224_b6", "dla34_nusc_128x224_b6_bevnms"]
+)
 def test_hip_matches_reference_golden(hiplib, name):
     """HIP path vs the committed golden vectors (produced by the reference's own DD3D.forward, tests/golden/make_golden.py):
     head maps within float tolerance end-to-end; with the golden head maps as input, the HIP post-processing reproduces the
     reference's detections (classes / levels / locations bit-exact, floats within 1e-3 rel)."""
     import os
     import numpy as np
-    from tests.golden.make_golden import CASES, case_inputs
+    from tests.golden.make_golden import CASES, DETECTIONS_ONLY, EXTRA_OVERRIDES, case_inputs
     from tests.util import bundle
     exp, tag, B, H, W, ragged = CASES[name]
-    cfg, sd = bundle(exp, tag)
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
-    t = lambda k: torch.from_numpy(g[k])
+    nusc = "nusc" in exp
+    cfg, sd = bundle(exp, tag, EXTRA_OVERRIDES.get(name))
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(gold, name + ".npz"))
+    gh = np.load(os.path.join(gold, "dla34_nusc_128x224_b6.npz")) if name in DETECTIONS_ONLY else g  # same weights and inputs
+    t = lambda k: torch.from_numpy(g[k] if k in g else gh[k])
     model = gpu_model(cfg, sd, use_graph=False)
-    inputs = case_inputs(B, H, W, ragged)
+    inputs = case_inputs(B, H, W, ragged, "nusc" if nusc else "kitti")
     plan, image_sizes = model.stage_inputs(inputs)
     plan.run()
     torch.cuda.synchronize()
     C = cfg.DD3D.NUM_CLASSES
     assert torch.equal(plan.bufs["img4"].nchw(0, 3).cpu(), t("images"))
-    st = {k: [t(f"{k}{l}") for l in range(5)] for k in ("logits", "box2d_reg", "centerness", "quat", "ctr", "depth", "size", "conf")}
+    keys = ("logits", "box2d_reg", "centerness", "quat", "ctr", "depth", "size", "conf") + (("attr", "speed") if nusc else ())
+    st = {k: [t(f"{k}{l}") for l in range(5)] for k in keys}
     for l in range(5):
+        if nusc:
+            na = st["attr"][l].shape[1]
+            assert max_abs(plan.cls_maps[l].nchw(C, na), st["attr"][l]) < 1e-4 * max(1.0, float(st["attr"][l].abs().max()))
+            assert max_abs(plan.cls_maps[l].nchw(C + na, 1), st["speed"][l]) < 1e-4 * max(1.0, float(st["speed"][l].abs().max()))
         assert max_abs(plan.cls_maps[l].nchw(0, C), st["logits"][l]) < 1e-4 * max(1.0, float(st["logits"][l].abs().max()))
         assert max_abs(plan.b2d_maps[l].nchw(0, 4), st["box2d_reg"][l]) < 1e-4 * max(1.0, float(st["box2d_reg"][l].abs().max()))
         assert max_abs(plan.b3d_maps[l].nchw(6 * C, C), st["depth"][l]) < 1e-4 * max(1.0, float(st["depth"][l].abs().max()))
     oracle_heads_to_plan(plan, st, C)
-    plan.launch(first=len(plan.ops) - 2)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
     torch.cuda.synchronize()
     out = model.collect(plan, inputs, image_sizes)
     for i in range(B):
@@ -207,6 +217,10 @@ def test_hip_matches_reference_golden(hiplib, name):
         assert rel_err(o.scores_3d, t(f"det{i}_scores_3d")) < REL_TOL and rel_err(o.pred_boxes3d.depth, t(f"det{i}_depth")) < REL_TOL
         assert rel_err(o.pred_boxes3d.size, t(f"det{i}_size")) < REL_TOL and quat_err(o.pred_boxes3d.quat, t(f"det{i}_quat")) < REL_TOL
         assert max_abs(o.pred_boxes3d.vectorize()[:, 4:], t(f"det{i}_vectorize")[:, 4:]) < REL_TOL * max(1.0, float(t(f"det{i}_vectorize").abs().max()))
+        if nusc:
+            assert torch.equal(o.pred_attributes.cpu(), t(f"det{i}_attributes")) and rel_err(o.pred_speeds, t(f"det{i}_speeds")) < REL_TOL
+            gl, gg = o.pred_boxes3d_global.vectorize().cpu(), t(f"det{i}_global")
+            assert max_abs(gl[:, 4:], gg[:, 4:]) < REL_TOL * max(1.0, float(gg[:, 4:].abs().max())) and quat_err(gl[:, :4], gg[:, :4]) < REL_TOL
 
 
 def test_v99_forward_matches_oracle(hiplib):
@@ -226,8 +240,81 @@ def test_v99_forward_matches_oracle(hiplib):
         assert max_abs(plan.bottom_up[k].nchw(), v) < 1e-4 * max(1.0, float(v.abs().max())), k
     _check_head_maps(plan, st, C)
     oracle_heads_to_plan(plan, st, C)
-    plan.launch(first=len(plan.ops) - 2)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
     torch.cuda.synchronize()
     out = model.collect(plan, inputs, image_sizes)
+    for i in range(2):
+        _check_final(out[i], ref[i])
+
+
+def _nusc_check(o, r, with_global):
+    assert torch.equal(o.pred_attributes.cpu(), r["pred_attributes"]) and rel_err(o.pred_speeds, r["pred_speeds"]) < REL_TOL
+    if with_global and len(o):
+        gl, gg = o.pred_boxes3d_global.vectorize().cpu(), r["pred_boxes3d_global"]
+        assert max_abs(gl[:, 4:], gg[:, 4:]) < REL_TOL * max(1.0, float(gg[:, 4:].abs().max())) and quat_err(gl[:, :4], gg[:, :4]) < REL_TOL
+
+
+@pytest.mark.parametrize("bev_nms,cap", [(False, 500), (True, 45)], ids=["aggregate", "bevnms_cap45"])
+def test_nuscenes_two_samples_match_oracle(hiplib, bev_nms, cap):
+    """NuscenesDD3D on 2 samples x 6 cameras: attribute argmax / speed per candidate, resize, then the cross-camera BEV
+    rotated NMS per sample (category = class + sample * C) with the batch-global cap, against the oracle on identical head
+    maps (integer fields exact).  The 'bevnms' variant adds the per-image BEV NMS before the resize (DO_BEV_NMS)."""
+    from oracle import nuscenes_oracle as N
+    from dd3d_amd.synthetic import make_inputs
+    from tests.util import bundle
+    over = {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}, "INFERENCE": {"DO_BEV_NMS": bev_nms},
+                     "NUSC": {"INFERENCE": {"MAX_NUM_DETS_PER_SAMPLE": cap}}}}
+    cfg, sd = bundle("dd3d_nusc_dla34", "dla34_nusc", over)
+    model = gpu_model(cfg, sd, use_graph=False)
+    B = 12
+    inputs = make_inputs(B, 128, 160, dataset="nusc")
+    for i, x in enumerate(inputs):
+        x["height"], x["width"] = 128 + 8 * (i % 3), 300
+    with torch.no_grad():
+        ref, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
+    plan, image_sizes = model.stage_inputs(inputs)
+    plan.run()
+    torch.cuda.synchronize()
+    C = cfg.DD3D.NUM_CLASSES
+    _check_head_maps(plan, st, C)
+    oracle_heads_to_plan(plan, st, C)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
+    torch.cuda.synchronize()
+    out = model.collect(plan, inputs, image_sizes)
+    n_before = sum(len(x["scores"]) for x in st["before_aggregate"])
+    n_after = sum(len(r["scores"]) for r in ref)
+    assert n_after < n_before and (cap == 500 or n_after == cap)  # suppression (and the cap) really happen
+    for i in range(B):
+        _check_final(out[i], ref[i])
+        _nusc_check(out[i]["instances"], ref[i], True)
+    # graph replay of the same plan is idempotent
+    model2 = gpu_model(cfg, sd, use_graph=True)
+    a, b = model2(inputs), model2(inputs)
+    for x, y in zip(a, b):
+        assert torch.equal(x["instances"].scores_3d, y["instances"].scores_3d) and torch.equal(x["instances"].pred_boxes.tensor, y["instances"].pred_boxes.tensor)
+
+
+def test_kitti_bev_nms_matches_oracle(hiplib, kitti_dla34):
+    """DD3D.INFERENCE.DO_BEV_NMS on the KITTI model (core.py:135-150): per-image BEV rotated NMS between the 2D NMS and the
+    resize, poses taken from 'extrinsics' when there is no 'pose'."""
+    from dd3d_amd import get_cfg
+    from dd3d_amd.structures import Pose
+    from dd3d_amd.synthetic import make_inputs
+    _, _, sd = kitti_dla34
+    cfg = get_cfg("dd3d_kitti_dla34", {"DD3D": {"INFERENCE": {"DO_BEV_NMS": True}, "FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.02}}}})
+    model = gpu_model(cfg, sd, use_graph=False)
+    assert model.do_bev_nms
+    inputs = make_inputs(2, 192, 384, out_hw=(250, 500))
+    for i, x in enumerate(inputs):
+        x["extrinsics"] = Pose.from_yaw(20.0 * i, (1.0, 2.0 + i, 3.0))
+    ref, st = _oracle(cfg, sd, inputs)
+    n_nms = sum(len(x["scores"]) for x in st["after_nms"]) if "after_nms" in st else None
+    plan, image_sizes = model.stage_inputs(inputs)
+    plan.run()
+    oracle_heads_to_plan(plan, st, cfg.DD3D.NUM_CLASSES)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
+    torch.cuda.synchronize()
+    out = model.collect(plan, inputs, image_sizes)
+    assert sum(len(r["scores"]) for r in ref) < 2 * cfg.DD3D.FCOS2D.INFERENCE.POST_NMS_TOPK  # something got suppressed
     for i in range(2):
         _check_final(out[i], ref[i])

@@ -54,6 +54,10 @@ def oracle_heads_to_plan(plan, st, num_classes):
         nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
         plan.cls_maps[l].t.zero_()
         plan.cls_maps[l].t[..., :num_classes] = nhwc(st["logits"][l]).to(plan.device)
+        if "attr" in st:  # nuScenes extras ride on the cls map: [logits | attr logits | speed]
+            na = st["attr"][l].shape[1]
+            plan.cls_maps[l].t[..., num_classes:num_classes + na] = nhwc(st["attr"][l]).to(plan.device)
+            plan.cls_maps[l].t[..., num_classes + na:num_classes + na + 1] = nhwc(st["speed"][l]).to(plan.device)
         plan.b2d_maps[l].t.zero_()
         plan.b2d_maps[l].t[..., 0:4] = nhwc(st["box2d_reg"][l]).to(plan.device)
         plan.b2d_maps[l].t[..., 4:5] = nhwc(st["centerness"][l]).to(plan.device)
