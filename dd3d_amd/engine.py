@@ -725,6 +725,7 @@ class ForwardPlan(PlanBase):
             self.bev_meta = torch.zeros((4, ), dtype=torch.int32, device=dev)
             self.own_group = torch.arange(B, dtype=torch.int32, device=dev)  # dummy_group_idxs = {i: [i]} (core.py:137)
             self.bev_args = []
+            self.det_stages = [(self.det, self.det_count)]  # every stage's buffers stay referenced: the arg structs hold raw pointers
 
             def stage(group, max_dets, write_global, do_pp, name):
                 b = hip.BevArgs()
@@ -741,6 +742,7 @@ class ForwardPlan(PlanBase):
                 self.bev_args.append(b)
                 self.ops.append(CallOp(lambda lib, st, b=b: hip.check(lib.dd3d_bev_nms_aggregate(C.byref(b), st), name), name))
                 self.det, self.det_count = det_out, cnt_out  # what collect() reads (this rank's slice only when W > 1)
+                self.det_stages.append((det_out, cnt_out))
 
             if bev_single:
                 stage(self.own_group, 0, False, bool(inf.DO_POSTPROCESS), "bev_nms")
