@@ -41,9 +41,9 @@ struct ConvKArgs {
   int T;         // KH*KW
   int cc_shift;  // log2(CC) when Cin < 32
   int kw_magic;  // (65536 / KW) + 1 : tap / KW == (tap * kw_magic) >> 16 for tap < 64
-  int relu, splitk, ws_rows, kt_per_split;
-  int N4;              // round_up(N, 4): row stride of the split-K workspace
+  int relu, splitk, kt_per_split;
   const float* zeros;  // >= 128 B of zeros (source of padded taps for the LDS-DMA kernel)
+  int* tile_counters;  // split-K: arrivals per output tile (zero between launches)
 };
 
 // Global-address-space views: the segment descriptor is loaded from memory, so without these casts the compiler
@@ -63,45 +63,107 @@ __device__ __forceinline__ int remap_block(int bid, int nwg) {
 
 // Epilogue shared by both kernels.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 //   out = max(lo, acc*scale + bias (+ residual));  one lane owns one output channel per 32-wide column block.
-// Split-K launches store the raw partial sums to the workspace instead.
+// Split-K fix-up, fused into the conv kernel: every K-slice of an output tile stores its raw accumulators to the workspace
+// and counts its arrival; the slice that arrives LAST re-reads all slices in slice order (deterministic, independent of the
+// arrival order) into its accumulators and runs the normal epilogue.  No second launch; the counter resets itself.
+//
+// Coherence across the 8 XCD-private L2s WITHOUT agent-scope fences (on gfx950 a release/acquire fence writes back /
+// invalidates the whole L2: measured +30 us per launch): the partial sums are moved with sc1 (agent-coherent: write-through /
+// L2-bypassing) 16-byte accesses and ordered by s_waitcnt only.  Workspace layout = accumulator layout,
+// ws[slice][tile][quad q of (i,j)][thread][4]: every store / load instruction of a wave covers 1 KiB contiguous.
+__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld_sc1(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// returns true when this block has to finish the tile (acc then holds the full sum)
+template <int TM, int TN>
+__device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int tile_id, int tid) {
+  constexpr int Q = TM * TN * 4;  // 16-byte quads per thread
+  const long slab = (long)a.ntiles * a.nn * Q * 1024;  // floats per slice
+  float* mine = a.ws + (long)blockIdx.y * slab + ((long)tile_id * Q * 256 + tid) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        st_sc1(mine + ((i * TN + j) * 4 + q) * 1024, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have been acknowledged by the coherence point
+  __shared__ int sh_last;
+  __syncthreads();
+  if (tid == 0) {
+    const int prev = __hip_atomic_fetch_add(a.tile_counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == a.splitk - 1;
+    if (last) __hip_atomic_store(a.tile_counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all slices have arrived
+    sh_last = last;
+  }
+  __syncthreads();
+  if (!sh_last) return false;
+  constexpr int ZC = Q >= 16 ? 1 : (Q >= 8 ? 2 : 4);  // slices in flight: 64 VGPRs of loads
+  const float* base = a.ws + ((long)tile_id * Q * 256 + tid) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int z0 = 0; z0 < a.splitk; z0 += ZC) {
+    f32x4 t[ZC][Q];
+#pragma unroll
+    for (int zz = 0; zz < ZC; ++zz) {
+      const int z = min(z0 + zz, a.splitk - 1);  // clamped re-read of the last slice; its value is not added
+#pragma unroll
+      for (int q = 0; q < Q; ++q) t[zz][q] = ld_sc1(base + (long)z * slab + q * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int zz = 0; zz < ZC; ++zz)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(t[zz][q]));  // uses below depend on the wait above
+#pragma unroll
+    for (int zz = 0; zz < ZC; ++zz) {
+      if (z0 + zz >= a.splitk) break;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += t[zz][(i * TN + j) * 4 + q][e];
+    }
+  }
+  return true;
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0,
                                               int wm, int wn, int lane) {
   const gcfp g_res = as_g(s.res);
   const gfp g_out = as_g(s.out);
-  const gfp g_ws = as_g(a.ws);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
     if (n >= a.N) continue;
-    float sc = 1.f, bi = 0.f, lo = -INFINITY;
-    if (a.splitk == 1) {
-      sc = as_g(s.scale)[n];
-      bi = as_g(s.bias)[n];
-      if (s.lo) lo = as_g(s.lo)[n];
-      if (a.relu) lo = fmaxf(lo, 0.f);
-    }
+    const float sc = as_g(s.scale)[n], bi = as_g(s.bias)[n];
+    float lo = s.lo ? as_g(s.lo)[n] : -INFINITY;
+    if (a.relu) lo = fmaxf(lo, 0.f);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
-      if (a.splitk > 1) {
+      float rv[16];  // residuals first, all 16 loads in flight together (they must not queue behind the stores)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < s.M) g_ws[((long)blockIdx.y * a.ws_rows + s.ws_row0 + m) * a.N4 + n] = acc[i][j][r];
-        }
-      } else {
-        float rv[16];  // residuals first, all 16 loads in flight together (they must not queue behind the stores)
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        rv[r] = (s.res_mode == 1 && m < s.M) ? g_res[(long)m * s.res_pitch + n] : 0.f;
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          rv[r] = (s.res_mode == 1 && m < s.M) ? g_res[(long)m * s.res_pitch + n] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (m < s.M) g_out[(long)m * s.out_pitch + n] = fmaxf(acc[i][j][r] * sc + bi + rv[r], lo);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m < s.M) g_out[(long)m * s.out_pitch + n] = fmaxf(acc[i][j][r] * sc + bi + rv[r], lo);
       }
     }
   }
@@ -111,7 +173,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
 // Register-staged kernel.  Block = 256 threads = 4 wave64; block tile = (TM*32*WM) x (TN*32*WN); double-buffered LDS.
 // PIPE 0: one staging register set (load kt+1 -> MFMA kt -> LDS store kt+1 -> barrier).
 // PIPE 2: two staging sets, prefetch distance 2, raw barriers (global loads stay in flight across them).
-template <int TM, int TN, int WM, int WN, bool SMALLC, int PIPE>
+template <int TM, int TN, int WM, int WN, bool SMALLC, int PIPE, bool SK>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) {
   constexpr int BM = TM * 32 * WM;
   constexpr int BN = TN * 32 * WN;
@@ -138,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
 
   const int nk = a.Kpad / BK;
   int kt_begin = 0, kt_end = nk;
-  if (a.splitk > 1) {
+  if (SK) {
     kt_begin = blockIdx.y * a.kt_per_split;
     kt_end = min(nk, kt_begin + a.kt_per_split);
   }
@@ -297,6 +359,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
     }
   }
 
+  if constexpr (SK) {  // separate instantiation: the exchange must not cost the plain kernel registers
+    if (!splitk_exchange<TM, TN>(a, acc, bid, tid)) return;
+  }
   conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
 }
 
@@ -313,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
 // WK = 1: 4 waves, each owns a (TM*32)x(TN*32) output sub-tile.  WK = 2: 8 waves; waves w and w+4 own the SAME sub-tile
 // and split every K-tile's four k-steps between them (partial sums merged through LDS at the end), so that the
 // small-tile layers (<= 256 blocks, one block per CU) still put two waves on every SIMD.
-template <int TM, int TN, int WM, int WN, int NS, int U, int WK>
+template <int TM, int TN, int WM, int WN, int NS, int U, int WK, bool SK>
 __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const ConvKArgs a) {
   constexpr int BM = TM * 32 * WM;
   constexpr int BN = TN * 32 * WN;
@@ -349,7 +414,7 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
 
   const int nk = a.Kpad / BK;
   int kt_begin = 0, kt_end = nk;
-  if (a.splitk > 1) {
+  if (SK) {
     kt_begin = blockIdx.y * a.kt_per_split;
     kt_end = min(nk, kt_begin + a.kt_per_split);
   }
@@ -510,39 +575,11 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
         for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 64];
   }
 
-  conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Split-K second pass: sum the partial slabs and apply the epilogue.  grid = (m-tiles, BM / 8): one block per 8 output
-// rows, 16 B per lane, so even a 30-tile layer spreads over the whole chip.
-constexpr int RED_ROWS = 8;
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvKArgs a) {
-  const int seg_id = a.tiles[2 * blockIdx.x];
-  const int m0 = a.tiles[2 * blockIdx.x + 1] + blockIdx.y * RED_ROWS;
-  const dd3d_conv_seg s = a.segs[seg_id];
-  const gcfp g_ws = as_g(a.ws);
-  const gcfp g_res = as_g(s.res);
-  const gfp g_out = as_g(s.out);
-  const int n4 = a.N4 >> 2;  // workspace rows are N4 = round_up(N, 4) floats wide; columns >= N are never written nor used
-  for (int idx = threadIdx.x; idx < RED_ROWS * n4; idx += 256) {
-    const int r = idx / n4;
-    const int c = (idx - r * n4) * 4;
-    const int m = m0 + r;
-    if (m >= s.M) break;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < a.splitk; ++z) v += *(gcf4p)(g_ws + ((long)z * a.ws_rows + s.ws_row0 + m) * a.N4 + c);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int n = c + e;
-      if (n >= a.N) break;
-      float o = v[e] * as_g(s.scale)[n] + as_g(s.bias)[n];
-      if (s.res_mode == 1) o += g_res[(long)m * s.res_pitch + n];
-      float lo = s.lo ? as_g(s.lo)[n] : -INFINITY;
-      if (a.relu) lo = fmaxf(lo, 0.f);
-      g_out[(long)m * s.out_pitch + n] = fmaxf(o, lo);
-    }
+  // (WK == 2: the kg == 1 waves have exited, tid < 256 here)
+  if constexpr (SK) {  // separate instantiation: the exchange must not cost the plain kernel registers
+    if (!splitk_exchange<TM, TN>(a, acc, bid, tid)) return;
   }
+  conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
@@ -551,11 +588,11 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <int TM, int TN, int WM, int WN, bool SMALLC, int PIPE>
-static void launch_reg(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
+template <int TM, int TN, int WM, int WN, bool SMALLC, int PIPE, bool SK>
+static void launch_reg_sk(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
   const size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(float);
-  auto k = conv_igemm_f32_kernel<TM, TN, WM, WN, SMALLC, PIPE>;
+  auto k = conv_igemm_f32_kernel<TM, TN, WM, WN, SMALLC, PIPE, SK>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -564,17 +601,29 @@ static void launch_reg(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL(k, grid, dim3(256, 1, 1), lds, st, ka);
 }
 
-template <int TM, int TN, int WM, int WN, int NS, int U, int WK>
-static void launch_dma(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
+template <int TM, int TN, int WM, int WN, bool SMALLC, int PIPE>
+static void launch_reg(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
+  if (ka.splitk > 1) launch_reg_sk<TM, TN, WM, WN, SMALLC, PIPE, true>(ka, grid, st);
+  else launch_reg_sk<TM, TN, WM, WN, SMALLC, PIPE, false>(ka, grid, st);
+}
+
+template <int TM, int TN, int WM, int WN, int NS, int U, int WK, bool SK>
+static void launch_dma_sk(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
   const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
-  auto k = conv_igemm_f32_dma_kernel<TM, TN, WM, WN, NS, U, WK>;
+  auto k = conv_igemm_f32_dma_kernel<TM, TN, WM, WN, NS, U, WK, SK>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   hipLaunchKernelGGL(k, grid, dim3(256 * WK, 1, 1), lds, st, ka);
+}
+
+template <int TM, int TN, int WM, int WN, int NS, int U, int WK>
+static void launch_dma(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
+  if (ka.splitk > 1) launch_dma_sk<TM, TN, WM, WN, NS, U, WK, true>(ka, grid, st);
+  else launch_dma_sk<TM, TN, WM, WN, NS, U, WK, false>(ka, grid, st);
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -606,13 +655,7 @@ static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
       else launch_reg<TM, TN, WM, WN, false, 2>(ka, grid, st);
     }
   }
-  int rc = check_launch("conv_igemm_f32 kernel");
-  if (rc != DD3D_OK) return rc;
-  if (ka.splitk > 1) {
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(ka.ntiles, BM / RED_ROWS), dim3(256), 0, st, ka);
-    rc = check_launch("conv_splitk_reduce_kernel");
-  }
-  return rc;
+  return check_launch("conv_igemm_f32 kernel");
 }
 
 }  // namespace dd3d
@@ -634,7 +677,8 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   DD3D_REQUIRE(L->Kpad % 32 == 0 && L->Kpad >= L->KH * L->KW * L->Cin, "dd3d_conv2d_igemm_f32: Kpad=%d invalid", L->Kpad);
   DD3D_REQUIRE(L->Npad % 32 == 0 && L->Npad >= L->N && L->N > 0, "dd3d_conv2d_igemm_f32: Npad=%d / N=%d invalid", L->Npad, L->N);
   DD3D_REQUIRE(L->splitk >= 1, "dd3d_conv2d_igemm_f32: splitk=%d", L->splitk);
-  DD3D_REQUIRE(L->splitk == 1 || L->workspace, "dd3d_conv2d_igemm_f32: split-K needs a workspace of splitk*ws_rows*round_up(N,4) floats");
+  DD3D_REQUIRE(L->splitk == 1 || (L->workspace && L->tile_counters),
+               "dd3d_conv2d_igemm_f32: split-K needs a workspace of splitk*ntiles*ceil(N/BN)*BM*BN floats and zeroed tile counters");
   int bm, bn;
   if (dd3d_conv_tile_shape(L->tile_cfg, &bm, &bn) != DD3D_OK) return DD3D_E_INVALID;
 
@@ -651,9 +695,8 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.kw_magic = 65536 / L->KW + 1;
   ka.relu = L->relu;
   ka.splitk = L->splitk;
-  ka.ws_rows = L->ws_rows;
-  ka.N4 = (L->N + 3) / 4 * 4;
   ka.zeros = L->zero_page;
+  ka.tile_counters = L->tile_counters;
   const int nk = L->Kpad / 32;
   ka.kt_per_split = ceil_div(nk, L->splitk);
   const bool smallc = L->Cin < 32;

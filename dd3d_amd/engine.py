@@ -152,10 +152,16 @@ class ConvOp:
             self.keep += [s["w"], s["scale"], s["bias"], s.get("lo")]
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
-        self.ws = plan.workspace(sk * ws_rows * ((meta["N"] + 3) // 4 * 4)) if sk > 1 else None
+        # split-K: private partial-sum slab + per-tile arrival counters (private, so that independent convs may overlap)
+        self.ws = self.counters = None
+        if sk > 1:
+            ntile = len(tiles) * -(-meta["N"] // bn)
+            self.ws = torch.empty(sk * ntile * bm * bn, dtype=torch.float32, device=dev)
+            self.counters = torch.zeros(ntile, dtype=torch.int32, device=dev)
         L = hip.ConvLaunch()
         L.segs, L.tiles = self.segs_dev.data_ptr(), self.tiles_dev.data_ptr()
         L.workspace = self.ws.data_ptr() if self.ws is not None else None
+        L.tile_counters = self.counters.data_ptr() if self.counters is not None else None
         L.nsegs, L.ntiles = len(segs), len(tiles)
         L.KH, L.KW, L.stride, L.pad = meta["KH"], meta["KW"], stride, pad
         L.Cin, L.N, L.Kpad, L.Npad = meta["Cin"], meta["N"], meta["Kpad"], meta["Npad"]
@@ -187,9 +193,6 @@ class PlanBase:
         self.dry_run = dry_run  # plan construction only (host-logic tests on a GPU-less box); launching is refused
         assert dry_run or self.device.type == "cuda", "dd3d_amd runs on an MI355X HIP device only (no CPU fallback)"
         self.ops = []
-        self._ws = None
-        self._ws_need = 0
-        self._ws_users = []
         self.bufs = {}
         self.graph = None
         self.world_size = 1
@@ -200,22 +203,6 @@ class PlanBase:
         b = Buf(B, H, W, Cc, self.device, name)
         self.bufs[name] = b
         return b
-
-    def workspace(self, nfloats):
-        """Split-K scratch: one arena shared by all convs (they run back-to-back on one stream)."""
-        self._ws_need = max(self._ws_need, nfloats)
-        h = _Lazy()
-        self._ws_users.append(h)
-        return h
-
-    def _finalize_workspace(self):
-        if self._ws_need:
-            self._ws = torch.empty(self._ws_need, dtype=torch.float32, device=self.device)
-            for h in self._ws_users:
-                h.t = self._ws
-            for op in self.ops:
-                if isinstance(op, ConvOp) and op.ws is not None:
-                    op.L.workspace = self._ws.data_ptr()
 
     def _vec(self, t):
         return t.detach().float().contiguous().to(self.device)
@@ -325,7 +312,6 @@ class ForwardPlan(PlanBase):
         # ---- heads + post-processing
         self._heads(model, self.features)
         self._postprocess(model, world_size, rank)
-        self._finalize_workspace()
 
     # ------------------------------------------------------------------ DLA-34 (dla.py:170-355)
     def _block(self, m, x, residual, out, name):
@@ -753,12 +739,3 @@ class ForwardPlan(PlanBase):
     def gather_pairs(self):
         """(local, global) tensors the multi-GPU step all-gathers between select/decode and the NMS stages."""
         return [(self.cand, self.cand_all), (self.counts, self.counts_all), (self.in_outsize, self.outsize_all)]
-
-
-
-class _Lazy:
-    """Placeholder for the shared split-K arena (sized after all ops are known)."""
-    t = None
-
-    def data_ptr(self):
-        return self.t.data_ptr() if self.t is not None else 0

@@ -73,23 +73,26 @@ typedef struct dd3d_conv_seg {  /* array lives in DEVICE memory */
   int32_t M;           /* B*Ho*Wo                                                                */
   int32_t res_mode;    /* 0 none, 1 add res[m, n] (same pixel) before the clamp                  */
   int32_t reserved0[2];
-  int32_t ws_row0;     /* first row of this segment in the split-K workspace                     */
+  int32_t ws_row0;     /* unused (split-K slabs are indexed by tile)                              */
   int32_t reserved[3];
 } dd3d_conv_seg;
 
 typedef struct dd3d_conv_launch {  /* host memory */
   const dd3d_conv_seg* segs; /* device */
   const int32_t* tiles;      /* device, ntiles x {seg, m0} */
-  float* workspace;          /* device, [splitk][ws_rows][round_up(N,4)] partial sums when splitk > 1, else NULL */
+  float* workspace;          /* device, splitk * ntiles * ceil(N/BN) * BM * BN floats (raw accumulator slabs) when splitk > 1, else NULL */
   int32_t nsegs, ntiles;
   int32_t KH, KW, stride, pad;
   int32_t Cin, N, Kpad, Npad;
   int32_t relu;      /* 1: clamp every output channel at 0 */
   int32_t splitk;    /* >= 1 */
-  int32_t ws_rows;   /* rows per split in the workspace */
+  int32_t ws_rows;   /* unused (kept for layout stability) */
   int32_t tile_cfg;  /* DD3D_TILE_* */
   const float* zero_page; /* device, >= 128 B of zeros, 16-B aligned: source of padded taps for the LDS-DMA kernel
                              (NULL selects the register-staged kernel) */
+  int32_t* tile_counters; /* device, ceil(N/BN) * ntiles int32, ZERO on entry when splitk > 1 (else NULL).  The slice of an
+                             output tile that arrives last sums the partial slabs in slice order and applies the epilogue
+                             inside the same launch; the counters are zero again when the launch has completed. */
 } dd3d_conv_launch;
 
 #define DD3D_TILE_128x128 0

@@ -59,7 +59,6 @@ def test_conv_matches_torch(hiplib, case):
         seg["res"] = rbuf.view()
     op = ConvOp(plan, meta, stride, pad, [seg], relu, tile=tile, splitk=splitk, name=name)
     plan.ops.append(op)
-    plan._finalize_workspace()
     plan.launch()
     torch.cuda.synchronize()
     got = yout.t[..., 4:4 + Cout].permute(0, 3, 1, 2).cpu()
@@ -88,7 +87,6 @@ def test_multi_segment_launch(hiplib):
         refs.append(F.relu(F.conv2d(x, w, padding=1) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)))
         outs.append(yb)
     plan.ops.append(ConvOp(plan, meta, 1, 1, segs, True, name="multi"))
-    plan._finalize_workspace()
     plan.launch()
     torch.cuda.synchronize()
     for yb, ref in zip(outs, refs):
@@ -130,3 +128,30 @@ def test_aux_kernels(hiplib):
     ref[1, :, :, 19:] = 0
     assert torch.equal(dst[..., :3].permute(0, 3, 1, 2).cpu(), ref) and torch.all(dst[..., 3] == 0)
     assert (invK.view(2, 3, 3).cpu() - K.inverse()).abs().max() < 1e-6
+
+
+def test_splitk_fixup_sees_fresh_partials(hiplib):
+    """The split-K fix-up reads the other slices' partial sums across XCD-private L2s.  Re-launch ONE split-K conv with a
+    new input every time (many tiles, so the slices of a tile land on different XCDs): a stale partial from the previous
+    launch would give the previous answer.  Also checks the arrival counters are zero again after every launch."""
+    from dd3d_amd.engine import ConvOp, PlanBase, pack_filter
+    B, H, W, Cin, Cout = 1, 24, 80, 256, 256
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9)**0.5
+    plan = PlanBase("cuda")
+    wp, meta = pack_filter(w, plan.device)
+    xin, yout = plan.buf("x", B, H, W, Cin), plan.buf("y", B, H, W, Cout)
+    ones, zeros = torch.ones(Cout, device=plan.device), torch.zeros(Cout, device=plan.device)
+    seg = {"in": xin.view(), "out": yout.view(), "w": wp, "scale": ones, "bias": zeros}
+    for tile, sk in ((hip.TILE_128x64, 4), (hip.TILE_64x64, 8)):
+        op = ConvOp(plan, meta, 1, 1, [seg], False, tile=tile, splitk=sk, name="stress")
+        wd = w.to(plan.device)
+        for it in range(12):
+            x = torch.randn(B, Cin, H, W, generator=g)
+            xin.t.copy_(x.permute(0, 2, 3, 1))
+            op(plan.lib, hip.current_stream())
+            torch.cuda.synchronize()
+            ref = F.conv2d(x, w, None, padding=1)
+            got = yout.nchw().cpu()
+            assert float((got - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), (tile, sk, it)
+            assert int(op.counters.abs().sum()) == 0
