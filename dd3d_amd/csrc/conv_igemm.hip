@@ -79,18 +79,19 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 }
 
 // returns true when this block has to finish the tile (acc then holds the full sum)
-template <int TM, int TN>
+template <int TM, int TN, int NT = 256>
 __device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int tile_id, int tid) {
   constexpr int Q = TM * TN * 4;  // 16-byte quads per thread
-  const long slab = (long)a.ntiles * a.nn * Q * 1024;  // floats per slice
-  float* mine = a.ws + (long)blockIdx.y * slab + ((long)tile_id * Q * 256 + tid) * 4;
+  constexpr int QS = NT * 4;      // floats between consecutive quads of one thread
+  const long slab = (long)a.ntiles * a.nn * Q * QS;  // floats per slice
+  float* mine = a.ws + (long)blockIdx.y * slab + ((long)tile_id * Q * NT + tid) * 4;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        st_sc1(mine + ((i * TN + j) * 4 + q) * 1024, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+        st_sc1(mine + ((i * TN + j) * 4 + q) * QS, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have been acknowledged by the coherence point
   __shared__ int sh_last;
   __syncthreads();
@@ -103,7 +104,7 @@ __device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc
   __syncthreads();
   if (!sh_last) return false;
   constexpr int ZC = Q >= 16 ? 1 : (Q >= 8 ? 2 : 4);  // slices in flight: 64 VGPRs of loads
-  const float* base = a.ws + ((long)tile_id * Q * 256 + tid) * 4;
+  const float* base = a.ws + ((long)tile_id * Q * NT + tid) * 4;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -116,7 +117,7 @@ __device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc
     for (int zz = 0; zz < ZC; ++zz) {
       const int z = min(z0 + zz, a.splitk - 1);  // clamped re-read of the last slice; its value is not added
 #pragma unroll
-      for (int q = 0; q < Q; ++q) t[zz][q] = ld_sc1(base + (long)z * slab + q * 1024);
+      for (int q = 0; q < Q; ++q) t[zz][q] = ld_sc1(base + (long)z * slab + q * QS);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -582,6 +583,228 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
   conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-operand kernel (Cin % 32 == 0): f32-equivalent products on the BF16 matrix pipe.
+//
+// Every f32 operand is split EXACTLY into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 significand bits, by truncation),
+// and a*b is accumulated in f32 from the six largest cross products (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi);
+// the three dropped ones are <= 2^-24 |a*b|, i.e. at the level of one f32 rounding.  v_mfma_f32_32x32x16_bf16 retires
+// 16 k-values in 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64, so six of them cost 192 vs 512 cycles per 16 k.
+//
+// Filters are split once at plan build (Wp3[n][k-tile][plane][32] bf16) and streamed HBM/L2 -> LDS by LDS-DMA into a
+// 3-stage ring; activations stay f32 in HBM (no format change for any other kernel): each thread loads 16-byte pieces two
+// K-tiles ahead into registers, splits them (5.5 VALU / element, issued in the MFMA shadow) and writes the three planes to
+// a double-buffered LDS image.  LDS rows are 64 B (32 bf16) per plane; their four 16-byte slots are XOR-swizzled with
+// (row >> 2) & 3, which makes every ds_read_b128 lane group hit 16 distinct 4-bank groups.
+// Block = 512 threads = 8 wave64 (two per SIMD), wave tile (TM*32) x (TN*32), WM x WN waves.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int TM, int TN, int WM, int WN, bool SK>
+__global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs a) {
+  constexpr int BM = TM * 32 * WM;
+  constexpr int BN = TN * 32 * WN;
+  constexpr int NTHR = 512;
+  constexpr int AP = BM * 8 / NTHR;         // 16-byte f32 pieces of the A tile per thread
+  constexpr int PLA = BM * 64;              // bytes per A plane
+  constexpr int PLB = BN * 64;              // bytes per B plane
+  constexpr int A_STAGE = 3 * PLA, B_STAGE = 3 * PLB;
+  constexpr int NPIECE = B_STAGE / 1024;    // 1-KiB DMA pieces per B stage
+  constexpr int PB = (NPIECE + 7) / 8;      // pieces per wave (the surplus re-fetches an existing piece)
+  static_assert(WM * WN == 8 && AP >= 1, "8 waves per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);  // [A stage 0 | A stage 1 | B stage 0 | B stage 1 | B stage 2]
+  typedef unsigned char __attribute__((address_space(3))) * ldsbp;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+
+  const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
+  const int mt = bid / a.nn;
+  const int nt = bid - mt * a.nn;
+  const int seg_id = a.tiles[2 * mt];
+  const int m0 = a.tiles[2 * mt + 1];
+  const int n0 = nt * BN;
+  const dd3d_conv_seg s = a.segs[seg_id];
+  const gcfp g_in = as_g(s.in);
+  const gcfp g_zero = as_g(a.zeros);
+  const unsigned char __attribute__((address_space(1)))* g_w3 = (const unsigned char __attribute__((address_space(1)))*)s.w;
+
+  const int nk = a.Kpad / BK;
+  int kt_begin = 0, kt_end = nk;
+  if (SK) {
+    kt_begin = blockIdx.y * a.kt_per_split;
+    kt_end = min(nk, kt_begin + a.kt_per_split);
+  }
+
+  // ---- A gather geometry: thread -> (row = tid >> 3 (+64 per piece), f32 quad = tid & 7)
+  const int arow = tid >> 3;
+  const int avec = tid & 7;
+  long a_base[AP];
+  int a_hi0[AP], a_wi0[AP];
+  {
+    const int howo = s.Ho * s.Wo;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int m = m0 + p * 64 + arow;
+      if (m < s.M) {
+        const int b = m / howo;
+        const int r = m - b * howo;
+        const int ho = r / s.Wo;
+        const int wo = r - ho * s.Wo;
+        a_hi0[p] = ho * a.stride - a.pad;
+        a_wi0[p] = wo * a.stride - a.pad;
+        a_base[p] = (((long)b * s.H + a_hi0[p]) * s.W + a_wi0[p]) * s.in_pitch + avec * 4;
+      } else {
+        a_hi0[p] = -(1 << 28);
+        a_wi0[p] = 0;
+        a_base[p] = 0;
+      }
+    }
+  }
+  // LDS byte offset (inside a plane) of this thread's 8-byte half slot, per piece
+  int a_st[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int row = p * 64 + arow;
+    a_st[p] = row * 64 + (((avec >> 1) ^ ((row >> 2) & 3)) << 4) + ((avec & 1) << 3);
+  }
+
+  // ---- B DMA geometry: piece = q*8 + wave (mod NPIECE) -> (plane, 16-row block); lane -> (row = lane >> 2, LDS slot = lane & 3)
+  long b_src[PB];
+  int b_dst[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    int piece = q * 8 + wave;
+    piece = piece >= NPIECE ? piece - NPIECE : piece;
+    const int plane = piece / (BN / 16);
+    const int rb = piece - plane * (BN / 16);
+    const int row = rb * 16 + (lane >> 2);
+    const int n = min(n0 + row, a.Npad - 1);
+    const int slot = (lane & 3) ^ ((lane >> 4) & 3);  // source-side swizzle: LDS slot (lane & 3) of row holds k-slot `slot`
+    b_src[q] = ((long)n * nk * 3 + plane) * 64 + slot * 16;
+    b_dst[q] = plane * PLB + rb * 1024;  // + lane * 16 implied by the DMA (lane-linear)
+  }
+
+  f32x4 ra[2][AP];
+  auto load_a = [&](int kt, int set) {
+    const int chunk = kt / a.T;
+    const int tap = kt - chunk * a.T;
+    const int dh = (tap * a.kw_magic) >> 16;
+    const int dw = tap - dh * a.KW;
+    const long koff = ((long)dh * s.W + dw) * s.in_pitch + chunk * BK;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const bool ok = (unsigned)(a_hi0[p] + dh) < (unsigned)s.H && (unsigned)(a_wi0[p] + dw) < (unsigned)s.W;
+      ra[set][p] = ok ? *(gcf4p)(g_in + a_base[p] + koff) : *(gcf4p)(g_zero + avec * 4);
+    }
+  };
+  auto issue_b = [&](int kt, int stage) {
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(g_w3 + b_src[q] + (long)kt * 192),
+                                       (ldsbp)(lds + 2 * A_STAGE + stage * B_STAGE + b_dst[q]), 16, 0, 0);
+  };
+  // split four f32 into the three bf16 planes (exact, by truncation) and store them
+  auto split_store = [&](int set, int stage) {
+    unsigned char* As = lds + stage * A_STAGE;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = ra[set][p][e];
+        h[e] = __float_as_uint(x) & 0xffff0000u;
+        const float r = x - __uint_as_float(h[e]);
+        m[e] = __float_as_uint(r) & 0xffff0000u;
+        l[e] = __float_as_uint(r - __uint_as_float(m[e]));
+      }
+      const u32x2 hv = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+      const u32x2 mv = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+      const u32x2 lv = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+      *reinterpret_cast<u32x2*>(As + a_st[p]) = hv;
+      *reinterpret_cast<u32x2*>(As + PLA + a_st[p]) = mv;
+      *reinterpret_cast<u32x2*>(As + 2 * PLA + a_st[p]) = lv;
+    }
+  };
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31;
+  const int kh = lane >> 5;
+  const int swz = (lrow >> 2) & 3;
+  const int frag_off[2] = {lrow * 64 + (((0 + kh) ^ swz) << 4), lrow * 64 + (((2 + kh) ^ swz) << 4)};  // k-chunk 0 / 1
+
+  auto compute_tile = [&](int sa, int sb) {
+    const unsigned char* As = lds + sa * A_STAGE + wm * TM * 32 * 64;
+    const unsigned char* Bs = lds + 2 * A_STAGE + sb * B_STAGE + wn * TN * 32 * 64;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLA + i * 32 * 64 + frag_off[c]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PLB + j * 32 * 64 + frag_off[c]);
+      // smallest terms first; the (i, j) loops are innermost so consecutive MFMAs hit different accumulators
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0};
+      constexpr int PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA_[t]], bf[j][PB_[t]], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (kt_begin < kt_end) {
+    const int kt_last = kt_end - 1;
+    issue_b(kt_begin, 0);
+    load_a(kt_begin, 0);
+    issue_b(min(kt_begin + 1, kt_last), 1);
+    load_a(min(kt_begin + 1, kt_last), 1);
+    split_store(0, 0);  // waits for A(0); B(0) is older, hence landed as well
+    issue_b(min(kt_begin + 2, kt_last), 2);
+    load_a(min(kt_begin + 2, kt_last), 0);
+    lds_barrier();
+    int sb = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int it = kt - kt_begin;
+      compute_tile(it & 1, sb);
+      split_store((it + 1) & 1, (it + 1) & 1);  // A(kt+1): its loads are older than everything issued below
+      lds_barrier();                             // A(kt+1) visible; everyone is done with A stage it&1 and B stage sb
+      issue_b(min(kt + 3, kt_last), sb);         // exactly PB + AP VMEM ops per iteration, clamped past the end
+      load_a(min(kt + 3, kt_last), (it + 1) & 1);
+      sb = sb == 2 ? 0 : sb + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is released
+  }
+
+  if constexpr (SK) {
+    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
+  }
+  conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
+}
+
 // ------------------------------------------------------------------------------------------------------------------ host
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -624,6 +847,24 @@ template <int TM, int TN, int WM, int WN, int NS, int U, int WK>
 static void launch_dma(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   if (ka.splitk > 1) launch_dma_sk<TM, TN, WM, WN, NS, U, WK, true>(ka, grid, st);
   else launch_dma_sk<TM, TN, WM, WN, NS, U, WK, false>(ka, grid, st);
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_x3(const ConvKArgs& ka, hipStream_t st) {
+  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
+  const size_t lds = (size_t)2 * 3 * BM * 64 + (size_t)3 * 3 * BN * 64;
+  dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, true>), grid, dim3(512), lds, st, ka);
+  else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, false>), grid, dim3(512), lds, st, ka);
+  return check_launch("conv_igemm_bf16x3 kernel");
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -701,6 +942,15 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.kt_per_split = ceil_div(nk, L->splitk);
   const bool smallc = L->Cin < 32;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (L->math_mode == DD3D_MATH_BF16X3) {
+    DD3D_REQUIRE(!smallc && L->zero_page, "dd3d_conv2d_igemm_f32: the split-bf16 kernel needs Cin %% 32 == 0 and a zero page");
+    switch (L->tile_cfg) {
+      case DD3D_TILE_128x128: return launch_x3<2, 1, 2, 4>(ka, st);
+      case DD3D_TILE_128x64: return launch_x3<1, 1, 4, 2>(ka, st);
+      case DD3D_TILE_64x128: return launch_x3<1, 1, 2, 4>(ka, st);
+    }
+    DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no split-bf16 kernel", L->tile_cfg);
+  }
   switch (L->tile_cfg) {
     case DD3D_TILE_128x128: return launch_cfg<2, 2, 2, 2>(ka, smallc, st);
     case DD3D_TILE_128x64: return launch_cfg<2, 1, 2, 2>(ka, smallc, st);

@@ -82,12 +82,59 @@ def pack_filter(weights, device):
     return out.to(device), meta
 
 
-def choose_tiling(m_list, N, Kpad):
-    """Pick (tile_cfg, splitk) minimising the modelled makespan on 256 CUs: every block costs BM*BN*K MACs on its
-    CU's matrix pipe (partial tiles cost the same as full ones); a split-K adds a second, small launch."""
+def split_bf16x3(wp):
+    """Wp[Npad][Kpad] f32 -> Wp3[Npad][Kpad/32][3][32] bf16 (int16 bit patterns): x = hi + mid + lo exactly, each term the
+    next 8 significand bits (truncation), as conv_igemm_bf16x3_kernel splits the activations (include/dd3d_hip.h)."""
+    x = wp.detach().float().cpu().contiguous()
+    mask = torch.tensor(-65536, dtype=torch.int32)  # 0xffff0000
+    hi = (x.view(torch.int32) & mask).view(torch.float32)
+    r = x - hi
+    mid = (r.view(torch.int32) & mask).view(torch.float32)
+    lo = r - mid
+    planes = torch.stack([hi, mid, lo], 0).view(torch.int32) >> 16  # arithmetic shift; the low 16 bits are what we keep
+    planes = planes.to(torch.int16)  # wraps to the same 16-bit pattern
+    Npad, Kpad = x.shape
+    return planes.view(3, Npad, Kpad // 32, 32).permute(1, 2, 0, 3).contiguous()
+
+
+MATH_TILES = {hip.MATH_BF16X3: ((128, 128), (128, 64), (64, 128))}  # tiles the split-bf16 kernel is instantiated for
+
+
+def default_math():
+    import os
+    return {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3}[os.environ.get("DD3D_MATH", "f32")]
+
+
+def tile_key(m_list, N, Kpad, stride):
+    return f"{'+'.join(str(m) for m in m_list)},{N},{Kpad},{stride}"
+
+
+def _load_tile_table():
+    """Measured exceptions to the analytic model below: {tile_key: [tile, splitk, best_us, model_us]}, produced on an MI355X by
+    tests/gpu_tile_explore.py (every candidate timed; entries kept only where the best beats the model's pick by > 3 %)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "data", "tile_table.json")
+    return json.load(open(path)) if os.path.exists(path) else {}
+
+
+TILE_TABLE = _load_tile_table()
+
+
+def choose_tiling(m_list, N, Kpad, stride=1, math=0):
+    """Pick (tile_cfg, splitk): a measured table entry when this exact shape has one, else minimise the modelled makespan
+    on 256 CUs: every block costs BM*BN*K MACs on its CU's matrix pipe (partial tiles cost the same as full ones); split-K
+    adds the partial-sum exchange."""
+    allowed = MATH_TILES.get(math)
+    hit = TILE_TABLE.get(tile_key(m_list, N, Kpad, stride)) if allowed is None else None
+    if hit is not None:
+        bm, bn = (int(v) for v in hit[0].split("x"))
+        return next(c for c, shp in hip.TILE_SHAPES.items() if shp == (bm, bn)), int(hit[1])
     nk = Kpad // 32
     best = None
     for cfg, (bm, bn) in hip.TILE_SHAPES.items():
+        if allowed is not None and (bm, bn) not in allowed:
+            continue
         if bn == 32 and N > 32:
             continue
         if bn > 32 and N <= 32:
@@ -114,11 +161,16 @@ def choose_tiling(m_list, N, Kpad):
 
 class ConvOp:
     """One dd3d_conv2d_igemm_f32 launch (possibly many segments)."""
-    def __init__(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name=""):
+    def __init__(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name="", math=None):
         dev = plan.device
         self.name = name
         m_list = [s["out"].B * s["out"].H * s["out"].W for s in segs]
-        cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"])
+        if math is None:
+            math = plan.math
+        if meta["Cin"] % 32 or meta["N"] <= 32:  # stem layers (Cin 4 / 16) and the 5-channel predictors stay on the f32 kernel
+            math = hip.MATH_F32
+        self.math = math
+        cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math)
         if tile is not None:
             cfg = tile
         if splitk is not None:
@@ -136,7 +188,8 @@ class ConvOp:
             Wo = (vin.W + 2 * pad - meta["KW"]) // stride + 1
             assert (Ho, Wo) == (vout.H, vout.W) and vin.B == vout.B, (name, Ho, Wo, vout.H, vout.W)
             a = arr[i]
-            a["in_"], a["w"], a["out"] = vin.ptr, s["w"].data_ptr(), vout.ptr
+            w = s["w"] if math == hip.MATH_F32 else plan.split_weight(s["w"])
+            a["in_"], a["w"], a["out"] = vin.ptr, w.data_ptr(), vout.ptr
             a["scale"], a["bias"] = s["scale"].data_ptr(), s["bias"].data_ptr()
             a["lo"] = s["lo"].data_ptr() if s.get("lo") is not None else 0
             a["B"], a["H"], a["W"], a["Ho"], a["Wo"] = vin.B, vin.H, vin.W, Ho, Wo
@@ -149,7 +202,7 @@ class ConvOp:
             a["ws_row0"] = ws_rows
             ws_rows += m_list[i]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
-            self.keep += [s["w"], s["scale"], s["bias"], s.get("lo")]
+            self.keep += [w, s["scale"], s["bias"], s.get("lo")]
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
         # split-K: private partial-sum slab + per-tile arrival counters (private, so that independent convs may overlap)
@@ -165,11 +218,11 @@ class ConvOp:
         L.nsegs, L.ntiles = len(segs), len(tiles)
         L.KH, L.KW, L.stride, L.pad = meta["KH"], meta["KW"], stride, pad
         L.Cin, L.N, L.Kpad, L.Npad = meta["Cin"], meta["N"], meta["Kpad"], meta["Npad"]
-        L.relu, L.splitk, L.ws_rows, L.tile_cfg = int(relu), sk, ws_rows, cfg
+        L.relu, L.splitk, L.math_mode, L.tile_cfg = int(relu), sk, math, cfg
         L.zero_page = plan.zero_page.data_ptr()
         self.L = L
         self.macs = sum(m_list) * meta["N"] * meta["KH"] * meta["KW"] * meta["Cin"]
-        self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), splitk=sk,
+        self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), splitk=sk, math=math,
                          blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs))
 
     def __call__(self, lib, stream):
@@ -197,6 +250,15 @@ class PlanBase:
         self.graph = None
         self.world_size = 1
         self.zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)  # padded-tap source of the DMA conv
+        self.math = default_math()
+        self._split = {}
+
+    def split_weight(self, wp):
+        """bf16 hi/mid/lo planes of a packed filter, built once per filter (the towers share theirs over 5 levels)."""
+        key = wp.data_ptr()
+        if key not in self._split:
+            self._split[key] = (wp, split_bf16x3(wp).to(self.device))
+        return self._split[key][1]
 
     # ------------------------------------------------------------------ helpers
     def buf(self, name, B, H, W, Cc):

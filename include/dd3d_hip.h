@@ -86,7 +86,7 @@ typedef struct dd3d_conv_launch {  /* host memory */
   int32_t Cin, N, Kpad, Npad;
   int32_t relu;      /* 1: clamp every output channel at 0 */
   int32_t splitk;    /* >= 1 */
-  int32_t ws_rows;   /* unused (kept for layout stability) */
+  int32_t math_mode; /* DD3D_MATH_* */
   int32_t tile_cfg;  /* DD3D_TILE_* */
   const float* zero_page; /* device, >= 128 B of zeros, 16-B aligned: source of padded taps for the LDS-DMA kernel
                              (NULL selects the register-staged kernel) */
@@ -94,6 +94,14 @@ typedef struct dd3d_conv_launch {  /* host memory */
                              output tile that arrives last sums the partial slabs in slice order and applies the epilogue
                              inside the same launch; the counters are zero again when the launch has completed. */
 } dd3d_conv_launch;
+
+/* Arithmetic of the implicit GEMM (results agree to f32 rounding level; both accumulate in f32):
+ *   DD3D_MATH_F32     v_mfma_f32_32x32x2_f32 on f32 operands; segment.w = Wp[Npad][Kpad] f32
+ *   DD3D_MATH_BF16X3  each f32 operand split exactly into 3 bf16 terms, 6 cross products on v_mfma_f32_32x32x16_bf16;
+ *                     segment.w = Wp3[Npad][Kpad/32][3][32] bf16 (planes hi, mid, lo of the same k order); Cin % 32 == 0,
+ *                     tiles 128x128 / 128x64 / 64x128 */
+#define DD3D_MATH_F32 0
+#define DD3D_MATH_BF16X3 1
 
 #define DD3D_TILE_128x128 0
 #define DD3D_TILE_128x64 1

@@ -1,0 +1,108 @@
+"""Dev tool: time every (tile, split-K) candidate for each distinct conv of the DD3D-DLA34 plan on the GPU.
+
+    python tests/gpu_tile_explore.py [H W B] > gpurun_out/tile_explore.txt
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g  # noqa: E402
+
+g.build()
+from dd3d_amd import build_model, get_cfg, hip  # noqa: E402
+from dd3d_amd import engine  # noqa: E402
+from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict  # noqa: E402
+
+RECORD = []
+_orig_init = engine.ConvOp.__init__
+
+
+def _rec_init(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name=""):
+    _orig_init(self, plan, meta, stride, pad, segs, relu, tile=tile, splitk=splitk, name=name)
+    RECORD.append((name, plan, meta, stride, pad, segs, relu))
+
+
+def time_op(plan, op, iters=30):
+    st = hip.current_stream()
+    best = float("inf")
+    for _ in range(2):
+        for _ in range(5):
+            op(plan.lib, st)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            op(plan.lib, st)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters * 1e3)
+    return best
+
+
+def main():
+    global exp
+    H = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+    W = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    exp = os.environ.get("DD3D_EXP", "dd3d_kitti_dla34")
+    cfg = get_cfg(exp)
+    model = build_model(cfg)
+    model.load_state_dict(make_state_dict(model, calib=load_calib("dla34_kitti" if "dla34" in exp else "v99_kitti")))
+    model.use_graph = False
+    engine.ConvOp.__init__ = _rec_init
+    plan, _ = model.stage_inputs(make_inputs(B, H, W))
+    engine.ConvOp.__init__ = _orig_init
+    plan.run()
+    torch.cuda.synchronize()
+    seen = {}
+    table = {}
+    engine.TILE_TABLE = {}  # measure against the analytic model
+    for name, pl, meta, stride, pad, segs, relu in RECORD:
+        m_list = tuple(s["out"].B * s["out"].H * s["out"].W for s in segs)
+        key = (m_list, meta["N"], meta["Kpad"], meta["Cin"], stride)
+        if key in seen:
+            continue
+        seen[key] = name
+        nk = meta["Kpad"] // 32
+        cur_cfg, cur_sk = engine.choose_tiling(list(m_list), meta["N"], meta["Kpad"], stride)
+        res = []
+        for cfg_id, (bm, bn) in hip.TILE_SHAPES.items():
+            if (bn == 32) != (meta["N"] <= 32):
+                continue
+            if bn == 128 and meta["N"] <= 64:
+                continue
+            blocks = sum(-(-m // bm) for m in m_list) * -(-meta["N"] // bn)
+            for sk in (1, 2, 3, 4, 6, 8, 12, 16):
+                if sk > 1 and (nk // sk < 3 or blocks * sk > 1200):
+                    continue
+                if sk == 1 and blocks > 6000 and (bm, bn) != hip.TILE_SHAPES[cur_cfg]:
+                    continue
+                try:
+                    op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name)
+                    us = time_op(pl, op)
+                except Exception as e:  # noqa: BLE001
+                    us = float("nan")
+                res.append((us, bm, bn, sk, blocks * sk))
+        res.sort()
+        cur = [r for r in res if (r[1], r[2]) == hip.TILE_SHAPES[cur_cfg] and r[3] == cur_sk]
+        cur_us = cur[0][0] if cur else float("nan")
+        best = res[0]
+        if cur_us > 1.03 * best[0]:  # only keep entries that beat the model by more than the measurement noise
+            table[engine.tile_key(m_list, meta["N"], meta["Kpad"], stride)] = [f"{best[1]}x{best[2]}", best[3], round(best[0], 1), round(cur_us, 1)]
+        print(f"{name:26s} M={sum(m_list):7d} N={meta['N']:4d} K={meta['Kpad']:5d} s{stride} model=({hip.TILE_SHAPES[cur_cfg][0]}x{hip.TILE_SHAPES[cur_cfg][1]},sk{cur_sk}) {cur_us:7.2f}us "
+              f"best=({best[1]}x{best[2]},sk{best[3]},{best[4]}blk) {best[0]:7.2f}us gain {cur_us - best[0]:6.2f} | "
+              + " ".join(f"{r[1]}x{r[2]}/{r[3]}:{r[0]:.1f}" for r in res[:6]), flush=True)
+
+
+    import json
+    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}.json")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(out, "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+    print("wrote", out, len(table), "entries")
+
+
+if __name__ == "__main__":
+    main()

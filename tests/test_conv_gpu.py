@@ -26,10 +26,24 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+X3_CASES = [  # split-bf16 arithmetic (DD3D_MATH_BF16X3): same f32-level tolerance as the f32-MFMA kernel
+    ("x3_tower3x3_128x128", 2, 17, 23, 256, 256, 3, 1, 1, True, True, hip.TILE_128x128, 1),
+    ("x3_tower3x3_128x64", 1, 24, 40, 256, 256, 3, 1, 1, True, False, hip.TILE_128x64, 1),
+    ("x3_tower3x3_64x128_sk3", 1, 9, 31, 128, 192, 3, 1, 1, False, True, hip.TILE_64x128, 3),
+    ("x3_128x128_sk4", 1, 12, 20, 256, 256, 3, 1, 1, True, True, hip.TILE_128x128, 4),
+    ("x3_stride2_odd", 1, 13, 21, 256, 256, 3, 2, 1, False, False, hip.TILE_128x64, 2),
+    ("x3_root1x1", 1, 24, 40, 448, 128, 1, 1, 0, True, False, None, None),
+    ("x3_proj1x1_k32", 1, 24, 40, 32, 64, 1, 1, 0, False, False, None, None),
+    ("x3_pred_n55", 1, 24, 40, 256, 55, 3, 1, 1, False, False, None, None),
+    ("x3_model_choice", 1, 48, 160, 256, 256, 3, 1, 1, True, False, None, None),
+]
+
+
+@pytest.mark.parametrize("case", CASES + X3_CASES, ids=[c[0] for c in CASES + X3_CASES])
 def test_conv_matches_torch(hiplib, case):
     from dd3d_amd.engine import ConvOp, PlanBase, pack_filter
     name, B, H, W, Cin, Cout, k, stride, pad, relu, use_res, tile, splitk = case
+    math = hip.MATH_BF16X3 if name.startswith("x3_") else hip.MATH_F32
     g = torch.Generator().manual_seed(hash(name) % 1000)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k)**0.5
@@ -57,7 +71,8 @@ def test_conv_matches_torch(hiplib, case):
         rbuf = plan.buf("r", B, Ho, Wo, Cout)
         rbuf.t.copy_(res.permute(0, 2, 3, 1))
         seg["res"] = rbuf.view()
-    op = ConvOp(plan, meta, stride, pad, [seg], relu, tile=tile, splitk=splitk, name=name)
+    op = ConvOp(plan, meta, stride, pad, [seg], relu, tile=tile, splitk=splitk, name=name, math=math)
+    assert op.math == math
     plan.ops.append(op)
     plan.launch()
     torch.cuda.synchronize()
