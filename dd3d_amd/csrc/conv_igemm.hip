@@ -689,8 +689,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
     b_dst[q] = plane * PLB + rb * 1024;  // + lane * 16 implied by the DMA (lane-linear)
   }
 
-  f32x4 ra[2][AP];
-  auto load_a = [&](int kt, int set) {
+  f32x4 ra[2][AP];  // two register sets, always indexed by a compile-time constant (runtime indexing would serialise the loads)
+  auto load_a = [&](int kt, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     const int chunk = kt / a.T;
     const int tap = kt - chunk * a.T;
     const int dh = (tap * a.kw_magic) >> 16;
@@ -699,7 +700,21 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool ok = (unsigned)(a_hi0[p] + dh) < (unsigned)s.H && (unsigned)(a_wi0[p] + dw) < (unsigned)s.W;
-      ra[set][p] = ok ? *(gcf4p)(g_in + a_base[p] + koff) : *(gcf4p)(g_zero + avec * 4);
+      const gcfp src = ok ? g_in + a_base[p] + koff : g_zero + avec * 4;
+      // issued behind the compiler's back: its waitcnt pass drains vmcnt to 0 whenever register loads and LDS-DMA are both
+      // pending, which would expose the whole memory latency every other step.  wait_a() below is the matching wait.
+      f32x4& dst = ra[set][p];
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
+    }
+  };
+  // A(set) has landed once at most the PB + AP operations issued after it are outstanding (in-order return)
+  auto wait_a = [&](auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB + AP) : "memory");
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      f32x4& r = ra[set][p];
+      asm volatile("" : "+v"(r));  // the split below depends on the wait above
     }
   };
   auto issue_b = [&](int kt, int stage) {
@@ -709,7 +724,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
                                        (ldsbp)(lds + 2 * A_STAGE + stage * B_STAGE + b_dst[q]), 16, 0, 0);
   };
   // split four f32 into the three bf16 planes (exact, by truncation) and store them
-  auto split_store = [&](int set, int stage) {
+  auto split_store = [&](auto set_c, int stage) {
+    constexpr int set = decltype(set_c)::value;
+    wait_a(set_c);
     unsigned char* As = lds + stage * A_STAGE;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
@@ -778,22 +795,33 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
 
   if (kt_begin < kt_end) {
     const int kt_last = kt_end - 1;
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
     issue_b(kt_begin, 0);
-    load_a(kt_begin, 0);
+    load_a(kt_begin, S0);
     issue_b(min(kt_begin + 1, kt_last), 1);
-    load_a(min(kt_begin + 1, kt_last), 1);
-    split_store(0, 0);  // waits for A(0); B(0) is older, hence landed as well
+    load_a(min(kt_begin + 1, kt_last), S1);
+    split_store(S0, 0);  // waits for A(0); B(0) is older, hence landed as well
     issue_b(min(kt_begin + 2, kt_last), 2);
-    load_a(min(kt_begin + 2, kt_last), 0);
+    load_a(min(kt_begin + 2, kt_last), S0);
     lds_barrier();
     int sb = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int it = kt - kt_begin;
-      compute_tile(it & 1, sb);
-      split_store((it + 1) & 1, (it + 1) & 1);  // A(kt+1): its loads are older than everything issued below
-      lds_barrier();                             // A(kt+1) visible; everyone is done with A stage it&1 and B stage sb
-      issue_b(min(kt + 3, kt_last), sb);         // exactly PB + AP VMEM ops per iteration, clamped past the end
-      load_a(min(kt + 3, kt_last), (it + 1) & 1);
+    // Each step: MFMAs of tile kt | split + store A(kt+1) (loaded two steps ago; everything issued later stays in flight) |
+    // barrier | refill: B(kt+3) into the ring stage just consumed, A(kt+3) into the register set just stored.  Exactly
+    // PB + AP VMEM operations per step (indices clamped past the end) so the waits stay counted.
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      compute_tile(0, sb);
+      split_store(S1, 1);
+      lds_barrier();
+      issue_b(min(kt + 3, kt_last), sb);
+      load_a(min(kt + 3, kt_last), S1);
+      sb = sb == 2 ? 0 : sb + 1;
+      if (kt + 1 >= kt_end) break;
+      compute_tile(1, sb);
+      split_store(S0, 0);
+      lds_barrier();
+      issue_b(min(kt + 4, kt_last), sb);
+      load_a(min(kt + 4, kt_last), S0);
       sb = sb == 2 ? 0 : sb + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is released
