@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int TM, int TN, int WM, int WN, bool SK>
+template <int TM, int TN, int WM, int WN, int NSB, bool SK>
 __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs a) {
   constexpr int BM = TM * 32 * WM;
   constexpr int BN = TN * 32 * WN;
@@ -611,9 +611,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
   constexpr int A_STAGE = 3 * PLA, B_STAGE = 3 * PLB;
   constexpr int NPIECE = B_STAGE / 1024;    // 1-KiB DMA pieces per B stage
   constexpr int PB = (NPIECE + 7) / 8;      // pieces per wave (the surplus re-fetches an existing piece)
-  static_assert(WM * WN == 8 && AP >= 1, "8 waves per block");
+  // A(kt+1) and B(kt+1) must have landed when step kt stores A(kt+1).  Issue order is ... A(x) B(x) A(x+1) B(x+1) ... with
+  // a 3-stage B ring (B(kt+3) refills the stage step kt consumed) and ... A(x+1) B(x) A(x+2) B(x+1) ... with 2 stages
+  // (B(kt+2) refills it), so the in-order wait leaves one step's worth in flight, or nothing.
+  constexpr int WAIT_A = NSB == 3 ? AP + PB : 0;
+  static_assert(WM * WN == 8 && AP >= 1 && (NSB == 2 || NSB == 3), "8 waves per block");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);  // [A stage 0 | A stage 1 | B stage 0 | B stage 1 | B stage 2]
+  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);  // [A stage 0 | A stage 1 | B stage 0 .. NSB-1]
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
 
   const int tid = threadIdx.x;
@@ -665,13 +669,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
       }
     }
   }
-  // LDS byte offset (inside a plane) of this thread's 8-byte half slot, per piece
-  int a_st[AP];
-#pragma unroll
-  for (int p = 0; p < AP; ++p) {
-    const int row = p * 64 + arow;
-    a_st[p] = row * 64 + (((avec >> 1) ^ ((row >> 2) & 3)) << 4) + ((avec & 1) << 3);
-  }
+  // LDS byte offset (inside a plane) of this thread's 8-byte half slot; piece p adds p * 64 rows (the swizzle term only
+  // depends on (row >> 2) & 3, which 64-row steps leave unchanged)
+  const int a_st0 = arow * 64 + (((avec >> 1) ^ ((arow >> 2) & 3)) << 4) + ((avec & 1) << 3);
 
   // ---- B DMA geometry: piece = q*8 + wave (mod NPIECE) -> (plane, 16-row block); lane -> (row = lane >> 2, LDS slot = lane & 3)
   long b_src[PB];
@@ -689,14 +689,18 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
     b_dst[q] = plane * PLB + rb * 1024;  // + lane * 16 implied by the DMA (lane-linear)
   }
 
+  // The A stream walks the K-tiles in order; (chunk, tap) are carried instead of divided out of kt.
+  int ld_kt = kt_begin;
+  int ld_chunk = kt_begin / a.T;
+  int ld_tap = kt_begin - ld_chunk * a.T;
+  const int kt_last = kt_end - 1;
+
   f32x4 ra[2][AP];  // two register sets, always indexed by a compile-time constant (runtime indexing would serialise the loads)
-  auto load_a = [&](int kt, auto set_c) {
+  auto load_a = [&](auto set_c) {  // next K-tile of the stream (re-fetches the last one past the end, so counts stay uniform)
     constexpr int set = decltype(set_c)::value;
-    const int chunk = kt / a.T;
-    const int tap = kt - chunk * a.T;
-    const int dh = (tap * a.kw_magic) >> 16;
-    const int dw = tap - dh * a.KW;
-    const long koff = ((long)dh * s.W + dw) * s.in_pitch + chunk * BK;
+    const int dh = (ld_tap * a.kw_magic) >> 16;
+    const int dw = ld_tap - dh * a.KW;
+    const long koff = ((long)dh * s.W + dw) * s.in_pitch + ld_chunk * BK;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       const bool ok = (unsigned)(a_hi0[p] + dh) < (unsigned)s.H && (unsigned)(a_wi0[p] + dw) < (unsigned)s.W;
@@ -706,11 +710,14 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
       f32x4& dst = ra[set][p];
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
     }
+    if (ld_kt < kt_last) {
+      ++ld_kt;
+      if (++ld_tap == a.T) ld_tap = 0, ++ld_chunk;
+    }
   };
-  // A(set) has landed once at most the PB + AP operations issued after it are outstanding (in-order return)
   auto wait_a = [&](auto set_c) {
     constexpr int set = decltype(set_c)::value;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB + AP) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_A) : "memory");
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       f32x4& r = ra[set][p];
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
   auto split_store = [&](auto set_c, int stage) {
     constexpr int set = decltype(set_c)::value;
     wait_a(set_c);
-    unsigned char* As = lds + stage * A_STAGE;
+    unsigned char* As = lds + stage * A_STAGE + a_st0;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       unsigned h[4], m[4], l[4];
@@ -742,9 +749,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
       const u32x2 hv = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
       const u32x2 mv = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
       const u32x2 lv = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
-      *reinterpret_cast<u32x2*>(As + a_st[p]) = hv;
-      *reinterpret_cast<u32x2*>(As + PLA + a_st[p]) = mv;
-      *reinterpret_cast<u32x2*>(As + 2 * PLA + a_st[p]) = lv;
+      *reinterpret_cast<u32x2*>(As + p * 4096) = hv;
+      *reinterpret_cast<u32x2*>(As + PLA + p * 4096) = mv;
+      *reinterpret_cast<u32x2*>(As + 2 * PLA + p * 4096) = lv;
     }
   };
   auto lds_barrier = [&]() {
@@ -769,60 +776,62 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
   auto compute_tile = [&](int sa, int sb) {
     const unsigned char* As = lds + sa * A_STAGE + wm * TM * 32 * 64;
     const unsigned char* Bs = lds + 2 * A_STAGE + sb * B_STAGE + wn * TN * 32 * 64;
+    bf16x8 af[2][TM][3], bf[2][TN][3];  // fragments of both k-chunks: the reads of chunk 1 fly under the MFMAs of chunk 0
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLA + i * 32 * 64 + frag_off[c]);
+        for (int pl = 0; pl < 3; ++pl) af[c][i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLA + i * 32 * 64 + frag_off[c]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PLB + j * 32 * 64 + frag_off[c]);
-      // smallest terms first; the (i, j) loops are innermost so consecutive MFMAs hit different accumulators
-      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0};
-      constexpr int PB_[6] = {0, 2, 1, 0, 1, 0};
+        for (int pl = 0; pl < 3; ++pl) bf[c][j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PLB + j * 32 * 64 + frag_off[c]);
+    }
+    // smallest terms first; the (i, j) loops are innermost so consecutive MFMAs hit different accumulators
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA_[t]], bf[j][PB_[t]], acc[i][j], 0, 0, 0);
-    }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i][PA_[t]], bf[c][j][PB_[t]], acc[i][j], 0, 0, 0);
   };
 
   if (kt_begin < kt_end) {
-    const int kt_last = kt_end - 1;
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
+    // prologue: A(0) B(0) A(1) B(1) | store A(0) | A(2) | barrier | [3 stages: B(2)]
+    load_a(S0);
     issue_b(kt_begin, 0);
-    load_a(kt_begin, S0);
+    load_a(S1);
     issue_b(min(kt_begin + 1, kt_last), 1);
-    load_a(min(kt_begin + 1, kt_last), S1);
-    split_store(S0, 0);  // waits for A(0); B(0) is older, hence landed as well
-    issue_b(min(kt_begin + 2, kt_last), 2);
-    load_a(min(kt_begin + 2, kt_last), S0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSB == 3 ? AP + PB : 0) : "memory");
+    split_store(S0, 0);
+    load_a(S0);
     lds_barrier();
+    if (NSB == 3) issue_b(min(kt_begin + 2, kt_last), 2);
     int sb = 0;
-    // Each step: MFMAs of tile kt | split + store A(kt+1) (loaded two steps ago; everything issued later stays in flight) |
-    // barrier | refill: B(kt+3) into the ring stage just consumed, A(kt+3) into the register set just stored.  Exactly
-    // PB + AP VMEM operations per step (indices clamped past the end) so the waits stay counted.
+    // Step kt: MFMAs of tile kt | split + store A(kt+1) | A(kt+3) -> the register set just stored | barrier | B refill of
+    // the ring stage just consumed.  Exactly AP + PB VMEM operations per step (indices clamped past the end).
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
       compute_tile(0, sb);
       split_store(S1, 1);
+      load_a(S1);
       lds_barrier();
-      issue_b(min(kt + 3, kt_last), sb);
-      load_a(min(kt + 3, kt_last), S1);
-      sb = sb == 2 ? 0 : sb + 1;
+      issue_b(min(kt + NSB, kt_last), sb);
+      sb = sb == NSB - 1 ? 0 : sb + 1;
       if (kt + 1 >= kt_end) break;
       compute_tile(1, sb);
       split_store(S0, 0);
+      load_a(S0);
       lds_barrier();
-      issue_b(min(kt + 4, kt_last), sb);
-      load_a(min(kt + 4, kt_last), S0);
-      sb = sb == 2 ? 0 : sb + 1;
+      issue_b(min(kt + 1 + NSB, kt_last), sb);
+      sb = sb == NSB - 1 ? 0 : sb + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is released
   }
@@ -877,21 +886,21 @@ static void launch_dma(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   else launch_dma_sk<TM, TN, WM, WN, NS, U, WK, false>(ka, grid, st);
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int NSB>
 static int launch_x3(const ConvKArgs& ka, hipStream_t st) {
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
-  const size_t lds = (size_t)2 * 3 * BM * 64 + (size_t)3 * 3 * BN * 64;
+  const size_t lds = (size_t)2 * 3 * BM * 64 + (size_t)NSB * 3 * BN * 64;
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, true>), grid, dim3(512), lds, st, ka);
-  else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, false>), grid, dim3(512), lds, st, ka);
+  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, true>), grid, dim3(512), lds, st, ka);
+  else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, false>), grid, dim3(512), lds, st, ka);
   return check_launch("conv_igemm_bf16x3 kernel");
 }
 
@@ -930,7 +939,7 @@ static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
 }  // namespace dd3d
 
 extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) {
-  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}};
+  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}};
   DD3D_REQUIRE(tile_cfg >= 0 && tile_cfg < DD3D_TILE_COUNT, "dd3d_conv_tile_shape: unknown tile_cfg %d", tile_cfg);
   *bm = shapes[tile_cfg][0];
   *bn = shapes[tile_cfg][1];
@@ -973,9 +982,10 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   if (L->math_mode == DD3D_MATH_BF16X3) {
     DD3D_REQUIRE(!smallc && L->zero_page, "dd3d_conv2d_igemm_f32: the split-bf16 kernel needs Cin %% 32 == 0 and a zero page");
     switch (L->tile_cfg) {
-      case DD3D_TILE_128x128: return launch_x3<2, 1, 2, 4>(ka, st);
-      case DD3D_TILE_128x64: return launch_x3<1, 1, 4, 2>(ka, st);
-      case DD3D_TILE_64x128: return launch_x3<1, 1, 2, 4>(ka, st);
+      case DD3D_TILE_128x128: return launch_x3<2, 1, 2, 4, 3>(ka, st);
+      case DD3D_TILE_128x64: return launch_x3<1, 1, 4, 2, 3>(ka, st);
+      case DD3D_TILE_64x128: return launch_x3<1, 1, 2, 4, 3>(ka, st);
+      case DD3D_TILE_256x128: return launch_x3<2, 2, 4, 2, 2>(ka, st);
     }
     DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no split-bf16 kernel", L->tile_cfg);
   }
@@ -985,6 +995,7 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
     case DD3D_TILE_64x64: return launch_cfg<1, 1, 2, 2>(ka, smallc, st);
     case DD3D_TILE_128x32: return launch_cfg<1, 1, 4, 1>(ka, smallc, st);
     case DD3D_TILE_64x128: return launch_cfg<1, 2, 2, 2>(ka, smallc, st);
+    case DD3D_TILE_256x128: DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: the 256x128 tile exists for DD3D_MATH_BF16X3 only");
   }
   return DD3D_E_INVALID;
 }

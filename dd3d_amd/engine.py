@@ -97,7 +97,8 @@ def split_bf16x3(wp):
     return planes.view(3, Npad, Kpad // 32, 32).permute(1, 2, 0, 3).contiguous()
 
 
-MATH_TILES = {hip.MATH_BF16X3: ((128, 128), (128, 64), (64, 128))}  # tiles the split-bf16 kernel is instantiated for
+MATH_TILES = {hip.MATH_F32: ((128, 128), (128, 64), (64, 64), (128, 32), (64, 128)),
+              hip.MATH_BF16X3: ((256, 128), (128, 128), (128, 64), (64, 128))}  # tiles the split-bf16 kernel is instantiated for
 
 
 def default_math():
@@ -125,15 +126,15 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
     """Pick (tile_cfg, splitk): a measured table entry when this exact shape has one, else minimise the modelled makespan
     on 256 CUs: every block costs BM*BN*K MACs on its CU's matrix pipe (partial tiles cost the same as full ones); split-K
     adds the partial-sum exchange."""
-    allowed = MATH_TILES.get(math)
-    hit = TILE_TABLE.get(tile_key(m_list, N, Kpad, stride)) if allowed is None else None
+    allowed = MATH_TILES[math]
+    hit = TILE_TABLE.get(tile_key(m_list, N, Kpad, stride)) if math == hip.MATH_F32 else None
     if hit is not None:
         bm, bn = (int(v) for v in hit[0].split("x"))
         return next(c for c, shp in hip.TILE_SHAPES.items() if shp == (bm, bn)), int(hit[1])
     nk = Kpad // 32
     best = None
     for cfg, (bm, bn) in hip.TILE_SHAPES.items():
-        if allowed is not None and (bm, bn) not in allowed:
+        if (bm, bn) not in allowed:
             continue
         if bn == 32 and N > 32:
             continue
@@ -149,7 +150,10 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
             cost = -(-blocks * sk // NUM_CU) * bm * bn * per * 32
             # measured matrix-pipe efficiency of each tile shape once the chip is full (profiles/r01b_conv_ops.txt):
             # 128x128 ~119 TF/s, 128x64 ~95, 64x64 ~74, 128x32 (N <= 32 pads the 32-wide MFMA) ~45
-            cost /= {(128, 128): 1.0, (128, 64): 0.80, (64, 128): 0.80, (64, 64): 0.63, (128, 32): 0.40}[(bm, bn)]
+            if math == hip.MATH_F32:
+                cost /= {(128, 128): 1.0, (128, 64): 0.80, (64, 128): 0.80, (64, 64): 0.63, (128, 32): 0.40}[(bm, bn)]
+            else:  # split-bf16 kernel: ~2x the f32 rate on the big tiles, LDS-read bound on the small ones
+                cost /= {(256, 128): 2.4, (128, 128): 1.8, (128, 64): 1.3, (64, 128): 1.3}[(bm, bn)]
             if sk > 1:
                 # second launch (~2 us) + partial-sum round trip (sk*M*N*8 B at ~3 TB/s), in per-CU MAC units
                 # (one CU retires 157.3e12 / 2 / 256 = 3.07e11 MAC/s)
@@ -172,6 +176,8 @@ class ConvOp:
         self.math = math
         cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math)
         if tile is not None:
+            if hip.TILE_SHAPES[tile] not in MATH_TILES[math]:
+                raise ValueError(f"conv {name}: tile {hip.TILE_SHAPES[tile]} is not instantiated for math mode {math}")
             cfg = tile
         if splitk is not None:
             sk = splitk

@@ -99,7 +99,7 @@ typedef struct dd3d_conv_launch {  /* host memory */
  *   DD3D_MATH_F32     v_mfma_f32_32x32x2_f32 on f32 operands; segment.w = Wp[Npad][Kpad] f32
  *   DD3D_MATH_BF16X3  each f32 operand split exactly into 3 bf16 terms, 6 cross products on v_mfma_f32_32x32x16_bf16;
  *                     segment.w = Wp3[Npad][Kpad/32][3][32] bf16 (planes hi, mid, lo of the same k order); Cin % 32 == 0,
- *                     tiles 128x128 / 128x64 / 64x128 */
+ *                     tiles 256x128 / 128x128 / 128x64 / 64x128 */
 #define DD3D_MATH_F32 0
 #define DD3D_MATH_BF16X3 1
 
@@ -108,7 +108,8 @@ typedef struct dd3d_conv_launch {  /* host memory */
 #define DD3D_TILE_64x64 2
 #define DD3D_TILE_128x32 3
 #define DD3D_TILE_64x128 4
-#define DD3D_TILE_COUNT 5
+#define DD3D_TILE_256x128 5 /* DD3D_MATH_BF16X3 only */
+#define DD3D_TILE_COUNT 6
 /* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
 int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
 int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);

@@ -66,9 +66,12 @@ def main():
             continue
         seen[key] = name
         nk = meta["Kpad"] // 32
-        cur_cfg, cur_sk = engine.choose_tiling(list(m_list), meta["N"], meta["Kpad"], stride)
+        math = pl.math if (meta["Cin"] % 32 == 0 and meta["N"] > 32) else hip.MATH_F32
+        cur_cfg, cur_sk = engine.choose_tiling(list(m_list), meta["N"], meta["Kpad"], stride, math)
         res = []
         for cfg_id, (bm, bn) in hip.TILE_SHAPES.items():
+            if (bm, bn) not in engine.MATH_TILES[math]:
+                continue
             if (bn == 32) != (meta["N"] <= 32):
                 continue
             if bn == 128 and meta["N"] <= 64:
@@ -80,7 +83,7 @@ def main():
                 if sk == 1 and blocks > 6000 and (bm, bn) != hip.TILE_SHAPES[cur_cfg]:
                     continue
                 try:
-                    op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name)
+                    op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name, math=math)
                     us = time_op(pl, op)
                 except Exception as e:  # noqa: BLE001
                     us = float("nan")
@@ -97,7 +100,7 @@ def main():
 
 
     import json
-    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}.json")
+    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}_{os.environ.get('DD3D_MATH', 'f32')}.json")
     os.makedirs("gpurun_out", exist_ok=True)
     with open(out, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)

@@ -36,6 +36,9 @@ X3_CASES = [  # split-bf16 arithmetic (DD3D_MATH_BF16X3): same f32-level toleran
     ("x3_proj1x1_k32", 1, 24, 40, 32, 64, 1, 1, 0, False, False, None, None),
     ("x3_pred_n55", 1, 24, 40, 256, 55, 3, 1, 1, False, False, None, None),
     ("x3_model_choice", 1, 48, 160, 256, 256, 3, 1, 1, True, False, None, None),
+    ("x3_256x128", 1, 33, 41, 256, 256, 3, 1, 1, True, True, hip.TILE_256x128, 1),
+    ("x3_256x128_sk3_s2", 1, 30, 44, 128, 192, 3, 2, 1, False, False, hip.TILE_256x128, 3),
+    ("x3_256x128_k32", 1, 24, 40, 32, 128, 1, 1, 0, False, False, hip.TILE_256x128, 1),
 ]
 
 
@@ -145,7 +148,8 @@ def test_aux_kernels(hiplib):
     assert (invK.view(2, 3, 3).cpu() - K.inverse()).abs().max() < 1e-6
 
 
-def test_splitk_fixup_sees_fresh_partials(hiplib):
+@pytest.mark.parametrize("math", [hip.MATH_F32, hip.MATH_BF16X3], ids=["f32", "bf16x3"])
+def test_splitk_fixup_sees_fresh_partials(hiplib, math):
     """The split-K fix-up reads the other slices' partial sums across XCD-private L2s.  Re-launch ONE split-K conv with a
     new input every time (many tiles, so the slices of a tile land on different XCDs): a stale partial from the previous
     launch would give the previous answer.  Also checks the arrival counters are zero again after every launch."""
@@ -158,8 +162,8 @@ def test_splitk_fixup_sees_fresh_partials(hiplib):
     xin, yout = plan.buf("x", B, H, W, Cin), plan.buf("y", B, H, W, Cout)
     ones, zeros = torch.ones(Cout, device=plan.device), torch.zeros(Cout, device=plan.device)
     seg = {"in": xin.view(), "out": yout.view(), "w": wp, "scale": ones, "bias": zeros}
-    for tile, sk in ((hip.TILE_128x64, 4), (hip.TILE_64x64, 8)):
-        op = ConvOp(plan, meta, 1, 1, [seg], False, tile=tile, splitk=sk, name="stress")
+    for tile, sk in ((hip.TILE_128x64, 4), (hip.TILE_64x64, 8) if math == hip.MATH_F32 else (hip.TILE_256x128, 3)):
+        op = ConvOp(plan, meta, 1, 1, [seg], False, tile=tile, splitk=sk, name="stress", math=math)
         wd = w.to(plan.device)
         for it in range(12):
             x = torch.randn(B, Cin, H, W, generator=g)
