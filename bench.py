@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
+# Split-operand arithmetic spends 6 bf16 MFMA products per f32 product, so its roofline in f32-equivalent FLOP/s is
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 GFLOP_PER_IMAGE = 220.77  # DD3D-DLA34 KITTI 384x1280, 2 x 110.384 GMAC
 
 
@@ -69,7 +72,7 @@ def kernel_time_us(plan, op, iters=5, burst=8):
 
 def main():
     args = parse_args()
-    from dd3d_amd import build_model, get_cfg
+    from dd3d_amd import build_model, get_cfg, hip
     from dd3d_amd.engine import ConvOp
     from dd3d_amd.parallel import DistributedForward, init_distributed
     from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
@@ -114,17 +117,23 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    x3 = plan.math == hip.MATH_BF16X3
+    # "f32x3bf16": every f32 operand split exactly into 3 bf16 terms, 6 cross products on the bf16 matrix pipe, f32
+    # accumulation -- agrees with the f32-MFMA path to f32 rounding level (tests/test_conv_gpu.py); stem / N<=32 convs are f32 MFMA
+    dtype = "f32 (f32x3bf16 split-operand MFMA, f32 accumulate)" if x3 else "f32"
+    peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
     out = {
         "metric": "images/sec (384x1280) DD3D-DLA34 fwd", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {
             "workload": f"DD3D-DLA34 KITTI3D {args.height}x{args.width} bs={B}/GPU fp32 inference (BASELINE.json configs[1]); "
                         "uint8 image in HBM -> normalise/pad -> DLA-34 -> FPN P3-P7 -> FCOS2D/3D heads -> select/decode -> NMS",
             "global_batch": world * B, "parallelism": f"dp{world}" + ("+rccl_allgather_candidates" if world > 1 else ""),
             "hip_graph": not args.no_graph, "gflop_per_image": GFLOP_PER_IMAGE,
             "achieved_tflops_per_gpu": round(value / world * GFLOP_PER_IMAGE / 1e3, 2),
-            "frac_of_f32_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+            "math": "bf16x3" if x3 else "f32",
+            "frac_of_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4),
         },
     }
 
@@ -137,12 +146,15 @@ def main():
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
-                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch_" + ("bf16x3" if x3 else "f32"))
             except Exception:
                 traffic = None
+        kname = ("dd3d::conv_igemm_bf16x3_kernel<2,2,4,2,2,false>" if x3 else "dd3d::conv_igemm_f32_kernel<2,2,2,2,false,0,false>")
         out["roofline"] = {
-            "kernel": "dd3d::conv_igemm_f32_kernel<2,2,2,2,false> (head towers, 15 segments / launch)", "bound": "mfma",
-            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "kernel": kname + " (head towers, 15 segments / launch)", "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 products per f32 product (f32-equivalent); for reference the f32-input "
+                           "MFMA peak is 157.3") if x3 else "157.3 TFLOP/s dense f32-input MFMA",
             "traffic": traffic, "flops_per_launch": flops, "avg_launch_us": round(us, 2), "tile": list(towers[0].info["tile"]),
             "blocks": towers[0].info["blocks"],
         }

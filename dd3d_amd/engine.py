@@ -101,9 +101,14 @@ MATH_TILES = {hip.MATH_F32: ((128, 128), (128, 64), (64, 64), (128, 32), (64, 12
               hip.MATH_BF16X3: ((256, 128), (128, 128), (128, 64), (64, 128))}  # tiles the split-bf16 kernel is instantiated for
 
 
+MATH_NAMES = {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3}
+
+
 def default_math():
+    """Arithmetic of the Cin % 32 == 0 convolutions: "bf16x3" (default; f32-equivalent split-operand products on the bf16 matrix
+    pipe, ~1.9x the throughput) or "f32" (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).  Env DD3D_MATH or model.math."""
     import os
-    return {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3}[os.environ.get("DD3D_MATH", "f32")]
+    return MATH_NAMES[os.environ.get("DD3D_MATH", "bf16x3")]
 
 
 def tile_key(m_list, N, Kpad, stride):
@@ -340,6 +345,8 @@ class ForwardPlan(PlanBase):
     """Static launch plan of DD3D.forward (inference) for one (B, Hp, Wp)."""
     def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0):
         super().__init__(device or model.device, dry_run=dry_run)
+        if getattr(model, "math", None) is not None:
+            self.math = MATH_NAMES[model.math] if isinstance(model.math, str) else int(model.math)
         self.model = model
         self.B, self.Hp, self.Wp = B, Hp, Wp
         cfg = model.cfg

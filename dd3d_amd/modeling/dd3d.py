@@ -52,6 +52,7 @@ class DD3D(nn.Module):
         self.register_buffer("pixel_std", torch.Tensor(list(cfg.MODEL.PIXEL_STD)).view(-1, 1, 1))
         self._plans = {}
         self.use_graph = True
+        self.math = None  # None: DD3D_MATH / the default ("bf16x3"); or "f32" / "bf16x3" (set before the first forward)
         self.training = False
 
     @property
@@ -87,7 +88,7 @@ class DD3D(nn.Module):
         return (bool(self.postprocess_in_inference), bool(self.do_nms), bool(self.do_bev_nms))
 
     def get_plan(self, B, Hp, Wp, world_size=1, rank=0):
-        key = (B, Hp, Wp, world_size, rank) + self._sync_flags()
+        key = (B, Hp, Wp, world_size, rank, self.math) + self._sync_flags()
         plan = self._plans.get(key)
         if plan is None:
             plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank)

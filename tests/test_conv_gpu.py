@@ -174,3 +174,29 @@ def test_splitk_fixup_sees_fresh_partials(hiplib, math):
             got = yout.nchw().cpu()
             assert float((got - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), (tile, sk, it)
             assert int(op.counters.abs().sum()) == 0
+
+
+def test_split_bf16_is_f32_accurate(hiplib):
+    """Error of both arithmetic modes against a float64 convolution of the same f32 data: the split-operand (3 x bf16, 6
+    products) path must sit at f32 rounding level like the f32-MFMA path -- not at bf16 level (which would be ~1e-2)."""
+    from dd3d_amd.engine import ConvOp, PlanBase, pack_filter
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 1, 24, 40, 256, 256
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 48.0
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    plan = PlanBase("cuda")
+    wp, meta = pack_filter(w, plan.device)
+    xin, yout = plan.buf("x", B, H, W, Cin), plan.buf("y", B, H, W, Cout)
+    xin.t.copy_(x.permute(0, 2, 3, 1))
+    ones, zeros = torch.ones(Cout, device=plan.device), torch.zeros(Cout, device=plan.device)
+    seg = {"in": xin.view(), "out": yout.view(), "w": wp, "scale": ones, "bias": zeros}
+    err = {}
+    for math in (hip.MATH_F32, hip.MATH_BF16X3):
+        op = ConvOp(plan, meta, 1, 1, [seg], False, name="acc", math=math)
+        op(plan.lib, hip.current_stream())
+        torch.cuda.synchronize()
+        err[math] = float((yout.nchw().cpu().double() - ref).abs().max() / ref.abs().max())
+    print("max |err| / max |ref|: f32 MFMA %.2e, split bf16 %.2e" % (err[hip.MATH_F32], err[hip.MATH_BF16X3]))
+    assert err[hip.MATH_F32] < 2e-6 and err[hip.MATH_BF16X3] < 2e-6
+    assert err[hip.MATH_BF16X3] < 3 * err[hip.MATH_F32] + 2e-7

@@ -64,11 +64,12 @@ def _check_final(out, ref, exact_ints=True):
     assert float((c_got - c_ref).abs().mean()) <= REL_TOL * max(1.0, float(c_ref.abs().mean()))
 
 
-@pytest.mark.parametrize("H,W,B", [(128, 256, 2), (384, 1280, 1)], ids=["small_b2", "kitti_full"])
-def test_forward_matches_oracle(hiplib, kitti_dla34, H, W, B):
+@pytest.mark.parametrize("H,W,B,math", [(128, 256, 2, None), (128, 256, 2, "f32"), (384, 1280, 1, None), (384, 1280, 1, "f32")],
+                         ids=["small_b2", "small_b2_f32mfma", "kitti_full", "kitti_full_f32mfma"])
+def test_forward_matches_oracle(hiplib, kitti_dla34, H, W, B, math):
     from dd3d_amd.synthetic import make_inputs
     cfg, _, sd = kitti_dla34
-    model = gpu_model(cfg, sd, use_graph=False)
+    model = gpu_model(cfg, sd, use_graph=False, math=math)
     inputs = make_inputs(B, H, W)
     if B > 1:  # ragged batch: second image smaller -> right/bottom zero padding after normalisation (image_list.py:120-142)
         inputs[1]["image"] = inputs[1]["image"][:, :H - 13, :W - 22].contiguous()

@@ -40,11 +40,12 @@ def quat_err(qa, qb):
     return float(torch.minimum((qa - qb).abs().amax(1), (qa + qb).abs().amax(1)).max())
 
 
-def gpu_model(cfg, sd, use_graph=True):
+def gpu_model(cfg, sd, use_graph=True, math=None):
     from dd3d_amd import build_model
     model = build_model(cfg)
     model.load_state_dict(sd)
     model.use_graph = use_graph
+    model.math = math
     return model
 
 
