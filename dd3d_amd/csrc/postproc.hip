@@ -96,7 +96,7 @@ __global__ __launch_bounds__(PT) void fcos_select_decode_kernel(const SelectK P)
 
   // ---- phase 1: score, threshold, ordered compaction  (fcos2d.py:274-300)
   // Each thread owns VPT consecutive (location, class) elements per round, so the block needs one scan per 4096 elements
-  // (the scan's two barriers, not the loads, set the pace of this phase).
+  // (measured A/B on one box: VPT 16 is 10 % slower than 4).
   constexpr int VPT = 4;
   int running = 0;
   for (int base = 0; base < n_el; base += PT * VPT) {
@@ -343,6 +343,22 @@ struct NmsK {
   int ncap2;  // next power of two >= levels*topk (size of the LDS sort arrays)
 };
 
+// Rank of (ki, position pos) among keys[0, n) in descending order, ties by position: the initial order of both sorters is
+// by increasing value index, so "val_j < val_i" is "j < pos" and the index array need not be read.  One broadcast
+// ds_read_b128 feeds four comparisons; keys[n, round_up(n, 4)) must hold -inf.
+__device__ __forceinline__ int rank_of(const float* keys, int n, float ki, int pos) {
+  int rank = 0;
+#pragma unroll 4
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    const float4 k4 = *reinterpret_cast<const float4*>(keys + j0);
+    rank += (k4.x > ki) || (k4.x == ki && j0 + 0 < pos);
+    rank += (k4.y > ki) || (k4.y == ki && j0 + 1 < pos);
+    rank += (k4.z > ki) || (k4.z == ki && j0 + 2 < pos);
+    rank += (k4.w > ki) || (k4.w == ki && j0 + 3 < pos);
+  }
+  return rank;
+}
+
 // mode written to nvalid[g][1]
 enum { NMS_TRICK = 0, NMS_PER_CLASS = 1, NMS_NONE = 2 };
 
@@ -367,7 +383,7 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   __syncthreads();
   const int n = pref[L];
   const bool suppress = a.do_nms && a.nms_thresh > 0.f;
-  int Pn = 1;
+  int Pn = 4;  // >= 4: the vectorised rank loop reads keys in quads
   while (Pn < n) Pn <<= 1;
   const float* key_src = cand + (a.use_score3d ? 5 : 4) * NS;
   float mx = -INFINITY;
@@ -394,13 +410,11 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   if (suppress) {
     if (n <= PT) {
       // rank sort: one candidate per thread, rank = number of candidates that sort before it (n LDS broadcasts)
+      // (measured: the scalar version of this loop -- two dependent ds_read_b32 per step -- took 107 k cycles for n = 511)
       const float ki = tid < n ? keys[tid] : 0.f;
       const int vi = tid < n ? vals[tid] : 0;
       int rank = 0;
-      if (tid < n) {
-#pragma unroll 16
-        for (int j = 0; j < n; ++j) rank += sorts_before(keys[j], vals[j], ki, vi);  // unrolled: LDS reads pipelined
-      }
+      if (tid < n) rank = rank_of(keys, n, ki, tid);
       __syncthreads();
       if (tid < n) {
         keys[rank] = ki;
@@ -469,6 +483,65 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsK P) {
   a.mask[((long)g * P.ncap + i) * (P.ncap / 64) + cb] = bits;
 }
 
+// Greedy suppression over a precomputed bit mask (row i, bit j set: j > i and i suppresses j), one block of PT threads.
+// Block row rb = candidates rb*64 .. rb*64+63.  Wave 0 resolves the row's 64 candidates from the DIAGONAL words alone: the
+// loop is fully unrolled with constant lane selects, so `rem` / `keep` live in SGPRs and a step is two v_readlane plus a few
+// scalar ops (the previous ds_bpermute / LDS-chasing version spent 118 cycles per step and 5.7 k cycles per row in the
+// OR phase).  Meanwhile wave w holds word rb+w of the 64 rows (one lane per row), loaded straight from the mask; after
+// the keep bits are published each wave ORs the words of the kept rows with a 6-step butterfly and folds them into
+// removed[rb+w] (fetching all words of an n <= 1024 problem up front measured 10 % SLOWER, A/B on one box).
+// on_row(rb, keepbits) runs on wave 0 (all 64 lanes) for every block row, in order.
+template <class F>
+__device__ __forceinline__ void greedy_reduce(const unsigned long long* mask, int nw, int n, unsigned long long* removed, F&& on_row) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ unsigned long long sh_keepbits;
+  const int nwords = (n + 63) / 64;
+  for (int rb = 0; rb < nwords; ++rb) {
+    const int i = rb * 64 + lane;
+    unsigned long long keepbits = 0;
+    if (wave == 0) {
+      const unsigned long long diag = i < n ? mask[(long)i * nw + rb] : 0ull;
+      const unsigned long long rem0 = removed[rb];
+      unsigned long long rem = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem0) |
+                               ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem0 >> 32)) << 32);
+      const int lim = min(64, n - rb * 64);
+      if (lim < 64) rem |= ~0ull << lim;  // rows past n can never be kept
+      const int dlo = (int)(unsigned)diag, dhi = (int)(unsigned)(diag >> 32);
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const unsigned long long dj = (unsigned)__builtin_amdgcn_readlane(dlo, j) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, j) << 32);
+        if (!((rem >> j) & 1ull)) {
+          keepbits |= 1ull << j;
+          rem |= dj;
+        }
+      }
+      if (lane == 0) sh_keepbits = keepbits;
+      on_row(rb, keepbits);
+    }
+    // words of the later columns: wave w -> word rb + w (+16, +32, ...), lane -> row; issued before the barrier so the loads
+    // overlap wave 0's serial part
+    unsigned long long word[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cw = rb + wave + 16 * q + (wave == 0 ? 16 : 0);  // wave 0 owns the diagonal; its first later word is rb + 16
+      word[q] = (cw < nwords && i < n) ? mask[(long)i * nw + cw] : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long kb = sh_keepbits;
+    const bool mine = (kb >> lane) & 1ull;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cw = rb + wave + 16 * q + (wave == 0 ? 16 : 0);
+      if (cw >= nwords) break;  // wave-uniform
+      unsigned long long v = mine ? word[q] : 0ull;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v |= __shfl_xor(v, d, 64);
+      if (lane == 0) removed[cw] |= v;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -484,8 +557,9 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   int* kept = reinterpret_cast<int*>(removed + NCAP_MAX / 64);  // [ncap2] sorted positions that survive NMS, in order
   float* tkeys = reinterpret_cast<float*>(kept + P.ncap2);      // [ncap2] scratch for the top-k threshold
   int* tvals = reinterpret_cast<int*>(tkeys + P.ncap2);         // [ncap2]
+  int* sidx = tvals + P.ncap2;                                  // [ncap2] sort_idx staged once (cuts a level off every gather below)
+  for (int i = tid; i < n; i += PT) sidx[i] = sort_idx[i];
   __shared__ int wsum[PT / 64];
-  __shared__ unsigned long long sh_keepbits;
   __shared__ int sh_nkeep;
   __shared__ float sh_thr;
 
@@ -495,55 +569,15 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
     nkeep = n;
     __syncthreads();
   } else {
-    const int nwords = (n + 63) / 64;
     for (int i = tid; i < NCAP_MAX / 64; i += PT) removed[i] = 0;
     if (tid == 0) sh_nkeep = 0;
     __syncthreads();
-    unsigned long long* stage = reinterpret_cast<unsigned long long*>(tkeys);  // [64][nwords] mask words of this block row
-    for (int rb = 0; rb < nwords; ++rb) {
-      // stage the 64 mask rows of this block row (words rb .. nwords-1) in LDS: one parallel, coalesced read instead of
-      // dependent global loads inside the serial part
-      const int nwr = nwords - rb;
-      for (int idx = tid; idx < 64 * nwr; idx += PT) {
-        const int j = idx / nwr, w = idx - j * nwr;
-        const int i = rb * 64 + j;
-        stage[j * nwords + w] = i < n ? mask[(long)i * nw + rb + w] : 0ull;
-      }
-      __syncthreads();
-      if (tid < 64) {  // wave 0: resolve the 64 candidates of this block row sequentially (diagonal word only)
-        const int i = rb * 64 + tid;
-        const unsigned long long diag = stage[tid * nwords];
-        unsigned long long rem = removed[rb];
-        unsigned long long keepbits = 0;
-        const int lim = min(64, n - rb * 64);
-        for (int j = 0; j < lim; ++j) {
-          const unsigned long long dj = __shfl(diag, j, 64);
-          if (!((rem >> j) & 1ull)) {
-            keepbits |= 1ull << j;
-            rem |= dj;
-          }
-        }
-        if (tid == 0) sh_keepbits = keepbits;
-        // append the kept positions in order
-        const int base = sh_nkeep;
-        if ((keepbits >> tid) & 1ull) kept[base + __popcll(keepbits & ((1ull << tid) - 1ull))] = i;
-        if (tid == 0) sh_nkeep = base + __popcll(keepbits);
-      }
-      __syncthreads();
-      // everyone: OR the kept rows into the removed bitmap of the later column words
-      const unsigned long long kb = sh_keepbits;
-      for (int cw = rb + 1 + tid; cw < nwords; cw += PT) {
-        unsigned long long acc = removed[cw];
-        unsigned long long bitsleft = kb;
-        while (bitsleft) {
-          const int j = __ffsll((long long)bitsleft) - 1;
-          bitsleft &= bitsleft - 1;
-          acc |= stage[j * nwords + (cw - rb)];
-        }
-        removed[cw] = acc;
-      }
-      __syncthreads();
-    }
+    greedy_reduce(mask, nw, n, removed, [&](int rb, unsigned long long keepbits) {
+      // append the kept positions in order (wave 0, lane = row of the block row)
+      const int base = sh_nkeep;
+      if ((keepbits >> tid) & 1ull) kept[base + __popcll(keepbits & ((1ull << tid) - 1ull))] = rb * 64 + tid;
+      if (tid == 0) sh_nkeep = base + __popcll(keepbits);
+    });
     nkeep = sh_nkeep;
   }
 
@@ -553,16 +587,16 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   if (a.do_nms && a.post_topk > 0 && nkeep > a.post_topk) {
     if (nkeep <= PT) {
       // one kept detection per thread: it is the k-th largest iff (#greater < k <= #greater-or-equal)
-      const float my = tid < nkeep ? score2d[sort_idx[kept[tid]]] : 0.f;
-      if (tid < nkeep) tkeys[tid] = my;
+      const float my = tid < nkeep ? score2d[sidx[kept[tid]]] : -INFINITY;
+      if (tid < ((nkeep + 3) & ~3)) tkeys[tid] = my;  // -inf padding up to a multiple of 4 (nkeep <= PT)
       __syncthreads();
       if (tid < nkeep) {
         int gt = 0, ge = 0;
-#pragma unroll 16
-        for (int j = 0; j < nkeep; ++j) {
-          const float v = tkeys[j];
-          gt += v > my;
-          ge += v >= my;
+#pragma unroll 4
+        for (int j0 = 0; j0 < nkeep; j0 += 4) {  // one broadcast ds_read_b128 per four candidates
+          const float4 v = *reinterpret_cast<const float4*>(tkeys + j0);
+          gt += (v.x > my) + (v.y > my) + (v.z > my) + (v.w > my);
+          ge += (v.x >= my) + (v.y >= my) + (v.z >= my) + (v.w >= my);
         }
         if (gt < a.post_topk && a.post_topk <= ge) sh_thr = my;  // every thread that gets here holds the same value
       }
@@ -571,7 +605,7 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
       int Pn = 1;
       while (Pn < nkeep) Pn <<= 1;
       for (int i = tid; i < Pn; i += PT) {
-        tkeys[i] = i < nkeep ? score2d[sort_idx[kept[i]]] : -INFINITY;
+        tkeys[i] = i < nkeep ? score2d[sidx[kept[i]]] : -INFINITY;
         tvals[i] = i;
       }
       __syncthreads();
@@ -593,7 +627,7 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
     int pass = 0, slot = 0;
     float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     if (i < nkeep) {
-      slot = sort_idx[kept[i]];
+      slot = sidx[kept[i]];
       pass = score2d[slot] >= thr;
       x1 = cand[0 * NS + slot], y1 = cand[1 * NS + slot], x2 = cand[2 * NS + slot], y2 = cand[3 * NS + slot];
       if (a.do_postprocess) {
@@ -830,7 +864,7 @@ __global__ __launch_bounds__(PT) void bev_prepare_kernel(const BevK P) {
     mx = fmaxf(mx, fmaxf(cx, cy) + ext);
     mn = fminf(mn, fminf(cx, cy) - ext);
   }
-  int Pn = 1;
+  int Pn = 4;
   while (Pn < n) Pn <<= 1;
   for (int i = n + tid; i < Pn; i += PT) keys[i] = -INFINITY, vals[i] = 0x7fffffff;
   for (int dlt = 32; dlt > 0; dlt >>= 1) {
@@ -845,10 +879,7 @@ __global__ __launch_bounds__(PT) void bev_prepare_kernel(const BevK P) {
     const float ki = tid < n ? keys[tid] : 0.f;
     const int vi = tid < n ? vals[tid] : 0;
     int rank = 0;
-    if (tid < n) {
-#pragma unroll 16
-      for (int j = 0; j < n; ++j) rank += sorts_before(keys[j], vals[j], ki, vi);
-    }
+    if (tid < n) rank = rank_of(keys, n, ki, tid);
     __syncthreads();
     if (tid < n) keys[rank] = ki, vals[rank] = vi;
   } else {
@@ -904,11 +935,9 @@ __global__ __launch_bounds__(PT) void bev_finalize_kernel(const BevK P) {
   const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(a.mask);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   unsigned long long* removed = reinterpret_cast<unsigned long long*>(dyn_lds);          // [NCAP_MAX/64]
-  unsigned long long* stage = removed + NCAP_MAX / 64;                                  // [64][nwords] <= 64 KiB
-  int* keepflag = reinterpret_cast<int*>(stage + (size_t)64 * (P.ncap2 / 64));           // [ncap2] by ORIGINAL index
+  int* keepflag = reinterpret_cast<int*>(removed + NCAP_MAX / 64);                       // [ncap2] by ORIGINAL index
   __shared__ int wsum[PT / 64];
-  __shared__ int offs[1025], imgbase[1025];
-  __shared__ unsigned long long sh_keepbits;
+  __shared__ int offs[1025];
   __shared__ int sh_nkeep;
   if (tid == 0) {
     int acc = 0;
@@ -926,50 +955,14 @@ __global__ __launch_bounds__(PT) void bev_finalize_kernel(const BevK P) {
     if (tid < a.G) a.count_out[tid] = -1;
     return;
   }
-  const int nwords = (n + 63) / 64;
   const int cap = a.max_dets > 0 ? a.max_dets : 0x7fffffff;
-  for (int rb = 0; rb < nwords; ++rb) {
-    const int nwr = nwords - rb;
-    for (int idx = tid; idx < 64 * nwr; idx += PT) {
-      const int j = idx / nwr, w = idx - j * nwr;
-      const int i = rb * 64 + j;
-      stage[j * nwords + w] = i < n ? mask[(long)i * nw + rb + w] : 0ull;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int i = rb * 64 + tid;
-      const unsigned long long diag = stage[tid * nwords];
-      unsigned long long rem = removed[rb];
-      unsigned long long keepbits = 0;
-      const int lim = min(64, n - rb * 64);
-      for (int j = 0; j < lim; ++j) {
-        const unsigned long long dj = __shfl(diag, j, 64);
-        if (!((rem >> j) & 1ull)) {
-          keepbits |= 1ull << j;
-          rem |= dj;
-        }
-      }
-      if (tid == 0) sh_keepbits = keepbits;
-      const int base = sh_nkeep;
-      // keep[:max_dets] truncates the score-ordered keep list of the WHOLE batch (postprocessing.py:93-94)
-      if (((keepbits >> tid) & 1ull) && base + __popcll(keepbits & ((1ull << tid) - 1ull)) < cap)
-        keepflag[__float_as_int(a.sbox[(long)i * 8 + 6])] = 1;
-      if (tid == 0) sh_nkeep = base + __popcll(keepbits);
-    }
-    __syncthreads();
-    const unsigned long long kb = sh_keepbits;
-    for (int cw = rb + 1 + tid; cw < nwords; cw += PT) {
-      unsigned long long acc = removed[cw];
-      unsigned long long bitsleft = kb;
-      while (bitsleft) {
-        const int j = __ffsll((long long)bitsleft) - 1;
-        bitsleft &= bitsleft - 1;
-        acc |= stage[j * nwords + (cw - rb)];
-      }
-      removed[cw] = acc;
-    }
-    __syncthreads();
-  }
+  greedy_reduce(mask, nw, n, removed, [&](int rb, unsigned long long keepbits) {
+    const int base = sh_nkeep;
+    // keep[:max_dets] truncates the score-ordered keep list of the WHOLE batch (postprocessing.py:93-94)
+    if (((keepbits >> tid) & 1ull) && base + __popcll(keepbits & ((1ull << tid) - 1ull)) < cap)
+      keepflag[__float_as_int(a.sbox[(long)(rb * 64 + tid) * 8 + 6])] = 1;
+    if (tid == 0) sh_nkeep = base + __popcll(keepbits);
+  });
   // survivors, image by image, in their original order
   int running = 0;
   for (int g = 0; g < a.G; ++g) {
@@ -1043,12 +1036,12 @@ extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
   while (P.ncap2 < ns) P.ncap2 <<= 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds_sort = (size_t)P.ncap2 * 8;
-  const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 12;
+  const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 16;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NCAP_MAX / 64 * 8 + NCAP_MAX * 12);
+                              NCAP_MAX / 64 * 8 + NCAP_MAX * 16);
     attr_done = true;
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(args->G), dim3(PT), lds_sort, st, P);
@@ -1077,12 +1070,12 @@ extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
   while (P.ncap2 < ntot && P.ncap2 < NCAP_MAX) P.ncap2 <<= 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds_prep = (size_t)P.ncap2 * 8;
-  const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)64 * (P.ncap2 / 64) * 8 + (size_t)P.ncap2 * 4;
+  const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 4;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bev_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bev_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NCAP_MAX / 64 * 8 + NCAP_MAX * 8 + NCAP_MAX * 4);
+                              NCAP_MAX / 64 * 8 + NCAP_MAX * 4);
     attr_done = true;
   }
   hipLaunchKernelGGL(bev_prepare_kernel, dim3(1), dim3(PT), lds_prep, st, P);
