@@ -18,6 +18,7 @@
 //                              used for the Cin < 32 stem layers and, by default, for the 128x128 head-tower tile.
 //   conv_igemm_f32_dma_kernel  LDS-DMA (global_load_lds_dwordx4) into a multi-stage swizzled ring with counted vmcnt
 //                              waits and raw barriers; Cin % 32 == 0 only; used for every other layer.
+#include <cstring>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -44,6 +45,10 @@ struct ConvKArgs {
   int relu, splitk, kt_per_split;
   const float* zeros;  // >= 128 B of zeros (source of padded taps for the LDS-DMA kernel)
   int* tile_counters;  // split-K: arrivals per output tile (zero between launches)
+  // Single-segment launches (every backbone / FPN conv) carry their descriptor in the kernel arguments: the block then
+  // starts its first data loads without the tiles[] -> segs[] -> pointer chain of dependent scalar loads.
+  int single, BMrows;
+  dd3d_conv_seg seg0;
 };
 
 // Global-address-space views: the segment descriptor is loaded from memory, so without these casts the compiler
@@ -192,10 +197,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
   const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
   const int mt = bid / a.nn;
   const int nt = bid - mt * a.nn;
-  const int seg_id = a.tiles[2 * mt];
-  const int m0 = a.tiles[2 * mt + 1];
+  int m0 = mt * BM;
+  dd3d_conv_seg s = a.seg0;
+  if (!a.single) {
+    m0 = a.tiles[2 * mt + 1];
+    s = a.segs[a.tiles[2 * mt]];
+  }
   const int n0 = nt * BN;
-  const dd3d_conv_seg s = a.segs[seg_id];
   const gcfp g_in = as_g(s.in);
   const gcfp g_w = as_g(s.w);
 
@@ -405,10 +413,13 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
   const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
   const int mt = bid / a.nn;
   const int nt = bid - mt * a.nn;
-  const int seg_id = a.tiles[2 * mt];
-  const int m0 = a.tiles[2 * mt + 1];
+  int m0 = mt * BM;
+  dd3d_conv_seg s = a.seg0;
+  if (!a.single) {
+    m0 = a.tiles[2 * mt + 1];
+    s = a.segs[a.tiles[2 * mt]];
+  }
   const int n0 = nt * BN;
-  const dd3d_conv_seg s = a.segs[seg_id];
   const gcfp g_in = as_g(s.in);
   const gcfp g_w = as_g(s.w);
   const gcfp g_zero = as_g(a.zeros);
@@ -629,10 +640,13 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
   const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
   const int mt = bid / a.nn;
   const int nt = bid - mt * a.nn;
-  const int seg_id = a.tiles[2 * mt];
-  const int m0 = a.tiles[2 * mt + 1];
+  int m0 = mt * BM;
+  dd3d_conv_seg s = a.seg0;
+  if (!a.single) {
+    m0 = a.tiles[2 * mt + 1];
+    s = a.segs[a.tiles[2 * mt]];
+  }
   const int n0 = nt * BN;
-  const dd3d_conv_seg s = a.segs[seg_id];
   const gcfp g_in = as_g(s.in);
   const gcfp g_zero = as_g(a.zeros);
   const unsigned char __attribute__((address_space(1)))* g_w3 = (const unsigned char __attribute__((address_space(1)))*)s.w;
@@ -975,6 +989,10 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.splitk = L->splitk;
   ka.zeros = L->zero_page;
   ka.tile_counters = L->tile_counters;
+  ka.single = (L->nsegs == 1 && L->seg0_host != nullptr);
+  ka.BMrows = bm;
+  if (ka.single) ka.seg0 = *L->seg0_host;
+  else memset(&ka.seg0, 0, sizeof(ka.seg0));
   const int nk = L->Kpad / 32;
   ka.kt_per_split = ceil_div(nk, L->splitk);
   const bool smallc = L->Cin < 32;

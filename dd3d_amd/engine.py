@@ -214,6 +214,7 @@ class ConvOp:
             ws_rows += m_list[i]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
             self.keep += [w, s["scale"], s["bias"], s.get("lo")]
+        self.segs_host = arr  # kept alive: single-segment launches hand the descriptor over by value (seg0_host)
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
         # split-K: private partial-sum slab + per-tile arrival counters (private, so that independent convs may overlap)
@@ -231,6 +232,7 @@ class ConvOp:
         L.Cin, L.N, L.Kpad, L.Npad = meta["Cin"], meta["N"], meta["Kpad"], meta["Npad"]
         L.relu, L.splitk, L.math_mode, L.tile_cfg = int(relu), sk, math, cfg
         L.zero_page = plan.zero_page.data_ptr()
+        L.seg0_host = self.segs_host.ctypes.data if len(segs) == 1 else None
         self.L = L
         self.macs = sum(m_list) * meta["N"] * meta["KH"] * meta["KW"] * meta["Cin"]
         self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), splitk=sk, math=math,

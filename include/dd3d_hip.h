@@ -93,6 +93,8 @@ typedef struct dd3d_conv_launch {  /* host memory */
   int32_t* tile_counters; /* device, ceil(N/BN) * ntiles int32, ZERO on entry when splitk > 1 (else NULL).  The slice of an
                              output tile that arrives last sums the partial slabs in slice order and applies the epilogue
                              inside the same launch; the counters are zero again when the launch has completed. */
+  const dd3d_conv_seg* seg0_host; /* HOST copy of segs[0], or NULL.  With nsegs == 1 the descriptor then travels in the kernel
+                                     arguments (tiles are taken as m0 = i * BM) and the device copies are not read. */
 } dd3d_conv_launch;
 
 /* Arithmetic of the implicit GEMM (results agree to f32 rounding level; both accumulate in f32):

@@ -125,7 +125,7 @@ def test_cabi_exports_match_header(hiplib):
     for cfg_id, shape in hip.TILE_SHAPES.items():
         assert hiplib.dd3d_conv_tile_shape(cfg_id, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == shape
     assert hiplib.dd3d_conv_tile_shape(99, C.byref(bm), C.byref(bn)) < 0 and b"tile_cfg" in hiplib.dd3d_last_error()
-    assert C.sizeof(hip.ConvLaunch) == 96 and hip.CONV_SEG_DTYPE.itemsize == 120
+    assert C.sizeof(hip.ConvLaunch) == 104 and hip.CONV_SEG_DTYPE.itemsize == 120
 
 
 def test_config_surface():
