@@ -611,24 +611,25 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int TM, int TN, int WM, int WN, int NSB, bool SK>
-__global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs a) {
+template <int TM, int TN, int WM, int WN, int NSA, int NSB, bool SK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const ConvKArgs a) {
   constexpr int BM = TM * 32 * WM;
   constexpr int BN = TN * 32 * WN;
-  constexpr int NTHR = 512;
+  constexpr int NW = WM * WN;                // waves per block: 8 (two per SIMD) or 4 (then two blocks share a CU)
+  constexpr int NTHR = 64 * NW;
   constexpr int AP = BM * 8 / NTHR;         // 16-byte f32 pieces of the A tile per thread
   constexpr int PLA = BM * 64;              // bytes per A plane
   constexpr int PLB = BN * 64;              // bytes per B plane
   constexpr int A_STAGE = 3 * PLA, B_STAGE = 3 * PLB;
   constexpr int NPIECE = B_STAGE / 1024;    // 1-KiB DMA pieces per B stage
-  constexpr int PB = (NPIECE + 7) / 8;      // pieces per wave (the surplus re-fetches an existing piece)
+  constexpr int PB = (NPIECE + NW - 1) / NW;  // pieces per wave (the surplus re-fetches an existing piece)
   // A(kt+1) and B(kt+1) must have landed when step kt stores A(kt+1).  Issue order is ... A(x) B(x) A(x+1) B(x+1) ... with
   // a 3-stage B ring (B(kt+3) refills the stage step kt consumed) and ... A(x+1) B(x) A(x+2) B(x+1) ... with 2 stages
   // (B(kt+2) refills it), so the in-order wait leaves one step's worth in flight, or nothing.
   constexpr int WAIT_A = NSB == 3 ? AP + PB : 0;
-  static_assert(WM * WN == 8 && AP >= 1 && (NSB == 2 || NSB == 3), "8 waves per block");
+  static_assert((NW == 8 || NW == 4) && AP >= 1 && (NSB == 2 || NSB == 3) && (NSA == 1 || NSA == 2), "block shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);  // [A stage 0 | A stage 1 | B stage 0 .. NSB-1]
+  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);  // [A stage 0 .. NSA-1 | B stage 0 .. NSB-1]
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
 
   const int tid = threadIdx.x;
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
     const int howo = s.Ho * s.Wo;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const int m = m0 + p * 64 + arow;
+      const int m = m0 + p * (NTHR / 8) + arow;
       if (m < s.M) {
         const int b = m / howo;
         const int r = m - b * howo;
@@ -683,8 +684,8 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
       }
     }
   }
-  // LDS byte offset (inside a plane) of this thread's 8-byte half slot; piece p adds p * 64 rows (the swizzle term only
-  // depends on (row >> 2) & 3, which 64-row steps leave unchanged)
+  // LDS byte offset (inside a plane) of this thread's 8-byte half slot; piece p adds p * NTHR/8 rows (the swizzle term only
+  // depends on (row >> 2) & 3, which 32- or 64-row steps leave unchanged)
   const int a_st0 = arow * 64 + (((avec >> 1) ^ ((arow >> 2) & 3)) << 4) + ((avec & 1) << 3);
 
   // ---- B DMA geometry: piece = q*8 + wave (mod NPIECE) -> (plane, 16-row block); lane -> (row = lane >> 2, LDS slot = lane & 3)
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
   int b_dst[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
-    int piece = q * 8 + wave;
+    int piece = q * NW + wave;
     piece = piece >= NPIECE ? piece - NPIECE : piece;
     const int plane = piece / (BN / 16);
     const int rb = piece - plane * (BN / 16);
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
 #pragma unroll
     for (int q = 0; q < PB; ++q)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(g_w3 + b_src[q] + (long)kt * 192),
-                                       (ldsbp)(lds + 2 * A_STAGE + stage * B_STAGE + b_dst[q]), 16, 0, 0);
+                                       (ldsbp)(lds + NSA * A_STAGE + stage * B_STAGE + b_dst[q]), 16, 0, 0);
   };
   // split four f32 into the three bf16 planes (exact, by truncation) and store them
   auto split_store = [&](auto set_c, int stage) {
@@ -763,9 +764,9 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
       const u32x2 hv = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
       const u32x2 mv = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
       const u32x2 lv = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
-      *reinterpret_cast<u32x2*>(As + p * 4096) = hv;
-      *reinterpret_cast<u32x2*>(As + PLA + p * 4096) = mv;
-      *reinterpret_cast<u32x2*>(As + 2 * PLA + p * 4096) = lv;
+      *reinterpret_cast<u32x2*>(As + p * (NTHR * 8)) = hv;
+      *reinterpret_cast<u32x2*>(As + PLA + p * (NTHR * 8)) = mv;
+      *reinterpret_cast<u32x2*>(As + 2 * PLA + p * (NTHR * 8)) = lv;
     }
   };
   auto lds_barrier = [&]() {
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
 
   auto compute_tile = [&](int sa, int sb) {
     const unsigned char* As = lds + sa * A_STAGE + wm * TM * 32 * 64;
-    const unsigned char* Bs = lds + 2 * A_STAGE + sb * B_STAGE + wn * TN * 32 * 64;
+    const unsigned char* Bs = lds + NSA * A_STAGE + sb * B_STAGE + wn * TN * 32 * 64;
     bf16x8 af[2][TM][3], bf[2][TN][3];  // fragments of both k-chunks: the reads of chunk 1 fly under the MFMAs of chunk 0
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -830,17 +831,20 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvKArgs 
     lds_barrier();
     if (NSB == 3) issue_b(min(kt_begin + 2, kt_last), 2);
     int sb = 0;
-    // Step kt: MFMAs of tile kt | split + store A(kt+1) | A(kt+3) -> the register set just stored | barrier | B refill of
-    // the ring stage just consumed.  Exactly AP + PB VMEM operations per step (indices clamped past the end).
+    // Step kt: MFMAs of tile kt | [one A stage: barrier, everyone is done reading it] | split + store A(kt+1) | A(kt+3) -> the
+    // register set just stored | barrier | B refill of the ring stage just consumed.  Exactly AP + PB VMEM operations per
+    // step (indices clamped past the end).
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
       compute_tile(0, sb);
-      split_store(S1, 1);
+      if (NSA == 1) lds_barrier();
+      split_store(S1, NSA - 1);
       load_a(S1);
       lds_barrier();
       issue_b(min(kt + NSB, kt_last), sb);
       sb = sb == NSB - 1 ? 0 : sb + 1;
       if (kt + 1 >= kt_end) break;
-      compute_tile(1, sb);
+      compute_tile(NSA - 1, sb);
+      if (NSA == 1) lds_barrier();
       split_store(S0, 0);
       load_a(S0);
       lds_barrier();
@@ -900,21 +904,21 @@ static void launch_dma(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   else launch_dma_sk<TM, TN, WM, WN, NS, U, WK, false>(ka, grid, st);
 }
 
-template <int TM, int TN, int WM, int WN, int NSB>
+template <int TM, int TN, int WM, int WN, int NSA, int NSB>
 static int launch_x3(const ConvKArgs& ka, hipStream_t st) {
-  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
-  const size_t lds = (size_t)2 * 3 * BM * 64 + (size_t)NSB * 3 * BN * 64;
+  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
+  const size_t lds = (size_t)NSA * 3 * BM * 64 + (size_t)NSB * 3 * BN * 64;
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, true>), grid, dim3(512), lds, st, ka);
-  else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSB, false>), grid, dim3(512), lds, st, ka);
+  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, true>), grid, dim3(NTHR), lds, st, ka);
+  else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, false>), grid, dim3(NTHR), lds, st, ka);
   return check_launch("conv_igemm_bf16x3 kernel");
 }
 
@@ -953,7 +957,7 @@ static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
 }  // namespace dd3d
 
 extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) {
-  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}};
+  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}};
   DD3D_REQUIRE(tile_cfg >= 0 && tile_cfg < DD3D_TILE_COUNT, "dd3d_conv_tile_shape: unknown tile_cfg %d", tile_cfg);
   *bm = shapes[tile_cfg][0];
   *bn = shapes[tile_cfg][1];
@@ -1000,10 +1004,15 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   if (L->math_mode == DD3D_MATH_BF16X3) {
     DD3D_REQUIRE(!smallc && L->zero_page, "dd3d_conv2d_igemm_f32: the split-bf16 kernel needs Cin %% 32 == 0 and a zero page");
     switch (L->tile_cfg) {
-      case DD3D_TILE_128x128: return launch_x3<2, 1, 2, 4, 3>(ka, st);
-      case DD3D_TILE_128x64: return launch_x3<1, 1, 4, 2, 3>(ka, st);
-      case DD3D_TILE_64x128: return launch_x3<1, 1, 2, 4, 3>(ka, st);
-      case DD3D_TILE_256x128: return launch_x3<2, 2, 4, 2, 2>(ka, st);
+      // 8-wave blocks, one per CU
+      case DD3D_TILE_128x128: return launch_x3<2, 1, 2, 4, 2, 3>(ka, st);
+      case DD3D_TILE_128x64: return launch_x3<1, 1, 4, 2, 2, 3>(ka, st);
+      case DD3D_TILE_64x128: return launch_x3<1, 1, 2, 4, 2, 3>(ka, st);
+      case DD3D_TILE_256x128: return launch_x3<2, 2, 4, 2, 2, 2>(ka, st);
+      // 4-wave blocks sized so that two (or more) share a CU and hide each other's barriers
+      case DD3D_TILE_128x128_W4: return launch_x3<2, 2, 2, 2, 1, 2>(ka, st);  // 24 + 48 = 72 KiB
+      case DD3D_TILE_64x64_W4: return launch_x3<1, 1, 2, 2, 2, 3>(ka, st);    // 24 + 36 = 60 KiB
+      case DD3D_TILE_128x64_W4: return launch_x3<2, 1, 2, 2, 1, 3>(ka, st);   // 24 + 36 = 60 KiB
     }
     DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no split-bf16 kernel", L->tile_cfg);
   }
@@ -1013,7 +1022,7 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
     case DD3D_TILE_64x64: return launch_cfg<1, 1, 2, 2>(ka, smallc, st);
     case DD3D_TILE_128x32: return launch_cfg<1, 1, 4, 1>(ka, smallc, st);
     case DD3D_TILE_64x128: return launch_cfg<1, 2, 2, 2>(ka, smallc, st);
-    case DD3D_TILE_256x128: DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: the 256x128 tile exists for DD3D_MATH_BF16X3 only");
+    default: DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d exists for DD3D_MATH_BF16X3 only", L->tile_cfg);
   }
   return DD3D_E_INVALID;
 }

@@ -97,8 +97,13 @@ def split_bf16x3(wp):
     return planes.view(3, Npad, Kpad // 32, 32).permute(1, 2, 0, 3).contiguous()
 
 
-MATH_TILES = {hip.MATH_F32: ((128, 128), (128, 64), (64, 64), (128, 32), (64, 128)),
-              hip.MATH_BF16X3: ((256, 128), (128, 128), (128, 64), (64, 128))}  # tiles the split-bf16 kernel is instantiated for
+MATH_TILES = {  # tile configurations instantiated per arithmetic mode
+    hip.MATH_F32: (hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x64, hip.TILE_128x32, hip.TILE_64x128),
+    hip.MATH_BF16X3: (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4,
+                      hip.TILE_128x64_W4),
+}
+# blocks of a configuration that can share a CU (LDS-limited); the f32 kernels were measured, see profiles/
+BLOCKS_PER_CU = {hip.TILE_128x128_W4: 2, hip.TILE_64x64_W4: 2, hip.TILE_128x64_W4: 2}  # tiles the split-bf16 kernel is instantiated for
 
 
 MATH_NAMES = {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3}
@@ -115,16 +120,16 @@ def tile_key(m_list, N, Kpad, stride):
     return f"{'+'.join(str(m) for m in m_list)},{N},{Kpad},{stride}"
 
 
-def _load_tile_table():
+def _load_tile_table(math_name):
     """Measured exceptions to the analytic model below: {tile_key: [tile, splitk, best_us, model_us]}, produced on an MI355X by
-    tests/gpu_tile_explore.py (every candidate timed; entries kept only where the best beats the model's pick by > 3 %)."""
+    tests/gpu_tile_explore.py (every candidate timed; entries kept only where the best beats the model's pick by > 5 %)."""
     import json
     import os
-    path = os.path.join(os.path.dirname(__file__), "data", "tile_table.json")
+    path = os.path.join(os.path.dirname(__file__), "data", f"tile_table_{math_name}.json")
     return json.load(open(path)) if os.path.exists(path) else {}
 
 
-TILE_TABLE = _load_tile_table()
+TILE_TABLE = {hip.MATH_F32: _load_tile_table("f32"), hip.MATH_BF16X3: _load_tile_table("bf16x3")}
 
 
 def choose_tiling(m_list, N, Kpad, stride=1, math=0):
@@ -132,15 +137,13 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
     on 256 CUs: every block costs BM*BN*K MACs on its CU's matrix pipe (partial tiles cost the same as full ones); split-K
     adds the partial-sum exchange."""
     allowed = MATH_TILES[math]
-    hit = TILE_TABLE.get(tile_key(m_list, N, Kpad, stride)) if math == hip.MATH_F32 else None
+    hit = TILE_TABLE[math].get(tile_key(m_list, N, Kpad, stride))
     if hit is not None:
-        bm, bn = (int(v) for v in hit[0].split("x"))
-        return next(c for c, shp in hip.TILE_SHAPES.items() if shp == (bm, bn)), int(hit[1])
+        return next(c for c, nm in hip.TILE_NAMES.items() if nm == hit[0]), int(hit[1])
     nk = Kpad // 32
     best = None
-    for cfg, (bm, bn) in hip.TILE_SHAPES.items():
-        if (bm, bn) not in allowed:
-            continue
+    for cfg in allowed:
+        bm, bn = hip.TILE_SHAPES[cfg]
         if bn == 32 and N > 32:
             continue
         if bn > 32 and N <= 32:
@@ -158,7 +161,8 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
             if math == hip.MATH_F32:
                 cost /= {(128, 128): 1.0, (128, 64): 0.80, (64, 128): 0.80, (64, 64): 0.63, (128, 32): 0.40}[(bm, bn)]
             else:  # split-bf16 kernel: ~2x the f32 rate on the big tiles, LDS-read bound on the small ones
-                cost /= {(256, 128): 2.4, (128, 128): 1.8, (128, 64): 1.3, (64, 128): 1.3}[(bm, bn)]
+                cost /= {hip.TILE_256x128: 2.4, hip.TILE_128x128: 1.8, hip.TILE_128x64: 1.3, hip.TILE_64x128: 1.3,
+                         hip.TILE_128x128_W4: 1.0, hip.TILE_64x64_W4: 0.6, hip.TILE_128x64_W4: 0.8}[cfg]  # W4: to be measured
             if sk > 1:
                 # second launch (~2 us) + partial-sum round trip (sk*M*N*8 B at ~3 TB/s), in per-CU MAC units
                 # (one CU retires 157.3e12 / 2 / 256 = 3.07e11 MAC/s)
@@ -181,8 +185,8 @@ class ConvOp:
         self.math = math
         cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math)
         if tile is not None:
-            if hip.TILE_SHAPES[tile] not in MATH_TILES[math]:
-                raise ValueError(f"conv {name}: tile {hip.TILE_SHAPES[tile]} is not instantiated for math mode {math}")
+            if tile not in MATH_TILES[math]:
+                raise ValueError(f"conv {name}: tile {hip.TILE_NAMES[tile]} is not instantiated for math mode {math}")
             cfg = tile
         if splitk is not None:
             sk = splitk
@@ -235,7 +239,7 @@ class ConvOp:
         L.seg0_host = self.segs_host.ctypes.data if len(segs) == 1 else None
         self.L = L
         self.macs = sum(m_list) * meta["N"] * meta["KH"] * meta["KW"] * meta["Cin"]
-        self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), splitk=sk, math=math,
+        self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), tile_name=hip.TILE_NAMES[cfg], splitk=sk, math=math,
                          blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs))
 
     def __call__(self, lib, stream):

@@ -58,7 +58,7 @@ def main():
     torch.cuda.synchronize()
     seen = {}
     table = {}
-    engine.TILE_TABLE = {}  # measure against the analytic model
+    engine.TILE_TABLE = {hip.MATH_F32: {}, hip.MATH_BF16X3: {}}  # measure against the analytic model
     for name, pl, meta, stride, pad, segs, relu in RECORD:
         m_list = tuple(s["out"].B * s["out"].H * s["out"].W for s in segs)
         key = (m_list, meta["N"], meta["Kpad"], meta["Cin"], stride)
@@ -69,38 +69,37 @@ def main():
         math = pl.math if (meta["Cin"] % 32 == 0 and meta["N"] > 32) else hip.MATH_F32
         cur_cfg, cur_sk = engine.choose_tiling(list(m_list), meta["N"], meta["Kpad"], stride, math)
         res = []
-        for cfg_id, (bm, bn) in hip.TILE_SHAPES.items():
-            if (bm, bn) not in engine.MATH_TILES[math]:
-                continue
+        for cfg_id in engine.MATH_TILES[math]:
+            bm, bn = hip.TILE_SHAPES[cfg_id]
             if (bn == 32) != (meta["N"] <= 32):
                 continue
             if bn == 128 and meta["N"] <= 64:
                 continue
             blocks = sum(-(-m // bm) for m in m_list) * -(-meta["N"] // bn)
             for sk in (1, 2, 3, 4, 6, 8, 12, 16):
-                if sk > 1 and (nk // sk < 3 or blocks * sk > 1200):
+                if sk > 1 and (nk // sk < 3 or blocks * sk > 1300):
                     continue
-                if sk == 1 and blocks > 6000 and (bm, bn) != hip.TILE_SHAPES[cur_cfg]:
+                if sk == 1 and blocks > 6000 and cfg_id != cur_cfg:
                     continue
                 try:
                     op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name, math=math)
                     us = time_op(pl, op)
                 except Exception as e:  # noqa: BLE001
                     us = float("nan")
-                res.append((us, bm, bn, sk, blocks * sk))
+                res.append((us, hip.TILE_NAMES[cfg_id], cfg_id, sk, blocks * sk))
         res.sort()
-        cur = [r for r in res if (r[1], r[2]) == hip.TILE_SHAPES[cur_cfg] and r[3] == cur_sk]
+        cur = [r for r in res if r[2] == cur_cfg and r[3] == cur_sk]
         cur_us = cur[0][0] if cur else float("nan")
         best = res[0]
         if cur_us > 1.03 * best[0]:  # only keep entries that beat the model by more than the measurement noise
-            table[engine.tile_key(m_list, meta["N"], meta["Kpad"], stride)] = [f"{best[1]}x{best[2]}", best[3], round(best[0], 1), round(cur_us, 1)]
-        print(f"{name:26s} M={sum(m_list):7d} N={meta['N']:4d} K={meta['Kpad']:5d} s{stride} model=({hip.TILE_SHAPES[cur_cfg][0]}x{hip.TILE_SHAPES[cur_cfg][1]},sk{cur_sk}) {cur_us:7.2f}us "
-              f"best=({best[1]}x{best[2]},sk{best[3]},{best[4]}blk) {best[0]:7.2f}us gain {cur_us - best[0]:6.2f} | "
-              + " ".join(f"{r[1]}x{r[2]}/{r[3]}:{r[0]:.1f}" for r in res[:6]), flush=True)
+            table[engine.tile_key(m_list, meta["N"], meta["Kpad"], stride)] = [best[1], best[3], round(best[0], 1), round(cur_us, 1)]
+        print(f"{name:26s} M={sum(m_list):7d} N={meta['N']:4d} K={meta['Kpad']:5d} s{stride} model=({hip.TILE_NAMES[cur_cfg]},sk{cur_sk}) {cur_us:7.2f}us "
+              f"best=({best[1]},sk{best[3]},{best[4]}blk) {best[0]:7.2f}us gain {cur_us - best[0]:6.2f} | "
+              + " ".join(f"{r[1]}/{r[3]}:{r[0]:.1f}" for r in res[:7]), flush=True)
 
 
     import json
-    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}_{os.environ.get('DD3D_MATH', 'f32')}.json")
+    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}_{'bf16x3' if plan.math == hip.MATH_BF16X3 else 'f32'}.json")
     os.makedirs("gpurun_out", exist_ok=True)
     with open(out, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)

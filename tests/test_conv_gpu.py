@@ -39,6 +39,12 @@ X3_CASES = [  # split-bf16 arithmetic (DD3D_MATH_BF16X3): same f32-level toleran
     ("x3_256x128", 1, 33, 41, 256, 256, 3, 1, 1, True, True, hip.TILE_256x128, 1),
     ("x3_256x128_sk3_s2", 1, 30, 44, 128, 192, 3, 2, 1, False, False, hip.TILE_256x128, 3),
     ("x3_256x128_k32", 1, 24, 40, 32, 128, 1, 1, 0, False, False, hip.TILE_256x128, 1),
+    ("x3_128x128w4", 2, 17, 23, 256, 256, 3, 1, 1, True, True, hip.TILE_128x128_W4, 1),
+    ("x3_128x128w4_sk3_s2", 1, 30, 44, 128, 192, 3, 2, 1, False, False, hip.TILE_128x128_W4, 3),
+    ("x3_64x64w4", 1, 24, 40, 256, 256, 3, 1, 1, True, False, hip.TILE_64x64_W4, 1),
+    ("x3_64x64w4_sk2_k32", 1, 24, 40, 64, 64, 1, 1, 0, False, True, hip.TILE_64x64_W4, 2),
+    ("x3_128x64w4", 1, 13, 21, 256, 256, 3, 2, 1, False, False, hip.TILE_128x64_W4, 1),
+    ("x3_128x64w4_sk4", 1, 24, 40, 256, 128, 3, 1, 1, True, True, hip.TILE_128x64_W4, 4),
 ]
 
 
