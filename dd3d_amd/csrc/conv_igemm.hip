@@ -153,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-    if (n >= a.N) continue;
+    if (n >= (s.n_limit > 0 ? s.n_limit : a.N)) continue;
     const float sc = as_g(s.scale)[n], bi = as_g(s.bias)[n];
     float lo = s.lo ? as_g(s.lo)[n] : -INFINITY;
     if (a.relu) lo = fmaxf(lo, 0.f);

@@ -193,12 +193,11 @@ class ConvOp:
         bm, bn = hip.TILE_SHAPES[cfg]
         arr = np.zeros(len(segs), dtype=hip.CONV_SEG_DTYPE)
         tiles = []
-        ws_rows = 0
         self.keep = []
         for i, s in enumerate(segs):
             vin, vout = s["in"], s["out"]
             assert vin.C == meta["Cin"], (name, vin.C, meta["Cin"])
-            assert vout.C >= meta["N"], (name, vout.C, meta["N"])
+            assert vout.C >= (s.get("n_limit") or meta["N"]), (name, vout.C, meta["N"])
             Ho = (vin.H + 2 * pad - meta["KH"]) // stride + 1
             Wo = (vin.W + 2 * pad - meta["KW"]) // stride + 1
             assert (Ho, Wo) == (vout.H, vout.W) and vin.B == vout.B, (name, Ho, Wo, vout.H, vout.W)
@@ -214,8 +213,8 @@ class ConvOp:
             if res is not None:
                 assert (res.B, res.H, res.W) == (vout.B, vout.H, vout.W) and res.C >= meta["N"]
                 a["res"], a["res_pitch"], a["res_mode"] = res.ptr, res.pitch, 1
-            a["ws_row0"] = ws_rows
-            ws_rows += m_list[i]
+            a["n_limit"] = int(s.get("n_limit", 0))
+            assert a["n_limit"] <= meta["N"]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
             self.keep += [w, s["scale"], s["bias"], s.get("lo")]
         self.segs_host = arr  # kept alive: single-segment launches hand the descriptor over by value (seg0_host)
@@ -238,7 +237,8 @@ class ConvOp:
         L.zero_page = plan.zero_page.data_ptr()
         L.seg0_host = self.segs_host.ctypes.data if len(segs) == 1 else None
         self.L = L
-        self.macs = sum(m_list) * meta["N"] * meta["KH"] * meta["KW"] * meta["Cin"]
+        # algorithmic MACs: every segment counts the channels it stores
+        self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs)) * meta["KH"] * meta["KW"] * meta["Cin"]
         self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), tile_name=hip.TILE_NAMES[cfg], splitk=sk, math=math,
                          blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs))
 
@@ -608,6 +608,8 @@ class ForwardPlan(PlanBase):
 
         C_ = model.num_classes
 
+        pred_groups = []  # every predictor group becomes a set of segments of ONE launch (see the end of this method)
+
         def fused_predictor(name, convs, tower_idx, level_scale, level_bias_extra, lo):
             """convs: list of (module per level-or-shared) concatenated along N.  level_scale(l) -> per-channel scale vector."""
             ws, metas = {}, None
@@ -631,9 +633,9 @@ class ForwardPlan(PlanBase):
                 maps.append(out)
                 segs.append({
                     "in": cur[l][tower_idx], "out": out.view(0, pitch), "w": w, "scale": self._vec(sc), "bias": self._vec(bias),
-                    "lo": None if lo is None else self._vec(lo)
+                    "lo": None if lo is None else self._vec(lo), "n_limit": n_total
                 })
-            self.ops.append(ConvOp(self, metas, 1, 1, segs, relu=False, name=name))
+            pred_groups.append((name, metas, segs))
             return maps, pitch
 
         ones = lambda n: torch.ones(n)
@@ -682,6 +684,24 @@ class ForwardPlan(PlanBase):
 
             preds = [list(h3.box3d_quat), list(h3.box3d_ctr), list(h3.box3d_depth), list(h3.box3d_size), list(h3.box3d_conf)]
             self.b3d_maps, self.b3d_pitch = fused_predictor("box3d_map", preds, 2, s3, b3, None)
+
+        # One launch for all predictors of all levels: the narrow ones (C or 5 channels) ride along with the widest (11*C) as
+        # extra segments, their filters zero-padded to its Npad and their stores cut at n_limit -- three launches of 25 us
+        # each become one of about the cost of the widest.
+        n_max = max(m["N"] for _, m, _ in pred_groups)
+        npad = (n_max + 31) // 32 * 32
+        meta = dict(pred_groups[0][1], N=n_max, Npad=npad)
+        padded, all_segs = {}, []
+        for _, m, segs in pred_groups:
+            assert (m["Cin"], m["KH"], m["KW"], m["Kpad"]) == (meta["Cin"], meta["KH"], meta["KW"], meta["Kpad"])
+            for sg in segs:
+                key = sg["w"].data_ptr()
+                if key not in padded:
+                    wpad = torch.zeros((npad, m["Kpad"]), dtype=torch.float32, device=dev)
+                    wpad[:sg["w"].shape[0]] = sg["w"]
+                    padded[key] = wpad
+                all_segs.append(dict(sg, w=padded[key]))
+        self.ops.append(ConvOp(self, meta, 1, 1, all_segs, relu=False, name="predictors"))
 
     # ------------------------------------------------------------------ selection / decode / NMS
     def _postprocess(self, model, world_size, rank=0):

@@ -28,7 +28,7 @@ TILE_NAMES = {TILE_128x128: "128x128", TILE_128x64: "128x64", TILE_64x64: "64x64
 CONV_SEG_DTYPE = np.dtype(
     [("in_", "<u8"), ("w", "<u8"), ("scale", "<u8"), ("bias", "<u8"), ("lo", "<u8"), ("res", "<u8"), ("out", "<u8"),
      ("B", "<i4"), ("H", "<i4"), ("W", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"), ("in_pitch", "<i4"), ("out_pitch", "<i4"),
-     ("res_pitch", "<i4"), ("M", "<i4"), ("res_mode", "<i4"), ("reserved0", "<i4", (2, )), ("ws_row0", "<i4"),
+     ("res_pitch", "<i4"), ("M", "<i4"), ("res_mode", "<i4"), ("reserved0", "<i4", (2, )), ("n_limit", "<i4"),
      ("reserved", "<i4", (3, ))]
 )
 assert CONV_SEG_DTYPE.itemsize == 120

@@ -73,7 +73,7 @@ typedef struct dd3d_conv_seg {  /* array lives in DEVICE memory */
   int32_t M;           /* B*Ho*Wo                                                                */
   int32_t res_mode;    /* 0 none, 1 add res[m, n] (same pixel) before the clamp                  */
   int32_t reserved0[2];
-  int32_t ws_row0;     /* unused (split-K slabs are indexed by tile)                              */
+  int32_t n_limit;     /* > 0: this segment stores only output channels < n_limit (<= launch N); 0: all N  */
   int32_t reserved[3];
 } dd3d_conv_seg;
 
