@@ -44,6 +44,16 @@ class ConvLaunch(C.Structure):
     ]
 
 
+class SmallcArgs(C.Structure):
+    """`dd3d_smallc_args`."""
+    _fields_ = [
+        ("in_", C.c_void_p), ("out", C.c_void_p), ("w3", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("lo", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("in_pitch", C.c_int32),
+        ("out_pitch", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("N", C.c_int32), ("relu", C.c_int32)
+    ]
+
+
 class SelectArgs(C.Structure):
     """`dd3d_select_args`."""
     _fields_ = [
@@ -85,7 +95,7 @@ class BevArgs(C.Structure):
 EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
-    "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate"
+    "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3"
 ]
 
 
@@ -125,6 +135,8 @@ def lib():
     L.dd3d_invert_intrinsics.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.dd3d_nms_finalize.argtypes = [C.POINTER(NmsArgs), C.c_void_p]
     L.dd3d_bev_nms_aggregate.argtypes = [C.POINTER(BevArgs), C.c_void_p]
+    L.dd3d_conv2d_smallc_supported.argtypes = [C.c_int32] * 6
+    L.dd3d_conv2d_smallc_bf16x3.argtypes = [C.POINTER(SmallcArgs), C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the .so is stale
     assert L.dd3d_abi_version() == 1, "libdd3d_hip.so ABI version mismatch; rebuild"

@@ -120,6 +120,35 @@ int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
 int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Small-channel convolution (the full-resolution stem: dla.py:271-280,327-344 base_layer / level0 / level1,
+ * vovnet.py stem_1), DD3D_MATH_BF16X3 arithmetic, + per-channel scale/bias (+ lower clamp / ReLU).
+ * The block stages the input patch of its output tile once (f32 -> bf16 hi/mid/lo planes) and feeds
+ * v_mfma_f32_16x16x32_bf16 straight from it; no im2col K loop.
+ *   in  f32 NHWC [B][H][W] rows of in_pitch floats, channels [0, Cin) used, Cin in {4, 16}
+ *   w3  bf16 [chunk][plane][Npad16][32]: 32-k chunks of the k order
+ *         Cin 4 : k = (dh*8 + dw)*4 + c      (one chunk per filter row, tap slots >= KW zero)
+ *         Cin 16: k = (dh*KW + dw)*16 + c    (two taps per chunk, an odd tap count zero-padded)
+ *       planes hi / mid / lo of the exact 3-way bf16 split, Npad16 = round_up(N, 16)
+ *   out f32 NHWC rows of out_pitch floats, channels [0, N)
+ * Instantiated: (Cin 4, 7x7, s1, p3, N<=16) (Cin 16, 3x3, s1, p1, N<=16) (Cin 16, 3x3, s2, p1, N<=32) (Cin 4, 3x3, s2, p1, N<=64);
+ * dd3d_conv2d_smallc_supported() tells.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dd3d_smallc_args {  /* host memory */
+  const float* in;
+  float* out;
+  const void* w3;
+  const float* scale;
+  const float* bias;
+  const float* lo; /* optional per-channel lower clamp */
+  int32_t B, H, W, Ho, Wo;
+  int32_t in_pitch, out_pitch;
+  int32_t Cin, KH, KW, stride, pad, N;
+  int32_t relu;
+} dd3d_smallc_args;
+int dd3d_conv2d_smallc_supported(int32_t Cin, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t N);
+int dd3d_conv2d_smallc_bf16x3(const dd3d_smallc_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Pre-processing.  Replaces DD3D.preprocess_image + ImageList.from_tensors
  * (tridet/modeling/dd3d/core.py:61-72, tridet/structures/image_list.py:120-142):
  * (u8 - mean)/std per channel inside the (h_i, w_i) image, 0.0 in the right/bottom padding.

@@ -206,3 +206,33 @@ def test_split_bf16_is_f32_accurate(hiplib):
     print("max |err| / max |ref|: f32 MFMA %.2e, split bf16 %.2e" % (err[hip.MATH_F32], err[hip.MATH_BF16X3]))
     assert err[hip.MATH_F32] < 2e-6 and err[hip.MATH_BF16X3] < 2e-6
     assert err[hip.MATH_BF16X3] < 3 * err[hip.MATH_F32] + 2e-7
+
+
+@pytest.mark.parametrize("case", [
+    ("base7x7_c3", 2, 43, 75, 3, 16, 7, 1, 3), ("level0_c16", 1, 40, 72, 16, 16, 3, 1, 1), ("level1_c16_s2", 1, 41, 73, 16, 32, 3, 2, 1),
+    ("v99_stem1_c3_s2", 1, 40, 72, 3, 64, 3, 2, 1), ("base7x7_big", 1, 96, 200, 3, 16, 7, 1, 3)
+], ids=lambda c: c[0])
+def test_smallc_patch_conv_matches_torch(hiplib, case):
+    """The stem kernel (input patch in LDS, split-bf16 MFMA 16x16x32, no im2col loop) vs F.conv2d, odd sizes included."""
+    from dd3d_amd.engine import PlanBase, SmallcConvOp
+    name, B, H, W, Cin, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(len(name))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k)**0.5
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = F.relu(F.conv2d(x, w, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    Ho, Wo = ref.shape[-2:]
+    plan = PlanBase("cuda")
+    cin_p = 4 if Cin <= 4 else 16
+    assert plan.lib.dd3d_conv2d_smallc_supported(cin_p, k, k, stride, pad, Cout)
+    xin = plan.buf("x", B, H, W, cin_p)
+    xin.t[..., :Cin] = x.permute(0, 2, 3, 1).to(plan.device)
+    yout = plan.buf("y", B, Ho, Wo, Cout + 4)
+    yout.t.fill_(-777.0)
+    op = SmallcConvOp(plan, w, cin_p, stride, pad, xin.view(), yout.view(0, Cout), scale.to(plan.device), bias.to(plan.device), True, name)
+    op(plan.lib, hip.current_stream())
+    torch.cuda.synchronize()
+    got = yout.t[..., :Cout].permute(0, 3, 1, 2).cpu()
+    err = float((got - ref).abs().max())
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (name, err)
+    assert torch.all(yout.t[..., Cout:] == -777.0)
