@@ -623,10 +623,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
   constexpr int A_STAGE = 3 * PLA, B_STAGE = 3 * PLB;
   constexpr int NPIECE = B_STAGE / 1024;    // 1-KiB DMA pieces per B stage
   constexpr int PB = (NPIECE + NW - 1) / NW;  // pieces per wave (the surplus re-fetches an existing piece)
-  // A(kt+1) and B(kt+1) must have landed when step kt stores A(kt+1).  Issue order is ... A(x) B(x) A(x+1) B(x+1) ... with
-  // a 3-stage B ring (B(kt+3) refills the stage step kt consumed) and ... A(x+1) B(x) A(x+2) B(x+1) ... with 2 stages
-  // (B(kt+2) refills it), so the in-order wait leaves one step's worth in flight, or nothing.
-  constexpr int WAIT_A = NSB == 3 ? AP + PB : 0;
+  // VMEM issue order: A0 B0 A1 B1 A2 [B2] | then per step kt: A(kt+3) before the barrier, B(kt+NSB) after it.  Returns are in
+  // order, so "A(kt+1) has landed" (needed at the START of step kt, where its split is interleaved with the MFMAs) is
+  // vmcnt <= AP + 2*PB, and "B(kt+1) has landed" (needed before the barrier that ends step kt) is vmcnt <= WAIT_B.
+  constexpr int WAIT_A = AP + 2 * PB;
+  constexpr int WAIT_B = NSB == 3 ? 2 * AP + PB : AP;
   static_assert((NW == 8 || NW == 4) && AP >= 1 && (NSB == 2 || NSB == 3) && (NSA == 1 || NSA == 2), "block shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);  // [A stage 0 .. NSA-1 | B stage 0 .. NSB-1]
@@ -730,9 +731,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
       if (++ld_tap == a.T) ld_tap = 0, ++ld_chunk;
     }
   };
-  auto wait_a = [&](auto set_c) {
+  auto wait_a = [&](auto set_c, auto cnt_c) {
     constexpr int set = decltype(set_c)::value;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_A) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(cnt_c)::value) : "memory");
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
       f32x4& r = ra[set][p];
@@ -745,29 +746,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(g_w3 + b_src[q] + (long)kt * 192),
                                        (ldsbp)(lds + NSA * A_STAGE + stage * B_STAGE + b_dst[q]), 16, 0, 0);
   };
-  // split four f32 into the three bf16 planes (exact, by truncation) and store them
-  auto split_store = [&](auto set_c, int stage) {
+  // split four f32 (piece p of register set `set`) into the three bf16 planes (exact, by truncation) and store them
+  auto split_store_piece = [&](auto set_c, int p, int stage) {
     constexpr int set = decltype(set_c)::value;
-    wait_a(set_c);
-    unsigned char* As = lds + stage * A_STAGE + a_st0;
+    unsigned char* As = lds + stage * A_STAGE + a_st0 + p * (NTHR * 8);
+    unsigned h[4], m[4], l[4];
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      unsigned h[4], m[4], l[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = ra[set][p][e];
-        h[e] = __float_as_uint(x) & 0xffff0000u;
-        const float r = x - __uint_as_float(h[e]);
-        m[e] = __float_as_uint(r) & 0xffff0000u;
-        l[e] = __float_as_uint(r - __uint_as_float(m[e]));
-      }
-      const u32x2 hv = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
-      const u32x2 mv = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
-      const u32x2 lv = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
-      *reinterpret_cast<u32x2*>(As + p * (NTHR * 8)) = hv;
-      *reinterpret_cast<u32x2*>(As + PLA + p * (NTHR * 8)) = mv;
-      *reinterpret_cast<u32x2*>(As + 2 * PLA + p * (NTHR * 8)) = lv;
+    for (int e = 0; e < 4; ++e) {
+      const float x = ra[set][p][e];
+      h[e] = __float_as_uint(x) & 0xffff0000u;
+      const float r = x - __uint_as_float(h[e]);
+      m[e] = __float_as_uint(r) & 0xffff0000u;
+      l[e] = __float_as_uint(r - __uint_as_float(m[e]));
     }
+    *reinterpret_cast<u32x2*>(As) = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+    *reinterpret_cast<u32x2*>(As + PLA) = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+    *reinterpret_cast<u32x2*>(As + 2 * PLA) = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+  };
+  auto split_store = [&](auto set_c, int stage) {
+    wait_a(set_c, std::integral_constant<int, WAIT_A>{});
+#pragma unroll
+    for (int p = 0; p < AP; ++p) split_store_piece(set_c, p, stage);
   };
   auto lds_barrier = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -788,7 +787,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
   const int swz = (lrow >> 2) & 3;
   const int frag_off[2] = {lrow * 64 + (((0 + kh) ^ swz) << 4), lrow * 64 + (((2 + kh) ^ swz) << 4)};  // k-chunk 0 / 1
 
-  auto compute_tile = [&](int sa, int sb) {
+  // MFMAs of the tile in (A stage sa, B stage sb).  With two A stages the split + store of the NEXT tile's A pieces (register
+  // set `set`, into A stage `next`) is spread between the MFMA groups, so the VALU work issues in the matrix pipe's shadow
+  // instead of after it (both waves of a SIMD leave the barrier together: doing all MFMAs, then all VALU, idles the pipe).
+  auto compute_tile = [&](int sa, int sb, auto set_c, int next) {
     const unsigned char* As = lds + sa * A_STAGE + wm * TM * 32 * 64;
     const unsigned char* Bs = lds + NSA * A_STAGE + sb * B_STAGE + wn * TN * 32 * 64;
     bf16x8 af[2][TM][3], bf[2][TN][3];  // fragments of both k-chunks: the reads of chunk 1 fly under the MFMAs of chunk 0
@@ -806,15 +808,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
     // smallest terms first; the (i, j) loops are innermost so consecutive MFMAs hit different accumulators
     constexpr int PA_[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB_[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int GSTRIDE = 12 / AP > 0 ? 12 / AP : 1;
+    static_assert(AP <= 12, "one A piece per MFMA group at most");
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < 6; ++t) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i][PA_[t]], bf[c][j][PB_[t]], acc[i][j], 0, 0, 0);
+        if constexpr (NSA == 2) {
+          const int grp = c * 6 + t;
+          if (grp % GSTRIDE == 0 && grp / GSTRIDE < AP) split_store_piece(set_c, grp / GSTRIDE, next);
+        }
+      }
   };
 
   if (kt_begin < kt_end) {
@@ -825,31 +834,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
     issue_b(kt_begin, 0);
     load_a(S1);
     issue_b(min(kt_begin + 1, kt_last), 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSB == 3 ? AP + PB : 0) : "memory");
-    split_store(S0, 0);
+    wait_a(S0, std::integral_constant<int, (NSB == 3 ? AP + PB : 0)>{});  // A(0), B(0) (2 stages: everything) landed
+#pragma unroll
+    for (int p = 0; p < AP; ++p) split_store_piece(S0, p, 0);
     load_a(S0);
     lds_barrier();
     if (NSB == 3) issue_b(min(kt_begin + 2, kt_last), 2);
     int sb = 0;
-    // Step kt: MFMAs of tile kt | [one A stage: barrier, everyone is done reading it] | split + store A(kt+1) | A(kt+3) -> the
-    // register set just stored | barrier | B refill of the ring stage just consumed.  Exactly AP + PB VMEM operations per
-    // step (indices clamped past the end).
+    // Step kt: [A(kt+1) landed] MFMAs of tile kt with the split + store of A(kt+1) in their shadow | A(kt+3) -> the register set
+    // just stored | [B(kt+1) landed] barrier | B refill of the ring stage just consumed.  (One A stage: MFMAs | barrier | split +
+    // store | ...)  Exactly AP + PB VMEM operations per step (indices clamped past the end).
+    auto step = [&](int kt_cur, int sa, auto set_c, int next) {
+      if constexpr (NSA == 2) {
+        wait_a(set_c, std::integral_constant<int, WAIT_A>{});
+        compute_tile(sa, sb, set_c, next);
+      } else {
+        compute_tile(sa, sb, set_c, next);
+        lds_barrier();
+        split_store(set_c, next);
+      }
+      load_a(set_c);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_B) : "memory");
+      lds_barrier();
+      issue_b(min(kt_cur + NSB, kt_last), sb);
+      sb = sb == NSB - 1 ? 0 : sb + 1;
+    };
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
-      compute_tile(0, sb);
-      if (NSA == 1) lds_barrier();
-      split_store(S1, NSA - 1);
-      load_a(S1);
-      lds_barrier();
-      issue_b(min(kt + NSB, kt_last), sb);
-      sb = sb == NSB - 1 ? 0 : sb + 1;
+      step(kt, 0, S1, NSA - 1);
       if (kt + 1 >= kt_end) break;
-      compute_tile(NSA - 1, sb);
-      if (NSA == 1) lds_barrier();
-      split_store(S0, 0);
-      load_a(S0);
-      lds_barrier();
-      issue_b(min(kt + 1 + NSB, kt_last), sb);
-      sb = sb == NSB - 1 ? 0 : sb + 1;
+      step(kt + 1, NSA - 1, S0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is released
   }

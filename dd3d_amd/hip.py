@@ -9,7 +9,8 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(__file__), "lib", "libdd3d_hip.so")
+# DD3D_HIP_LIB: alternate build of the same ABI (A/B measurements of two kernel versions on one box, tests/tools/ab_lib.sh)
+_LIB_PATH = os.environ.get("DD3D_HIP_LIB") or os.path.join(os.path.dirname(__file__), "lib", "libdd3d_hip.so")
 _lib = None
 
 MAX_LEVELS = 8
