@@ -43,8 +43,16 @@ def owner_of_image(g, B):
 def gather_candidates(pairs, group=None):
     """The step's only exchange: all_gather the local candidate buffer [B,F,NS], its per-level counts [B,L], the resize
     targets [B,4] into the rank-major global buffers [W*B, ...].  `pairs` = ForwardPlan.gather_pairs()."""
+    staged = dist.get_backend(group) == "gloo" and pairs[0][0].is_cuda
     for local, glob in pairs:
-        dist.all_gather_into_tensor(glob, local, group=group)
+        if staged:
+            # gloo has no device all_gather: test transport for driving the N > 1 GPU code path with several processes on ONE
+            # GPU (tests/gpu_dist_check.py); the product transport is RCCL ("nccl"), which takes the device tensors directly
+            g_cpu = torch.empty(glob.shape, dtype=glob.dtype)
+            dist.all_gather_into_tensor(g_cpu, local.cpu(), group=group)
+            glob.copy_(g_cpu)
+        else:
+            dist.all_gather_into_tensor(glob, local, group=group)
 
 
 class DistributedForward:

@@ -1,0 +1,16 @@
+"""N > 1 code path on the GPU: two processes share the one GPU of the test box; gloo (host-staged) carries the candidate gather,
+everything else -- the two captured hipGraph halves, NMS over all W*B images, rank-offset collect -- is the product path."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_on_one_gpu_match_single_rank(hiplib):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_dist_check.py"), "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "dist check: {" in r.stdout and "False" not in r.stdout.split("dist check:")[-1]
