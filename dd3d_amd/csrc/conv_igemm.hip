@@ -48,6 +48,7 @@ struct ConvKArgs {
   // Single-segment launches (every backbone / FPN conv) carry their descriptor in the kernel arguments: the block then
   // starts its first data loads without the tiles[] -> segs[] -> pointer chain of dependent scalar loads.
   int single, BMrows;
+  int in_relu;  // bf16x3 kernel: rectify the input while it is split (conv(relu(x)) without a rectified copy of x)
   dd3d_conv_seg seg0;
 };
 
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float x = ra[set][p][e];
+      const float x = a.in_relu ? fmaxf(ra[set][p][e], 0.f) : ra[set][p][e];
       h[e] = __float_as_uint(x) & 0xffff0000u;
       const float r = x - __uint_as_float(h[e]);
       m[e] = __float_as_uint(r) & 0xffff0000u;
@@ -1006,6 +1007,8 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.splitk = L->splitk;
   ka.zeros = L->zero_page;
   ka.tile_counters = L->tile_counters;
+  ka.in_relu = L->in_relu;
+  DD3D_REQUIRE(!L->in_relu || L->math_mode == DD3D_MATH_BF16X3, "dd3d_conv2d_igemm_f32: in_relu needs DD3D_MATH_BF16X3");
   ka.single = (L->nsegs == 1 && L->seg0_host != nullptr);
   ka.BMrows = bm;
   if (ka.single) ka.seg0 = *L->seg0_host;

@@ -215,7 +215,7 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
 
 class ConvOp:
     """One dd3d_conv2d_igemm_f32 launch (possibly many segments)."""
-    def __init__(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name="", math=None):
+    def __init__(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name="", math=None, in_relu=False):
         dev = plan.device
         self.name = name
         m_list = [s["out"].B * s["out"].H * s["out"].W for s in segs]
@@ -277,6 +277,8 @@ class ConvOp:
         L.relu, L.splitk, L.math_mode, L.tile_cfg = int(relu), sk, math, cfg
         L.zero_page = plan.zero_page.data_ptr()
         L.seg0_host = self.segs_host.ctypes.data if len(segs) == 1 else None
+        assert not in_relu or math == hip.MATH_BF16X3
+        L.in_relu = int(in_relu)
         self.L = L
         # algorithmic MACs: every segment counts the channels it stores
         self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs)) * meta["KH"] * meta["KW"] * meta["Cin"]
@@ -327,7 +329,7 @@ class PlanBase:
     def _vec(self, t):
         return t.detach().float().contiguous().to(self.device)
 
-    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name=""):
+    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name="", in_relu=False):
         """One Conv2d(+folded norm)(+residual)(+relu) as a single-segment launch."""
         scale, shift = fold_norm(conv, norm)
         N, Cin, KH, KW = conv.weight.shape
@@ -341,7 +343,7 @@ class PlanBase:
             return op
         w, meta = pack_filter(conv.weight, self.device)
         seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res}
-        op = ConvOp(self, meta, conv.stride, conv.padding, [seg], relu, name=name)
+        op = ConvOp(self, meta, conv.stride, conv.padding, [seg], relu, name=name, in_relu=in_relu)
         self.ops.append(op)
         return op
 
@@ -616,12 +618,14 @@ class ForwardPlan(PlanBase):
             self.conv_module(fpn.top_block.p6, x, p6, name="top_block.p6")
             results[f"p{st + 1}"] = p6
             if fpn.top_block.num_levels == 2:
-                # p7 = conv(relu(p6)): keep a rectified copy by running p6's conv twice is wasteful; instead the relu is
-                # applied by a second epilogue-only pass of the same conv into a scratch view.
-                p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C).view()
-                self.conv_module(fpn.top_block.p6, x, p6r, relu=True, name="top_block.p6.relu")
                 p7 = self.buf(f"p{st + 2}", p6.B, (p6.H + 1) // 2, (p6.W + 1) // 2, p6.C).view()
-                self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
+                if self.math == hip.MATH_BF16X3:
+                    # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the conv rectifies its input while splitting it
+                    self.conv_module(fpn.top_block.p7, p6, p7, name="top_block.p7", in_relu=True)
+                else:  # f32-MFMA mode: a rectified copy of p6 from a second run of its conv
+                    p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C).view()
+                    self.conv_module(fpn.top_block.p6, x, p6r, relu=True, name="top_block.p6.relu")
+                    self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
                 results[f"p{st + 2}"] = p7
         return [results[n] for n in fpn._out_features]
 

@@ -95,6 +95,8 @@ typedef struct dd3d_conv_launch {  /* host memory */
                              inside the same launch; the counters are zero again when the launch has completed. */
   const dd3d_conv_seg* seg0_host; /* HOST copy of segs[0], or NULL.  With nsegs == 1 the descriptor then travels in the kernel
                                      arguments (tiles are taken as m0 = i * BM) and the device copies are not read. */
+  int32_t in_relu; /* 1: the input is rectified on the fly, out = epilogue(conv(max(in, 0))) -- LastLevelP6P7: p7 = conv(relu(p6)).
+                      DD3D_MATH_BF16X3 only */
 } dd3d_conv_launch;
 
 /* Arithmetic of the implicit GEMM (results agree to f32 rounding level; both accumulate in f32):
