@@ -137,3 +137,54 @@ def test_config_surface():
     n = get_cfg("dd3d_nusc_v99")
     assert n.DD3D.NUM_CLASSES == 10 and n.DD3D.NUSC.INFERENCE.NUM_IMAGES_PER_SAMPLE == 6
     assert n.MODEL.META_ARCHITECTURE == "NuscenesDD3D" and n.FE.BUILDER == "build_fcos_vovnet_fpn_backbone_p6"
+
+
+def test_split_bf16x3_is_exact_and_packs_planes():
+    """x == hi + mid + lo exactly (each term the next 8 significand bits), in the Wp3[n][k-tile][plane][32] layout the kernel reads."""
+    import torch
+    from dd3d_amd.engine import split_bf16x3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 96, generator=g) * torch.logspace(-6, 6, 96).view(1, -1)
+    x[0, 0], x[0, 1] = 0.0, -0.0
+    p = split_bf16x3(x)
+    assert p.shape == (64, 3, 3, 32) and p.dtype == torch.int16
+    planes = (p.permute(2, 0, 1, 3).reshape(3, 64, 96).to(torch.int32) << 16).view(torch.float32)
+    assert torch.equal(planes.sum(0), x)  # exact: the three bf16 terms carry all 24 significand bits
+    assert float((planes[0] - x).abs().max() / x.abs().max()) < 2**-7 and float(((planes[0] + planes[1]) - x).abs().max() / x.abs().max()) < 2**-15
+
+
+def test_smallc_filter_packing_orders():
+    """k orders of the stem kernel: Cin 4 -> one 32-k chunk per filter row with 8 tap slots; Cin 16 -> two taps per chunk."""
+    import torch
+    from dd3d_amd.engine import pack_smallc_bf16x3
+    w = torch.arange(16 * 3 * 7 * 7, dtype=torch.float32).reshape(16, 3, 7, 7) / 4096.0  # exactly representable in bf16 hi+mid
+    p = pack_smallc_bf16x3(w, 4)
+    assert p.shape == (7, 3, 16, 32)  # [chunk = dh][plane][n][dw*4 + c]
+    full = (p.to(torch.int32) << 16).view(torch.float32).sum(1)  # [dh][n][32]
+    for dh, dw, c, n in [(0, 0, 0, 0), (3, 6, 2, 15), (6, 2, 1, 7)]:
+        assert float(full[dh, n, dw * 4 + c]) == float(w[n, c, dh, dw])
+    assert float(full[:, :, 28:].abs().max()) == 0.0 and float(full[:, :, 3::4].abs().max()) == 0.0  # tap slot 7 and channel 3 are padding
+    w16 = torch.arange(32 * 16 * 9, dtype=torch.float32).reshape(32, 16, 3, 3) / 8192.0
+    p = pack_smallc_bf16x3(w16, 16)
+    assert p.shape == (5, 3, 32, 32)
+    full = (p.to(torch.int32) << 16).view(torch.float32).sum(1)
+    for t, c, n in [(0, 0, 0), (5, 9, 31), (8, 15, 3)]:
+        assert float(full[t // 2, n, (t % 2) * 16 + c]) == float(w16[n, c, t // 3, t % 3])
+    assert float(full[4, :, 16:].abs().max()) == 0.0  # the padded tenth tap
+
+
+def test_tile_table_and_math_modes():
+    from dd3d_amd import hip
+    from dd3d_amd.engine import MATH_TILES, TILE_TABLE, choose_tiling
+    for math, table in TILE_TABLE.items():
+        for key, (tile, sk, best, model) in table.items():
+            cfg = next(c for c, nm in hip.TILE_NAMES.items() if nm == tile)
+            assert cfg in MATH_TILES[math] and sk >= 1 and best <= model, (key, tile)
+    # measured entry is honoured; unknown shapes fall back to the model and stay inside the mode's tile set
+    m_list = [7680]
+    cfg, sk = choose_tiling(m_list, 128, 256, 1, hip.MATH_BF16X3)
+    assert cfg in MATH_TILES[hip.MATH_BF16X3]
+    cfg, sk = choose_tiling([12345], 256, 2304, 1, hip.MATH_BF16X3)
+    assert cfg in MATH_TILES[hip.MATH_BF16X3] and sk >= 1
+    cfg, sk = choose_tiling([12345], 256, 2304, 1, hip.MATH_F32)
+    assert cfg in MATH_TILES[hip.MATH_F32]
