@@ -297,6 +297,20 @@ class CallOp:
         self.fn(lib, stream)
 
 
+class OpList(list):
+    """Launch sequence; every appended op is tagged with the branch it runs on (0 = the main stream) and with the side branches
+    that must have finished before it starts (PlanBase.branch / PlanBase.join)."""
+    def __init__(self, plan):
+        super().__init__()
+        self.plan = plan
+
+    def append(self, op):
+        op.branch = self.plan._branch
+        op.joins = tuple(self.plan._pending_joins)
+        self.plan._pending_joins = []
+        super().append(op)
+
+
 # --------------------------------------------------------------------------------------------- the plan
 class PlanBase:
     """Buffer / workspace bookkeeping and op helpers shared by the full forward plan and the kernel unit tests."""
@@ -305,7 +319,14 @@ class PlanBase:
         self.device = torch.device(device)
         self.dry_run = dry_run  # plan construction only (host-logic tests on a GPU-less box); launching is refused
         assert dry_run or self.device.type == "cuda", "dd3d_amd runs on an MI355X HIP device only (no CPU fallback)"
-        self.ops = []
+        self._branch, self._pending_joins = 0, []
+        self._side_streams = {}
+        import os
+        # Side branches (see branch()) are OFF by default: measured A/B on one MI355X, DD3D-DLA34 B=1 graph replay 1.758 ms without
+        # vs 1.783 ms with them -- the cross-stream edges cost more than the overlap of the short residual / lateral / P6-P7
+        # chains returns (their neighbours already fill the CUs).  DD3D_BRANCHES=1 turns them on.
+        self.use_branches = os.environ.get("DD3D_BRANCHES", "0") == "1"
+        self.ops = OpList(self)
         self.bufs = {}
         self.graph = None
         self.world_size = 1
@@ -365,13 +386,54 @@ class PlanBase:
 
         self.ops.append(CallOp(_f, name))
 
+    # ------------------------------------------------------------------ side branches
+    def branch(self, b):
+        """with plan.branch(b): ops appended inside run on side stream b, concurrently with what the main stream does until
+        plan.join(b).  Used for short independent chains next to a long op (DLA: pool -> project beside the block's first conv;
+        FPN: the other laterals beside lateral5/output5, P6/P7 beside the top-down path).  Inside a captured hipGraph the
+        fork / join become graph edges."""
+        plan = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                self_inner.prev = plan._branch
+                plan._branch = b if plan.use_branches else 0
+
+            def __exit__(self_inner, *exc):
+                plan._branch = self_inner.prev
+
+        return _Ctx()
+
+    def join(self, b):
+        """The next op appended (on the main stream) waits for side branch b."""
+        if self.use_branches:
+            self._pending_joins.append(b)
+
     # ------------------------------------------------------------------ execution
     def launch(self, first=0, last=None):
         if self.dry_run:
             raise RuntimeError("dry-run plan: there is no CPU execution path")
+        main = torch.cuda.current_stream()
         st = hip.current_stream()
+        ahead = set()  # side branches holding work the main stream has not waited for yet
         for op in self.ops[first:last]:
-            op(self.lib, st)
+            for j in op.joins:
+                if j in ahead:
+                    main.wait_stream(self._side_streams[j])
+                    ahead.discard(j)
+            if op.branch == 0:
+                op(self.lib, st)
+                continue
+            side = self._side_streams.get(op.branch)
+            if side is None:
+                side = self._side_streams[op.branch] = torch.cuda.Stream(device=self.device)
+            if op.branch not in ahead:
+                side.wait_stream(main)
+                ahead.add(op.branch)
+            with torch.cuda.stream(side):
+                op(self.lib, hip.current_stream())
+        for j in ahead:
+            main.wait_stream(self._side_streams[j])
 
     def capture(self):
         """Capture the whole launch sequence into one hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture)."""
@@ -439,6 +501,8 @@ class ForwardPlan(PlanBase):
             feats = self._vovnet(bb.bottom_up, img.view())
         self.bottom_up = feats
         self.features = self._fpn(bb, feats)  # list of views, finest first
+        if self.fpn_tail_join is not None:
+            self.join(self.fpn_tail_join)  # P6 / P7 (side branch) feed the towers
         self.strides = [s.stride for s in model.backbone_output_shape]
 
         # ---- heads + post-processing
@@ -446,13 +510,16 @@ class ForwardPlan(PlanBase):
         self._postprocess(model, world_size, rank)
 
     # ------------------------------------------------------------------ DLA-34 (dla.py:170-355)
-    def _block(self, m, x, residual, out, name):
-        """BasicBlock (dla.py:50-62): conv1+norm+relu, conv2+norm (+residual) relu."""
+    def _block(self, m, x, residual, out, name, join=None):
+        """BasicBlock (dla.py:50-62): conv1+norm+relu, conv2+norm (+residual) relu.  `join`: side branch that produces the
+        residual; it runs beside conv1."""
         mid = self.buf(name + ".mid", out.B, out.H, out.W, m.conv1.out_channels)
         self.conv_module(m.conv1, x, mid.view(), relu=True, name=name + ".conv1")
+        if join is not None:
+            self.join(join)
         self.conv_module(m.conv2, mid.view(), out, relu=True, res=residual, name=name + ".conv2")
 
-    def _tree(self, m, x, name, dst=None, cat=None, bottom=None):
+    def _tree(self, m, x, name, dst=None, cat=None, bottom=None, bottom_branch=None):
         """Tree.forward (dla.py:233-247) with the root's torch.cat realised by channel placement: the root reads
         one NHWC buffer [x2 | x1 | children...] whose slices are written in place by their producers."""
         B = x.B
@@ -464,22 +531,31 @@ class ForwardPlan(PlanBase):
                 if m.level_root:
                     bottom = cat.view(2 * oc, ic)
                     if m.stride > 1:
-                        self.maxpool(x, bottom, name + ".pool")
+                        with self.branch(1):
+                            self.maxpool(x, bottom, name + ".pool")
+                        bottom_branch = 1
                     else:
                         raise NotImplementedError("level_root without downsample does not occur in DLA-34")
+            # downsample / project (the residual path) only meet the main path at tree1.conv2 (and at the root, later): they run
+            # on side branch 1, beside tree1.conv1
+            side = bottom_branch
             if bottom is None:
                 if m.stride > 1:
                     bottom = self.buf(name + ".bottom", B, Ho, Wo, ic).view()
-                    self.maxpool(x, bottom, name + ".pool")
+                    with self.branch(1):
+                        self.maxpool(x, bottom, name + ".pool")
+                    side = 1
                 else:
                     bottom = x
             if m.project is not None:
                 residual = self.buf(name + ".proj", B, Ho, Wo, oc).view()
-                self.conv_module(m.project, bottom, residual, name=name + ".project")
+                with self.branch(1):
+                    self.conv_module(m.project, bottom, residual, name=name + ".project")
+                side = 1
             else:
                 residual = bottom
             x1, x2 = cat.view(oc, oc), cat.view(0, oc)
-            self._block(m.tree1, x, residual, x1, name + ".tree1")
+            self._block(m.tree1, x, residual, x1, name + ".tree1", join=side)
             self._block(m.tree2, x1, x1, x2, name + ".tree2")
             if dst is None:
                 dst = self.buf(name + ".out", B, Ho, Wo, oc).view()
@@ -489,12 +565,15 @@ class ForwardPlan(PlanBase):
         cat2 = self.buf(name + ".cat", B, Ho, Wo, m.tree2.root_dim)
         off = 2 * oc
         bottom = None
+        bb = None
         if m.level_root:
             bottom = cat2.view(off, ic)
-            self.maxpool(x, bottom, name + ".pool")
+            with self.branch(1):
+                self.maxpool(x, bottom, name + ".pool")
+            bb = 1
             off += ic
         t1 = cat2.view(off, oc)
-        self._tree(m.tree1, x, name + ".tree1", dst=t1, bottom=bottom)  # tree1 pools the same x: share `bottom`
+        self._tree(m.tree1, x, name + ".tree1", dst=t1, bottom=bottom, bottom_branch=bb)  # tree1 pools the same x: share `bottom`
         return self._tree(m.tree2, t1, name + ".tree2", dst=dst, cat=cat2)
 
     def _dla(self, dla, img):
@@ -598,35 +677,54 @@ class ForwardPlan(PlanBase):
     def _fpn(self, fpn, feats):
         names = fpn.in_features
         results = {}
-        prev = None
-        for idx in range(len(names)):
+        # The laterals of the finer levels only need backbone features: side branch 2, beside lateral/output of the coarsest
+        # level; P6/P7 only need the coarsest output: side branch 3, beside the rest of the top-down path.
+        lats = {}
+        for idx in list(range(1, len(names))) + [0]:  # side-branch ops first: a branch forks where its first op sits in the list
             f = feats[names[-idx - 1]]
             st = fpn.stages[-idx - 1]
             lat = self.buf(f"fpn_lateral{st}", f.B, f.H, f.W, fpn._out_feature_channels[f"p{st}"]).view()
-            self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}")
-            if prev is not None:
-                self.upsample_add(lat, prev, f"fpn_topdown{st}")
-            prev = lat
-            out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C).view()
-            self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
-            results[f"p{st}"] = out
-            assert fpn._fuse_type == "sum", "FUSE_TYPE avg is not used by any reference config"
+            lats[st] = lat
+            if idx == 0:
+                self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}")
+                out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C).view()
+                self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
+                results[f"p{st}"] = out
+            else:
+                with self.branch(2):
+                    self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}")
+        assert fpn._fuse_type == "sum", "FUSE_TYPE avg is not used by any reference config"
         if fpn.top_block is not None:
             st = fpn.stages[-1]
             x = results[f"p{st}"]  # in_feature "p5" is an FPN output (dla.py:550-557)
             p6 = self.buf(f"p{st + 1}", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C).view()
-            self.conv_module(fpn.top_block.p6, x, p6, name="top_block.p6")
+            with self.branch(3):
+                self.conv_module(fpn.top_block.p6, x, p6, name="top_block.p6")
             results[f"p{st + 1}"] = p6
             if fpn.top_block.num_levels == 2:
                 p7 = self.buf(f"p{st + 2}", p6.B, (p6.H + 1) // 2, (p6.W + 1) // 2, p6.C).view()
-                if self.math == hip.MATH_BF16X3:
-                    # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the conv rectifies its input while splitting it
-                    self.conv_module(fpn.top_block.p7, p6, p7, name="top_block.p7", in_relu=True)
-                else:  # f32-MFMA mode: a rectified copy of p6 from a second run of its conv
-                    p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C).view()
-                    self.conv_module(fpn.top_block.p6, x, p6r, relu=True, name="top_block.p6.relu")
-                    self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
+                with self.branch(3):
+                    if self.math == hip.MATH_BF16X3:
+                        # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the conv rectifies its input while splitting it
+                        self.conv_module(fpn.top_block.p7, p6, p7, name="top_block.p7", in_relu=True)
+                    else:  # f32-MFMA mode: a rectified copy of p6 from a second run of its conv
+                        p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C).view()
+                        self.conv_module(fpn.top_block.p6, x, p6r, relu=True, name="top_block.p6.relu")
+                        self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
                 results[f"p{st + 2}"] = p7
+        prev = lats[fpn.stages[-1]]
+        for idx in range(1, len(names)):
+            f = feats[names[-idx - 1]]
+            st = fpn.stages[-idx - 1]
+            lat = lats[st]
+            if idx == 1:
+                self.join(2)
+            self.upsample_add(lat, prev, f"fpn_topdown{st}")
+            prev = lat
+            out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C).view()
+            self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
+            results[f"p{st}"] = out
+        self.fpn_tail_join = 3 if fpn.top_block is not None else None
         return [results[n] for n in fpn._out_features]
 
     # ------------------------------------------------------------------ heads (fcos2d.py:130-156, fcos3d.py:160-188)
