@@ -307,6 +307,21 @@ typedef struct dd3d_bev_args {  /* host memory */
 } dd3d_bev_args;
 int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Evaluator-side overlaps (the step right after the path).  Replace the reference's own numba.cuda / numba
+ * kernels in tridet/evaluators/rotate_iou.py (called at kitti_3d_evaluator.py:622-632):
+ *   dd3d_rotate_iou_eval    rotate_iou_gpu_eval :292-327: boxes [N][5], qboxes [K][5] = (x, y, x_d, y_d, angle clockwise) ->
+ *                           out [N][K]; criterion -1 IoU, 0 / 1 intersection over the query's / box's area, 2 intersection area
+ *   dd3d_d3_box_overlap     d3_box_overlap_kernel :330-357: boxes [N][7], qboxes [K][7]; rinc [N][K] holds BEV intersection areas
+ *                           on entry (criterion 2 above) and 3D overlaps on return; camera_coordinate picks the vertical axis
+ *   dd3d_image_box_overlap  image_box_overlap :360-381: XYXY boxes [N][4], [K][4] -> out [N][K]
+ * All pointers device memory, float32, row-major.
+ * ------------------------------------------------------------------------------------------------ */
+int dd3d_rotate_iou_eval(const float* boxes, const float* qboxes, float* out, int32_t N, int32_t K, int32_t criterion, void* stream);
+int dd3d_d3_box_overlap(const float* boxes, const float* qboxes, float* rinc, int32_t N, int32_t K, int32_t criterion,
+                        int32_t camera_coordinate, void* stream);
+int dd3d_image_box_overlap(const float* boxes, const float* qboxes, float* out, int32_t N, int32_t K, int32_t criterion, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
