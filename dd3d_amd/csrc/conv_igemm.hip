@@ -612,24 +612,29 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int TM, int TN, int WM, int WN, int NSA, int NSB, bool SK>
+template <int TM, int TN, int WM, int WN, int NSA, int NSB, int KT, bool SK>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const ConvKArgs a) {
   constexpr int BM = TM * 32 * WM;
   constexpr int BN = TN * 32 * WN;
   constexpr int NW = WM * WN;                // waves per block: 8 (two per SIMD) or 4 (then two blocks share a CU)
   constexpr int NTHR = 64 * NW;
-  constexpr int AP = BM * 8 / NTHR;         // 16-byte f32 pieces of the A tile per thread
+  // A step (one barrier) covers KT consecutive K-tiles of 32 k; KT = 2 halves the barriers / LDS round trips per MFMA of the
+  // small tiles, whose 12 MFMAs per wave and K-tile are short next to that fixed cost.
+  constexpr int AP1 = BM * 8 / NTHR;        // 16-byte f32 pieces of one K-tile's A rows per thread
+  constexpr int AP = KT * AP1;              // ... of a step
   constexpr int PLA = BM * 64;              // bytes per A plane
   constexpr int PLB = BN * 64;              // bytes per B plane
-  constexpr int A_STAGE = 3 * PLA, B_STAGE = 3 * PLB;
-  constexpr int NPIECE = B_STAGE / 1024;    // 1-KiB DMA pieces per B stage
-  constexpr int PB = (NPIECE + NW - 1) / NW;  // pieces per wave (the surplus re-fetches an existing piece)
+  constexpr int A_SUB = 3 * PLA, B_SUB = 3 * PLB;  // one K-tile's image (3 planes)
+  constexpr int A_STAGE = KT * A_SUB, B_STAGE = KT * B_SUB;
+  constexpr int NPIECE1 = B_SUB / 1024;     // 1-KiB DMA pieces per K-tile of B
+  constexpr int NPIECE = KT * NPIECE1;
+  constexpr int PB = (NPIECE + NW - 1) / NW;  // pieces per wave and step (the surplus re-fetches an existing piece)
   // VMEM issue order: A0 B0 A1 B1 A2 [B2] | then per step kt: A(kt+3) before the barrier, B(kt+NSB) after it.  Returns are in
   // order, so "A(kt+1) has landed" (needed at the START of step kt, where its split is interleaved with the MFMAs) is
   // vmcnt <= AP + 2*PB, and "B(kt+1) has landed" (needed before the barrier that ends step kt) is vmcnt <= WAIT_B.
   constexpr int WAIT_A = AP + 2 * PB;
   constexpr int WAIT_B = NSB == 3 ? 2 * AP + PB : AP;
-  static_assert((NW == 8 || NW == 4) && AP >= 1 && (NSB == 2 || NSB == 3) && (NSA == 1 || NSA == 2), "block shape");
+  static_assert((NW == 8 || NW == 4) && AP1 >= 1 && (NSB == 2 || NSB == 3) && (NSA == 1 || NSA == 2) && (KT == 1 || KT == 2), "block shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);  // [A stage 0 .. NSA-1 | B stage 0 .. NSB-1]
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
@@ -664,12 +669,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
   // ---- A gather geometry: thread -> (row = tid >> 3 (+64 per piece), f32 quad = tid & 7)
   const int arow = tid >> 3;
   const int avec = tid & 7;
-  long a_base[AP];
-  int a_hi0[AP], a_wi0[AP];
+  long a_base[AP1];
+  int a_hi0[AP1], a_wi0[AP1];
   {
     const int howo = s.Ho * s.Wo;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
+    for (int p = 0; p < AP1; ++p) {
       const int m = m0 + p * (NTHR / 8) + arow;
       if (m < s.M) {
         const int b = m / howo;
@@ -692,44 +697,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
 
   // ---- B DMA geometry: piece = q*8 + wave (mod NPIECE) -> (plane, 16-row block); lane -> (row = lane >> 2, LDS slot = lane & 3)
   long b_src[PB];
-  int b_dst[PB];
+  int b_dst[PB], b_sub[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
     int piece = q * NW + wave;
     piece = piece >= NPIECE ? piece - NPIECE : piece;
-    const int plane = piece / (BN / 16);
-    const int rb = piece - plane * (BN / 16);
+    const int sub = piece / NPIECE1;  // which K-tile of the step
+    const int pc = piece - sub * NPIECE1;
+    const int plane = pc / (BN / 16);
+    const int rb = pc - plane * (BN / 16);
     const int row = rb * 16 + (lane >> 2);
     const int n = min(n0 + row, a.Npad - 1);
     const int slot = (lane & 3) ^ ((lane >> 4) & 3);  // source-side swizzle: LDS slot (lane & 3) of row holds k-slot `slot`
     b_src[q] = ((long)n * nk * 3 + plane) * 64 + slot * 16;
-    b_dst[q] = plane * PLB + rb * 1024;  // + lane * 16 implied by the DMA (lane-linear)
+    b_dst[q] = sub * B_SUB + plane * PLB + rb * 1024;  // + lane * 16 implied by the DMA (lane-linear)
+    b_sub[q] = sub;
   }
 
-  // The A stream walks the K-tiles in order; (chunk, tap) are carried instead of divided out of kt.
+  // The A stream walks the K-tiles in order; (chunk, tap) are carried instead of divided out of kt.  K-tiles past the end of
+  // this block's slice read the zero page: the odd tail of a KT = 2 step must contribute nothing.
   int ld_kt = kt_begin;
   int ld_chunk = kt_begin / a.T;
   int ld_tap = kt_begin - ld_chunk * a.T;
-  const int kt_last = kt_end - 1;
+  const int nst = (kt_end - kt_begin + KT - 1) / KT;  // steps
+  const int st_last = nst - 1;
 
   f32x4 ra[2][AP];  // two register sets, always indexed by a compile-time constant (runtime indexing would serialise the loads)
-  auto load_a = [&](auto set_c) {  // next K-tile of the stream (re-fetches the last one past the end, so counts stay uniform)
+  auto load_a = [&](auto set_c) {  // the next KT K-tiles of the stream (always AP loads, so the counted waits stay exact)
     constexpr int set = decltype(set_c)::value;
-    const int dh = (ld_tap * a.kw_magic) >> 16;
-    const int dw = ld_tap - dh * a.KW;
-    const long koff = ((long)dh * s.W + dw) * s.in_pitch + ld_chunk * BK;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      const bool ok = (unsigned)(a_hi0[p] + dh) < (unsigned)s.H && (unsigned)(a_wi0[p] + dw) < (unsigned)s.W;
-      const gcfp src = ok ? g_in + a_base[p] + koff : g_zero + avec * 4;
-      // issued behind the compiler's back: its waitcnt pass drains vmcnt to 0 whenever register loads and LDS-DMA are both
-      // pending, which would expose the whole memory latency every other step.  wait_a() below is the matching wait.
-      f32x4& dst = ra[set][p];
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
-    }
-    if (ld_kt < kt_last) {
-      ++ld_kt;
-      if (++ld_tap == a.T) ld_tap = 0, ++ld_chunk;
+    for (int u = 0; u < KT; ++u) {
+      const bool live = ld_kt < kt_end;
+      const int dh = (ld_tap * a.kw_magic) >> 16;
+      const int dw = ld_tap - dh * a.KW;
+      const long koff = ((long)dh * s.W + dw) * s.in_pitch + ld_chunk * BK;
+#pragma unroll
+      for (int p = 0; p < AP1; ++p) {
+        const bool ok = live && (unsigned)(a_hi0[p] + dh) < (unsigned)s.H && (unsigned)(a_wi0[p] + dw) < (unsigned)s.W;
+        const gcfp src = ok ? g_in + a_base[p] + koff : g_zero + avec * 4;
+        // issued behind the compiler's back: its waitcnt pass drains vmcnt to 0 whenever register loads and LDS-DMA are both
+        // pending, which would expose the whole memory latency every other step.  wait_a() below is the matching wait.
+        f32x4& dst = ra[set][u * AP1 + p];
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
+      }
+      if (live) {
+        ++ld_kt;
+        if (++ld_tap == a.T) ld_tap = 0, ++ld_chunk;
+      }
     }
   };
   auto wait_a = [&](auto set_c, auto cnt_c) {
@@ -741,16 +755,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
       asm volatile("" : "+v"(r));  // the split below depends on the wait above
     }
   };
-  auto issue_b = [&](int kt, int stage) {
+  auto issue_b = [&](int st, int stage) {  // B of step st (K-tiles kt_begin + st*KT ..; clamped inside the filter: the A side is zero there)
 #pragma unroll
-    for (int q = 0; q < PB; ++q)
+    for (int q = 0; q < PB; ++q) {
+      const int kt = min(kt_begin + st * KT + b_sub[q], nk - 1);
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(g_w3 + b_src[q] + (long)kt * 192),
                                        (ldsbp)(lds + NSA * A_STAGE + stage * B_STAGE + b_dst[q]), 16, 0, 0);
+    }
   };
   // split four f32 (piece p of register set `set`) into the three bf16 planes (exact, by truncation) and store them
   auto split_store_piece = [&](auto set_c, int p, int stage) {
     constexpr int set = decltype(set_c)::value;
-    unsigned char* As = lds + stage * A_STAGE + a_st0 + p * (NTHR * 8);
+    unsigned char* As = lds + stage * A_STAGE + (p / AP1) * A_SUB + a_st0 + (p % AP1) * (NTHR * 8);
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -792,39 +808,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
   // set `set`, into A stage `next`) is spread between the MFMA groups, so the VALU work issues in the matrix pipe's shadow
   // instead of after it (both waves of a SIMD leave the barrier together: doing all MFMAs, then all VALU, idles the pipe).
   auto compute_tile = [&](int sa, int sb, auto set_c, int next) {
-    const unsigned char* As = lds + sa * A_STAGE + wm * TM * 32 * 64;
-    const unsigned char* Bs = lds + NSA * A_STAGE + sb * B_STAGE + wn * TN * 32 * 64;
-    bf16x8 af[2][TM][3], bf[2][TN][3];  // fragments of both k-chunks: the reads of chunk 1 fly under the MFMAs of chunk 0
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[c][i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLA + i * 32 * 64 + frag_off[c]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[c][j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PLB + j * 32 * 64 + frag_off[c]);
-    }
     // smallest terms first; the (i, j) loops are innermost so consecutive MFMAs hit different accumulators
     constexpr int PA_[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB_[6] = {0, 2, 1, 0, 1, 0};
-    constexpr int GSTRIDE = 12 / AP > 0 ? 12 / AP : 1;
-    static_assert(AP <= 12, "one A piece per MFMA group at most");
+    constexpr int GSTRIDE = 12 / AP1 > 0 ? 12 / AP1 : 1;
+    static_assert(AP1 <= 12, "one A piece per MFMA group at most");
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int u = 0; u < KT; ++u) {
+      const unsigned char* As = lds + sa * A_STAGE + u * A_SUB + wm * TM * 32 * 64;
+      const unsigned char* Bs = lds + NSA * A_STAGE + sb * B_STAGE + u * B_SUB + wn * TN * 32 * 64;
+      bf16x8 af[2][TM][3], bf[2][TN][3];  // fragments of both k-chunks: the reads of chunk 1 fly under the MFMAs of chunk 0
 #pragma unroll
-      for (int t = 0; t < 6; ++t) {
+      for (int c = 0; c < 2; ++c) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i][PA_[t]], bf[c][j][PB_[t]], acc[i][j], 0, 0, 0);
-        if constexpr (NSA == 2) {
-          const int grp = c * 6 + t;
-          if (grp % GSTRIDE == 0 && grp / GSTRIDE < AP) split_store_piece(set_c, grp / GSTRIDE, next);
-        }
+          for (int pl = 0; pl < 3; ++pl) af[c][i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLA + i * 32 * 64 + frag_off[c]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bf[c][j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PLB + j * 32 * 64 + frag_off[c]);
       }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i][PA_[t]], bf[c][j][PB_[t]], acc[i][j], 0, 0, 0);
+          if constexpr (NSA == 2) {
+            const int grp = c * 6 + t;
+            if (grp % GSTRIDE == 0 && grp / GSTRIDE < AP1) split_store_piece(set_c, u * AP1 + grp / GSTRIDE, next);
+          }
+        }
+    }
   };
 
   if (kt_begin < kt_end) {
@@ -832,20 +851,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
     constexpr std::integral_constant<int, 1> S1{};
     // prologue: A(0) B(0) A(1) B(1) | store A(0) | A(2) | barrier | [3 stages: B(2)]
     load_a(S0);
-    issue_b(kt_begin, 0);
+    issue_b(0, 0);
     load_a(S1);
-    issue_b(min(kt_begin + 1, kt_last), 1);
+    issue_b(min(1, st_last), 1);
     wait_a(S0, std::integral_constant<int, (NSB == 3 ? AP + PB : 0)>{});  // A(0), B(0) (2 stages: everything) landed
 #pragma unroll
     for (int p = 0; p < AP; ++p) split_store_piece(S0, p, 0);
     load_a(S0);
     lds_barrier();
-    if (NSB == 3) issue_b(min(kt_begin + 2, kt_last), 2);
+    if (NSB == 3) issue_b(min(2, st_last), 2);
     int sb = 0;
     // Step kt: [A(kt+1) landed] MFMAs of tile kt with the split + store of A(kt+1) in their shadow | A(kt+3) -> the register set
     // just stored | [B(kt+1) landed] barrier | B refill of the ring stage just consumed.  (One A stage: MFMAs | barrier | split +
     // store | ...)  Exactly AP + PB VMEM operations per step (indices clamped past the end).
-    auto step = [&](int kt_cur, int sa, auto set_c, int next) {
+    auto step = [&](int st_cur, int sa, auto set_c, int next) {
       if constexpr (NSA == 2) {
         wait_a(set_c, std::integral_constant<int, WAIT_A>{});
         compute_tile(sa, sb, set_c, next);
@@ -857,13 +876,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
       load_a(set_c);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_B) : "memory");
       lds_barrier();
-      issue_b(min(kt_cur + NSB, kt_last), sb);
+      issue_b(min(st_cur + NSB, st_last), sb);
       sb = sb == NSB - 1 ? 0 : sb + 1;
     };
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
-      step(kt, 0, S1, NSA - 1);
-      if (kt + 1 >= kt_end) break;
-      step(kt + 1, NSA - 1, S0, 0);
+    for (int st = 0; st < nst; st += 2) {
+      step(st, 0, S1, NSA - 1);
+      if (st + 1 >= nst) break;
+      step(st + 1, NSA - 1, S0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is released
   }
@@ -918,21 +937,21 @@ static void launch_dma(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   else launch_dma_sk<TM, TN, WM, WN, NS, U, WK, false>(ka, grid, st);
 }
 
-template <int TM, int TN, int WM, int WN, int NSA, int NSB>
+template <int TM, int TN, int WM, int WN, int NSA, int NSB, int KT = 1>
 static int launch_x3(const ConvKArgs& ka, hipStream_t st) {
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
-  const size_t lds = (size_t)NSA * 3 * BM * 64 + (size_t)NSB * 3 * BN * 64;
+  const size_t lds = (size_t)KT * ((size_t)NSA * 3 * BM * 64 + (size_t)NSB * 3 * BN * 64);
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, true>), grid, dim3(NTHR), lds, st, ka);
-  else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, false>), grid, dim3(NTHR), lds, st, ka);
+  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, true>), grid, dim3(NTHR), lds, st, ka);
+  else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, false>), grid, dim3(NTHR), lds, st, ka);
   return check_launch("conv_igemm_bf16x3 kernel");
 }
 
@@ -971,7 +990,7 @@ static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
 }  // namespace dd3d
 
 extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) {
-  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}};
+  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}, {128, 64}, {64, 128}, {64, 64}};
   DD3D_REQUIRE(tile_cfg >= 0 && tile_cfg < DD3D_TILE_COUNT, "dd3d_conv_tile_shape: unknown tile_cfg %d", tile_cfg);
   *bm = shapes[tile_cfg][0];
   *bn = shapes[tile_cfg][1];
@@ -1029,6 +1048,10 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
       case DD3D_TILE_128x128_W4: return launch_x3<2, 2, 2, 2, 1, 2>(ka, st);  // 24 + 48 = 72 KiB
       case DD3D_TILE_64x64_W4: return launch_x3<1, 1, 2, 2, 2, 3>(ka, st);    // 24 + 36 = 60 KiB
       case DD3D_TILE_128x64_W4: return launch_x3<2, 1, 2, 2, 1, 3>(ka, st);   // 24 + 36 = 60 KiB
+      // two K-tiles per barrier
+      case DD3D_TILE_128x64_K2: return launch_x3<1, 1, 4, 2, 2, 2, 2>(ka, st);    // 96 + 48 = 144 KiB
+      case DD3D_TILE_64x128_K2: return launch_x3<1, 1, 2, 4, 2, 2, 2>(ka, st);    // 48 + 96 = 144 KiB
+      case DD3D_TILE_64x64_W4K2: return launch_x3<1, 1, 2, 2, 1, 2, 2>(ka, st);   // 24 + 48 = 72 KiB, two blocks per CU
     }
     DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no split-bf16 kernel", L->tile_cfg);
   }

@@ -141,7 +141,7 @@ class SmallcConvOp:
 MATH_TILES = {  # tile configurations instantiated per arithmetic mode
     hip.MATH_F32: (hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x64, hip.TILE_128x32, hip.TILE_64x128),
     hip.MATH_BF16X3: (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4,
-                      hip.TILE_128x64_W4),
+                      hip.TILE_128x64_W4, hip.TILE_128x64_K2, hip.TILE_64x128_K2, hip.TILE_64x64_W4K2),
 }
 # blocks of a configuration that can share a CU (LDS-limited); the f32 kernels were measured, see profiles/
 BLOCKS_PER_CU = {hip.TILE_128x128_W4: 2, hip.TILE_64x64_W4: 2, hip.TILE_128x64_W4: 2}  # tiles the split-bf16 kernel is instantiated for
@@ -203,7 +203,8 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
                 cost /= {(128, 128): 1.0, (128, 64): 0.80, (64, 128): 0.80, (64, 64): 0.63, (128, 32): 0.40}[(bm, bn)]
             else:  # split-bf16 kernel: ~2x the f32 rate on the big tiles, LDS-read bound on the small ones
                 cost /= {hip.TILE_256x128: 2.4, hip.TILE_128x128: 1.8, hip.TILE_128x64: 1.3, hip.TILE_64x128: 1.3,
-                         hip.TILE_128x128_W4: 1.0, hip.TILE_64x64_W4: 0.6, hip.TILE_128x64_W4: 0.8}[cfg]  # W4: to be measured
+                         hip.TILE_128x128_W4: 1.0, hip.TILE_64x64_W4: 0.6, hip.TILE_128x64_W4: 0.8,
+                         hip.TILE_128x64_K2: 1.0, hip.TILE_64x128_K2: 1.0, hip.TILE_64x64_W4K2: 0.5}[cfg]  # rough; the table decides
             if sk > 1:
                 # second launch (~2 us) + partial-sum round trip (sk*M*N*8 B at ~3 TB/s), in per-CU MAC units
                 # (one CU retires 157.3e12 / 2 / 256 = 3.07e11 MAC/s)

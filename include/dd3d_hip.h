@@ -116,7 +116,10 @@ typedef struct dd3d_conv_launch {  /* host memory */
 #define DD3D_TILE_128x128_W4 6 /* 4-wave blocks (256 threads) small enough in LDS for two per CU */
 #define DD3D_TILE_64x64_W4 7
 #define DD3D_TILE_128x64_W4 8
-#define DD3D_TILE_COUNT 9
+#define DD3D_TILE_128x64_K2 9  /* 8 waves, two K-tiles (64 k) per barrier */
+#define DD3D_TILE_64x128_K2 10
+#define DD3D_TILE_64x64_W4K2 11
+#define DD3D_TILE_COUNT 12
 /* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
 int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
 int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);

@@ -19,9 +19,9 @@ RECORD = []
 _orig_init = engine.ConvOp.__init__
 
 
-def _rec_init(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name=""):
-    _orig_init(self, plan, meta, stride, pad, segs, relu, tile=tile, splitk=splitk, name=name)
-    RECORD.append((name, plan, meta, stride, pad, segs, relu))
+def _rec_init(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name="", **kw):
+    _orig_init(self, plan, meta, stride, pad, segs, relu, tile=tile, splitk=splitk, name=name, **kw)
+    RECORD.append((name, plan, meta, stride, pad, segs, relu, kw))
 
 
 def time_op(plan, op, iters=30):
@@ -59,7 +59,7 @@ def main():
     seen = {}
     table = {}
     engine.TILE_TABLE = {hip.MATH_F32: {}, hip.MATH_BF16X3: {}}  # measure against the analytic model
-    for name, pl, meta, stride, pad, segs, relu in RECORD:
+    for name, pl, meta, stride, pad, segs, relu, kw in RECORD:
         m_list = tuple(s["out"].B * s["out"].H * s["out"].W for s in segs)
         key = (m_list, meta["N"], meta["Kpad"], meta["Cin"], stride)
         if key in seen:
@@ -82,7 +82,7 @@ def main():
                 if sk == 1 and blocks > 6000 and cfg_id != cur_cfg:
                     continue
                 try:
-                    op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name, math=math)
+                    op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name, math=math, **{k: v for k, v in kw.items() if k != 'math'})
                     us = time_op(pl, op)
                 except Exception as e:  # noqa: BLE001
                     us = float("nan")

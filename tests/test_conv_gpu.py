@@ -45,6 +45,11 @@ X3_CASES = [  # split-bf16 arithmetic (DD3D_MATH_BF16X3): same f32-level toleran
     ("x3_64x64w4_sk2_k32", 1, 24, 40, 64, 64, 1, 1, 0, False, True, hip.TILE_64x64_W4, 2),
     ("x3_128x64w4", 1, 13, 21, 256, 256, 3, 2, 1, False, False, hip.TILE_128x64_W4, 1),
     ("x3_128x64w4_sk4", 1, 24, 40, 256, 128, 3, 1, 1, True, True, hip.TILE_128x64_W4, 4),
+    ("x3_128x64k2", 1, 24, 40, 256, 128, 3, 1, 1, True, True, hip.TILE_128x64_K2, 1),
+    ("x3_128x64k2_odd_tiles_sk3", 1, 13, 21, 32, 128, 3, 2, 1, False, False, hip.TILE_128x64_K2, 3),  # 9 K-tiles: odd tails
+    ("x3_64x128k2_k32", 1, 24, 40, 32, 128, 1, 1, 0, False, True, hip.TILE_64x128_K2, 1),  # a single K-tile: second half of the step is zero
+    ("x3_64x64w4k2_sk2", 1, 24, 40, 448, 128, 1, 1, 0, True, False, hip.TILE_64x64_W4K2, 2),
+    ("x3_64x64w4k2", 2, 17, 23, 128, 192, 3, 1, 1, False, True, hip.TILE_64x64_W4K2, 1),
 ]
 
 
