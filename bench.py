@@ -11,8 +11,9 @@ For N > 1 every rank forwards its own images and the step includes the RCCL all_
 the batched NMS over all N*batch images (dd3d_amd/parallel.py).
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch,
-conv_igemm_f32_kernel<2,2,2,2,false>): algorithmic FLOPs of one launch / its mean duration measured here with HIP
-events on the launch stream, against the dense f32-MFMA peak.  ``cpu_baseline`` is the CPU oracle (a restatement
+conv_igemm_bf16x3_kernel<2,2,4,2,2,2,1,false> in the default split-bf16 arithmetic): algorithmic FLOPs of one launch / its mean
+duration measured here with HIP events on the launch stream, against the MFMA roofline of that arithmetic (2500 TFLOP/s dense
+bf16 / 6 products per f32 product; the f32-input MFMA peak 157.3 TFLOP/s when DD3D_MATH=f32).  ``cpu_baseline`` is the CPU oracle (a restatement
 "port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
 """
 import argparse
@@ -149,7 +150,7 @@ def main():
                 traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch_" + ("bf16x3" if x3 else "f32"))
             except Exception:
                 traffic = None
-        kname = ("dd3d::conv_igemm_bf16x3_kernel<2,2,4,2,2,false>" if x3 else "dd3d::conv_igemm_f32_kernel<2,2,2,2,false,0,false>")
+        kname = ("dd3d::conv_igemm_bf16x3_kernel<2,2,4,2,2,2,1,false>" if x3 else "dd3d::conv_igemm_f32_kernel<2,2,2,2,false,0,false>")
         out["roofline"] = {
             "kernel": kname + " (head towers, 15 segments / launch)", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
