@@ -49,10 +49,11 @@ def main():
     exp = os.environ.get("DD3D_EXP", "dd3d_kitti_dla34")
     cfg = get_cfg(exp)
     model = build_model(cfg)
-    model.load_state_dict(make_state_dict(model, calib=load_calib("dla34_kitti" if "dla34" in exp else "v99_kitti")))
+    tag = {"dd3d_kitti_dla34": "dla34_kitti", "dd3d_kitti_v99": "v99_kitti", "dd3d_nusc_dla34": "dla34_nusc"}.get(exp, "dla34_kitti")
+    model.load_state_dict(make_state_dict(model, calib=load_calib(tag)))
     model.use_graph = False
     engine.ConvOp.__init__ = _rec_init
-    plan, _ = model.stage_inputs(make_inputs(B, H, W))
+    plan, _ = model.stage_inputs(make_inputs(B, H, W, dataset="nusc" if "nusc" in exp else "kitti"))
     engine.ConvOp.__init__ = _orig_init
     plan.run()
     torch.cuda.synchronize()
