@@ -47,7 +47,7 @@ struct ConvKArgs {
   int* tile_counters;  // split-K: arrivals per output tile (zero between launches)
   // Single-segment launches (every backbone / FPN conv) carry their descriptor in the kernel arguments: the block then
   // starts its first data loads without the tiles[] -> segs[] -> pointer chain of dependent scalar loads.
-  int single, BMrows;
+  int single;
   int in_relu;  // bf16x3 kernel: rectify the input while it is split (conv(relu(x)) without a rectified copy of x)
   dd3d_conv_seg seg0;
 };
@@ -1029,7 +1029,6 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.in_relu = L->in_relu;
   DD3D_REQUIRE(!L->in_relu || L->math_mode == DD3D_MATH_BF16X3, "dd3d_conv2d_igemm_f32: in_relu needs DD3D_MATH_BF16X3");
   ka.single = (L->nsegs == 1 && L->seg0_host != nullptr);
-  ka.BMrows = bm;
   if (ka.single) ka.seg0 = *L->seg0_host;
   else memset(&ka.seg0, 0, sizeof(ka.seg0));
   const int nk = L->Kpad / 32;

@@ -11,7 +11,7 @@ from torch import nn
 from dd3d_amd.engine import ForwardPlan
 from dd3d_amd.modeling.heads import FCOS2DHead, FCOS3DHead
 from dd3d_amd.registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY
-from dd3d_amd.structures import Boxes, Boxes3D, GenericBoxes3D, Instances, ShapeSpec
+from dd3d_amd.structures import Boxes, Boxes3D, Instances, ShapeSpec
 
 
 def build_feature_extractor(cfg, input_shape=None):
