@@ -85,6 +85,38 @@ __global__ __launch_bounds__(256) void upsample2x_add_nhwc_kernel(float* __restr
   }
 }
 
+// Aligned bilinear upsampling by an integer factor f (tridet/utils/tensor2d.py:28-47: replicate-pad by one, bilinear with
+// align_corners=True to (f*h+1, f*w+1), crop; offset "half" shifts the result by f/2 with edge replication) of channel 0 of an
+// NHWC map, fused with the focal-length scaling of DD3DDenseDepth (dense_depth.py:146-151): out /= |(invK00, invK11)| * factor.
+__global__ __launch_bounds__(256) void aligned_bilinear_scale_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                                                     const float* __restrict__ inv_K, int B, int h, int w, int pitch, int f, int half,
+                                                                     float factor) {
+  const int H = h * f, W = w * f;
+  const long total = (long)B * H * W;
+  const float scale = (float)h / (float)(f * h);  // (in - 1) / (out - 1) of the padded (h+1) -> (f*h+1) resize, = 1/f
+  const float scale_w = (float)w / (float)(f * w);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    long t = i / W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const int ys = half ? max(y - f / 2, 0) : y, xs = half ? max(x - f / 2, 0) : x;
+    const float ry = scale * (float)ys, rx = scale_w * (float)xs;
+    const int y0 = (int)ry, x0 = (int)rx;
+    const float ly = ry - (float)y0, lx = rx - (float)x0;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);  // row / column h, w of the padded map replicate h-1, w-1
+    const float* p = src + (long)b * h * w * pitch;
+    const float v00 = p[((long)y0 * w + x0) * pitch], v01 = p[((long)y0 * w + x1) * pitch];
+    const float v10 = p[((long)y1 * w + x0) * pitch], v11 = p[((long)y1 * w + x1) * pitch];
+    float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    if (factor > 0.f) {
+      const float k0 = inv_K[9 * b], k4 = inv_K[9 * b + 4];
+      v = v / (sqrtf(k0 * k0 + k4 * k4) * factor);
+    }
+    out[i] = v;
+  }
+}
+
 // 3x3 stride-2 max pooling without padding, ceil_mode=True (windows may overhang the bottom / right edge).
 __global__ __launch_bounds__(256) void maxpool3x3s2_ceil_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                                                      int Ho, int Wo, int C4, int in_pitch, int out_pitch) {
@@ -282,3 +314,16 @@ extern "C" int dd3d_invert_intrinsics(const float* K, float* inv_K, int32_t B, v
   hipLaunchKernelGGL(invert3x3_kernel, dim3((B + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), K, inv_K, B);
   return check_launch("invert3x3_kernel");
 }
+
+extern "C" int dd3d_aligned_bilinear_scale(const float* src, float* out, const float* inv_K, int32_t B, int32_t h, int32_t w, int32_t pitch,
+                                           int32_t factor, int32_t offset_half, float focal_factor, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(src && out && B > 0 && h > 0 && w > 0 && factor >= 1 && pitch >= 1, "dd3d_aligned_bilinear_scale: bad arguments");
+  DD3D_REQUIRE(focal_factor <= 0.f || inv_K, "dd3d_aligned_bilinear_scale: focal scaling needs inv_K");
+  const long total = (long)B * h * w * factor * factor;
+  const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(aligned_bilinear_scale_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, out, inv_K, B, h, w, pitch,
+                     factor, offset_half, focal_factor);
+  return check_launch("aligned_bilinear_scale_kernel");
+}
+

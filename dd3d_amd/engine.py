@@ -465,11 +465,17 @@ class ForwardPlan(PlanBase):
     """Static launch plan of DD3D.forward (inference) for one (B, Hp, Wp)."""
     def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0):
         super().__init__(device or model.device, dry_run=dry_run)
+        self._trunk(model, B, Hp, Wp)
+        # ---- heads + post-processing
+        self._heads(model, self.features)
+        self._postprocess(model, world_size, rank)
+
+    def _trunk(self, model, B, Hp, Wp):
+        """Static inputs, pre-processing, backbone and FPN (shared with DenseDepthPlan)."""
         if getattr(model, "math", None) is not None:
             self.math = MATH_NAMES[model.math] if isinstance(model.math, str) else int(model.math)
         self.model = model
         self.B, self.Hp, self.Wp = B, Hp, Wp
-        cfg = model.cfg
         dev = self.device
 
         # ---- static inputs
@@ -505,10 +511,6 @@ class ForwardPlan(PlanBase):
         if self.fpn_tail_join is not None:
             self.join(self.fpn_tail_join)  # P6 / P7 (side branch) feed the towers
         self.strides = [s.stride for s in model.backbone_output_shape]
-
-        # ---- heads + post-processing
-        self._heads(model, self.features)
-        self._postprocess(model, world_size, rank)
 
     # ------------------------------------------------------------------ DLA-34 (dla.py:170-355)
     def _block(self, m, x, residual, out, name, join=None):
@@ -992,3 +994,55 @@ class ForwardPlan(PlanBase):
     def gather_pairs(self):
         """(local, global) tensors the multi-GPU step all-gathers between select/decode and the NMS stages."""
         return [(self.cand, self.cand_all), (self.counts, self.counts_all), (self.in_outsize, self.outsize_all)]
+
+
+class DenseDepthPlan(ForwardPlan):
+    """Launch plan of DD3DDenseDepth (dense_depth.py:121-151): trunk, the box3d tower (one multi-segment launch per layer), the
+    per-level 1-channel predictors with Scale / Offset folded in (one launch), then per level the aligned bilinear upsampling to
+    the input resolution fused with the focal-length scaling."""
+    def __init__(self, model, B, Hp, Wp, device=None, dry_run=False):
+        PlanBase.__init__(self, device or model.device, dry_run=dry_run)
+        self._trunk(model, B, Hp, Wp)
+        dev, feats, head = self.device, self.features, model.fcos3d_head
+        L, Cf = len(feats), feats[0].C
+        ping = [self.buf(f"ddA.{l}", f.B, f.H, f.W, Cf) for l, f in enumerate(feats)]
+        pong = [self.buf(f"ddB.{l}", f.B, f.H, f.W, Cf) for l, f in enumerate(feats)]
+        cur = list(feats)
+        for i, conv in enumerate(head.box3d_tower):
+            dst = ping if i % 2 == 0 else pong
+            w, meta = pack_filter(conv.weight, dev)
+            segs = []
+            for l in range(L):
+                norm = conv.norm[l] if isinstance(conv.norm, torch.nn.ModuleList) else conv.norm
+                scale, shift = fold_norm(conv, norm)
+                segs.append({"in": cur[l], "out": dst[l].view(), "w": w, "scale": self._vec(scale), "bias": self._vec(shift)})
+                cur[l] = dst[l].view()
+            self.ops.append(ConvOp(self, meta, 1, 1, segs, relu=True, name=f"dd_tower.{i}"))
+        # predictors: a different filter per level (dense_depth.py:63-67,93-97), (conv + b) * scale + offset
+        segs, self.dd_raw = [], []
+        meta = None
+        for l, conv in enumerate(head.dense_depth):
+            w, meta = pack_filter(conv.weight, dev)
+            b = conv.bias.detach().float().cpu() if conv.bias is not None else torch.zeros(1)
+            sc = head.scales_depth[l].scale.detach().float().cpu() if head.use_scale else torch.ones(1)
+            off = head.offsets_depth[l].bias.detach().float().cpu() if head.use_scale else torch.zeros(1)
+            out = self.buf(f"dd_raw.{l}", feats[l].B, feats[l].H, feats[l].W, 4)
+            self.dd_raw.append(out)
+            segs.append({"in": cur[l], "out": out.view(0, 4), "w": w, "scale": self._vec(sc), "bias": self._vec(b * sc + off), "n_limit": 1})
+        self.ops.append(ConvOp(self, meta, 1, 1, segs, relu=False, name="dd_predictors"))
+        # upsample + focal scaling (tensor2d.py:28-47, dense_depth.py:140-151)
+        self.depth_maps = []
+        half = int(model.feature_locations_offset == "half")
+        for l, f in enumerate(feats):
+            stride = self.strides[l]
+            assert f.H * stride == Hp and f.W * stride == Wp, "pyramid level does not tile the padded input"
+            o = torch.zeros((B, Hp, Wp), dtype=torch.float32, device=dev)
+            self.depth_maps.append(o)
+            factor = float(model.scale_depth_by_focal_lengths_factor) if model.scale_depth_by_focal_lengths else 0.0
+
+            def _up(lib, st, src=self.dd_raw[l], o=o, stride=stride, factor=factor, f=f):
+                hip.check(lib.dd3d_aligned_bilinear_scale(src.t.data_ptr(), o.data_ptr(), self.inv_K.data_ptr(), B, f.H, f.W, 4, stride, half,
+                                                          factor, st), "aligned_bilinear")
+
+            self.ops.append(CallOp(_up, f"dd_upsample.{l}"))
+

@@ -311,6 +311,14 @@ typedef struct dd3d_bev_args {  /* host memory */
 int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * DD3DDenseDepth tail (tridet/modeling/dd3d/dense_depth.py:140-151): aligned_bilinear(x, factor, offset)
+ * (tridet/utils/tensor2d.py:28-47) of channel 0 of an NHWC map [B][h][w] (rows of `pitch` floats) to out [B][factor*h][factor*w],
+ * then, when focal_factor > 0, out /= norm(inv_K[b][0][0], inv_K[b][1][1]) * focal_factor  (SCALE_DEPTH_BY_FOCAL_LENGTHS).
+ * ------------------------------------------------------------------------------------------------ */
+int dd3d_aligned_bilinear_scale(const float* src, float* out, const float* inv_K, int32_t B, int32_t h, int32_t w, int32_t pitch,
+                                int32_t factor, int32_t offset_half, float focal_factor, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Evaluator-side overlaps (the step right after the path).  Replace the reference's own numba.cuda / numba
  * kernels in tridet/evaluators/rotate_iou.py (called at kitti_3d_evaluator.py:622-632):
  *   dd3d_rotate_iou_eval    rotate_iou_gpu_eval :292-327: boxes [N][5], qboxes [K][5] = (x, y, x_d, y_d, angle clockwise) ->

@@ -82,6 +82,49 @@ def _merge(a, b):
     return out
 
 
+def dense_depth_golden(name="dla34_densedepth_128x256_b2"):
+    """DD3DDenseDepth: the reference's forward only exists in training mode; run THAT (every norm of this config is frozen, so
+    train == eval arithmetic) with a recorder in place of the loss module: what it is called with are the per-level depth maps."""
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
+    over = _merge(TRAINING_ONLY_KEYS, {"MODEL": {"META_ARCHITECTURE": "DD3DDenseDepth"},
+                                       "DD3D": {"IN_FEATURES": ["p3", "p4", "p5", "p6", "p7"],  # the class reads it without a default
+                                                "FCOS3D": {"DEPTH_HEAD": {"LOSS_TYPE": "L1", "LOSS_WEIGHT": 1.0}}}})
+    cfg = get_cfg("dd3d_kitti_dla34", over)
+    ours = META_ARCH_REGISTRY.get("DD3DDenseDepth")(cfg)
+    sd = make_state_dict(ours, calib=load_calib("dla34_kitti"))  # same backbone / box3d-tower norm names as DD3D
+    ref_shims.install()
+    sys.modules["detectron2.config.config"] = sys.modules["detectron2.config"]
+    from tridet.modeling.dd3d.dense_depth import DD3DDenseDepth
+    ref = DD3DDenseDepth(cfg)
+    ref.load_state_dict(sd, strict=True)
+    ref.train()
+    recorded = []
+
+    class Recorder(torch.nn.Module):
+        def forward(self, pred, gt, masks=None):
+            recorded.append(pred.detach().clone())
+            return {"loss_dense_depth": pred.sum() * 0.0}
+
+    ref.depth_loss = Recorder()
+    # the released class reads self.in_strides in forward (dense_depth.py:142) but only its HEAD defines it (:20): as released the
+    # forward raises AttributeError.  The evident intent -- the head's strides -- is supplied here.
+    ref.in_strides = ref.fcos3d_head.in_strides
+    B, H, W = 2, 128, 256
+    inputs = make_inputs(B, H, W)
+    inputs[1]["intrinsics"] = inputs[1]["intrinsics"] * torch.tensor([[1.25], [1.25], [1.0]])  # a different focal length per image
+    for x in inputs:
+        x["depth"] = torch.zeros(1, H, W)
+    with torch.no_grad():
+        losses = ref(inputs)
+    assert len(recorded) == 5 and len(losses) == 5
+    out = {f"depth{l}": r.numpy() for l, r in enumerate(recorded)}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB", [tuple(r.shape) for r in recorded], [float(r.mean()) for r in recorded])
+
+
 def main(only=None):
     import dd3d_amd.modeling  # noqa: F401
     from dd3d_amd import META_ARCH_REGISTRY, get_cfg
@@ -144,4 +187,7 @@ def main(only=None):
 
 
 if __name__ == "__main__":
-    main(set(sys.argv[1:]))
+    if "dense_depth" in sys.argv[1:]:
+        dense_depth_golden()
+    else:
+        main(set(sys.argv[1:]))
