@@ -117,6 +117,31 @@ __global__ __launch_bounds__(256) void aligned_bilinear_scale_kernel(const float
   }
 }
 
+// One pass of Pillow's 8-bit resampling (libImaging/Resample.c ImagingResampleHorizontal_8bpc / Vertical_8bpc): out = clip8((2^21 +
+// sum_i in[lo + i] * kk[i]) >> 22) with per-output-coordinate bounds (lo, n) and 22-bit fixed-point coefficients computed on the
+// host.  `along_w` selects the axis; strides are in bytes (= elements).  The reference resizes its uint8 images with exactly this
+// routine (detectron2 ResizeTransform.apply_image -> PIL Image.resize(BILINEAR)), which makes the device result bit-identical.
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int C, int out_h, int out_w,
+                                                          long src_plane, int src_row, long dst_plane, int dst_row, const int32_t* __restrict__ lo,
+                                                          const int32_t* __restrict__ cnt, const int32_t* __restrict__ kk, int ksize, int along_w) {
+  const long total = (long)C * out_h * out_w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % out_w);
+    long t = i / out_w;
+    const int y = (int)(t % out_h);
+    const int c = (int)(t / out_h);
+    const int o = along_w ? x : y;
+    const int first = lo[o], n = cnt[o];
+    const int32_t* k = kk + (long)o * ksize;
+    const uint8_t* p = along_w ? src + c * src_plane + (long)y * src_row + first : src + c * src_plane + (long)first * src_row + x;
+    const int step = along_w ? 1 : src_row;
+    int acc = 1 << 21;
+    for (int j = 0; j < n; ++j) acc += (int)p[(long)j * step] * k[j];
+    acc >>= 22;
+    dst[c * dst_plane + (long)y * dst_row + x] = (uint8_t)min(max(acc, 0), 255);
+  }
+}
+
 // 3x3 stride-2 max pooling without padding, ceil_mode=True (windows may overhang the bottom / right edge).
 __global__ __launch_bounds__(256) void maxpool3x3s2_ceil_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
                                                                      int Ho, int Wo, int C4, int in_pitch, int out_pitch) {
@@ -325,5 +350,42 @@ extern "C" int dd3d_aligned_bilinear_scale(const float* src, float* out, const f
   hipLaunchKernelGGL(aligned_bilinear_scale_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, out, inv_K, B, h, w, pitch,
                      factor, offset_half, focal_factor);
   return check_launch("aligned_bilinear_scale_kernel");
+}
+
+extern "C" int dd3d_resize_bilinear_u8(const dd3d_resize_args* a, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(a && a->src && a->dst && a->C > 0 && a->H > 0 && a->W > 0 && a->new_h > 0 && a->new_w > 0, "dd3d_resize_bilinear_u8: bad arguments");
+  const bool hpass = a->new_w != a->W, vpass = a->new_h != a->H;
+  DD3D_REQUIRE(!hpass || (a->lo_w && a->cnt_w && a->kk_w && a->ksize_w > 0), "dd3d_resize_bilinear_u8: horizontal coefficients missing");
+  DD3D_REQUIRE(!vpass || (a->lo_h && a->cnt_h && a->kk_h && a->ksize_h > 0), "dd3d_resize_bilinear_u8: vertical coefficients missing");
+  DD3D_REQUIRE(!(hpass && vpass) || a->tmp, "dd3d_resize_bilinear_u8: two passes need the C x H x new_w scratch image");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto grid_for = [](long total) { return (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384); };
+  if (!hpass && !vpass) {  // same size: plain copy into the destination canvas
+    for (int c = 0; c < a->C; ++c) {
+      hipError_t e = hipMemcpy2DAsync(a->dst + c * a->dst_plane, a->dst_row, a->src + c * a->src_plane, a->src_row, a->W, a->H, hipMemcpyDeviceToDevice, st);
+      DD3D_REQUIRE(e == hipSuccess, "dd3d_resize_bilinear_u8: copy failed: %s", hipGetErrorString(e));
+    }
+    return DD3D_OK;
+  }
+  const uint8_t* src = a->src;
+  long src_plane = a->src_plane;
+  int src_row = a->src_row;
+  if (hpass) {  // horizontal first, as ImagingResample
+    uint8_t* out = vpass ? a->tmp : a->dst;
+    const long op = vpass ? (long)a->H * a->new_w : a->dst_plane;
+    const int orow = vpass ? a->new_w : a->dst_row;
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(grid_for((long)a->C * a->H * a->new_w)), dim3(256), 0, st, src, out, a->C, a->H, a->new_w, src_plane,
+                       src_row, op, orow, a->lo_w, a->cnt_w, a->kk_w, a->ksize_w, 1);
+    int rc = check_launch("resample_u8_kernel (horizontal)");
+    if (rc != DD3D_OK) return rc;
+    src = out, src_plane = op, src_row = orow;
+  }
+  if (vpass) {
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(grid_for((long)a->C * a->new_h * a->new_w)), dim3(256), 0, st, src, a->dst, a->C, a->new_h, a->new_w,
+                       src_plane, src_row, a->dst_plane, a->dst_row, a->lo_h, a->cnt_h, a->kk_h, a->ksize_h, 0);
+    return check_launch("resample_u8_kernel (vertical)");
+  }
+  return DD3D_OK;
 }
 

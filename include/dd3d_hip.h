@@ -311,6 +311,29 @@ typedef struct dd3d_bev_args {  /* host memory */
 int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input side (the step right before the path): the test-time resize of the uint8 image.
+ * Replaces detectron2 ResizeTransform.apply_image [ext] = PIL Image.resize(BILINEAR) behind ResizeShortestEdge
+ * (tridet/data/augmentations/resize_transform.py:85-88, dataset_mapper.py:118-127): Pillow's separable 8-bit resampling --
+ * horizontal pass, 8-bit intermediate, vertical pass -- with the per-coordinate bounds and 22-bit fixed-point coefficients
+ * computed by the caller (dd3d_amd/inputs.py resample_coeffs).  Bit-identical to PIL.
+ *   src  uint8 planar [C][H][W] with strides (src_plane, src_row); dst planar with (dst_plane, dst_row) -- e.g. one image
+ *        slot of the forward plan's input canvas; tmp uint8 [C][H][new_w], needed when both sizes change
+ *   lo_* / cnt_* int32 [new size], kk_* int32 [new size][ksize_*]
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dd3d_resize_args {  /* host memory; all pointers device */
+  const uint8_t* src;
+  uint8_t* dst;
+  uint8_t* tmp;
+  int32_t C, H, W, new_h, new_w;
+  int64_t src_plane, dst_plane;
+  int32_t src_row, dst_row;
+  const int32_t *lo_w, *cnt_w, *kk_w;
+  const int32_t *lo_h, *cnt_h, *kk_h;
+  int32_t ksize_w, ksize_h;
+} dd3d_resize_args;
+int dd3d_resize_bilinear_u8(const dd3d_resize_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * DD3DDenseDepth tail (tridet/modeling/dd3d/dense_depth.py:140-151): aligned_bilinear(x, factor, offset)
  * (tridet/utils/tensor2d.py:28-47) of channel 0 of an NHWC map [B][h][w] (rows of `pitch` floats) to out [B][factor*h][factor*w],
  * then, when focal_factor > 0, out /= norm(inv_K[b][0][0], inv_K[b][1][1]) * focal_factor  (SCALE_DEPTH_BY_FOCAL_LENGTHS).
