@@ -1,0 +1,66 @@
+"""Golden vectors for the TTA wrapper: the reference's own DD3DWithTTA (tridet/modeling/dd3d/test_time_augmentation.py) around the
+reference's own DD3D, on CPU, on top of the third-party shims of ref_shims.py (detectron2 / fvcore transforms restated there, PIL real).
+
+    python tests/golden/make_tta_golden.py      ->  tests/golden/tta_dla34.npz
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from tests.golden import ref_shims  # noqa: E402
+from tests.golden.make_golden import TRAINING_ONLY_KEYS, _merge  # noqa: E402
+
+TTA_OVERRIDES = {
+    "DD3D": {"INFERENCE": {"DO_POSTPROCESS": False, "DO_BEV_NMS": True}, "FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.02}}},
+    "TEST": {"IMS_PER_BATCH": 4, "AUG": {"ENABLED": True, "MIN_SIZES": [96, 128, 160], "MAX_SIZE": 100000, "FLIP": True}},
+    "INPUT": {"FORMAT": "BGR"},
+}
+
+
+def tta_case():
+    from dd3d_amd.synthetic import KITTI_K
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 256, (3, 110, 260), dtype=np.uint8)
+    K = torch.tensor(KITTI_K) * torch.tensor([[260 / 1224], [110 / 370], [1.0]])
+    return {"image": torch.from_numpy(raw), "intrinsics": K, "height": 110, "width": 260}
+
+
+def main():
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_state_dict
+    cfg = get_cfg("dd3d_kitti_dla34", _merge(TRAINING_ONLY_KEYS, TTA_OVERRIDES))
+    sd = make_state_dict(META_ARCH_REGISTRY.get("DD3D")(cfg), calib=load_calib("dla34_kitti"))
+    ref_shims.install()
+    for pkg in ("tridet.data", "tridet.data.augmentations"):
+        m = sys.modules.get(pkg) or types.ModuleType(pkg)
+        m.__path__ = [os.path.join(ref_shims.REFERENCE_ROOT, *pkg.split("."))]
+        sys.modules[pkg] = m
+    importlib.import_module("tridet.data.augmentations.flip_transform")  # registers the intrinsics / box3d transform types
+    importlib.import_module("tridet.data.augmentations.resize_transform")
+    from tridet.modeling.dd3d.core import DD3D
+    from tridet.modeling.dd3d.test_time_augmentation import DD3DWithTTA
+    from tridet.structures.pose import Pose as RefPose
+    ref = DD3D(cfg)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    x = tta_case()
+    x["extrinsics"] = RefPose()  # DO_BEV_NMS inside every augmented forward reads a pose (core.py:138-141)
+    with torch.no_grad():
+        inst = DD3DWithTTA(cfg, ref)([x])[0]["instances"]
+    out = dict(boxes=inst.pred_boxes.tensor.numpy(), scores=inst.scores.numpy(), scores_3d=inst.scores_3d.numpy(), classes=inst.pred_classes.numpy(),
+               vectorize=inst.pred_boxes3d.vectorize().numpy(), proj_ctr=inst.pred_boxes3d.proj_ctr.numpy(), depth=inst.pred_boxes3d.depth.numpy(),
+               image_size=np.array(inst.image_size))
+    path = os.path.join(HERE, "tta_dla34.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(inst), "merged detections")
+
+
+if __name__ == "__main__":
+    main()

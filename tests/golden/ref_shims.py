@@ -457,6 +457,147 @@ class Quaternion:
         return self.rotation_matrix @ np.asarray(v, dtype=np.float64)
 
 
+
+# --------------------------------------------------------------------------------------------- fvcore / detectron2 transforms [ext]
+class Transform:
+    """[ext] fvcore.transforms.transform.Transform: apply_image / apply_coords, apply_box via the four corners, extra data types
+    registered per class (register_type -> apply_<type>)."""
+    @classmethod
+    def register_type(cls, data_type, func):
+        setattr(cls, "apply_" + data_type, lambda self, x, _f=func: _f(self, x))
+
+    def apply_box(self, box):
+        import numpy as np
+        idxs = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+        coords = np.asarray(box).reshape(-1, 4)[:, idxs].reshape(-1, 2)
+        coords = self.apply_coords(coords).reshape((-1, 4, 2))
+        minxy, maxxy = coords.min(axis=1), coords.max(axis=1)
+        return np.concatenate((minxy, maxxy), axis=1)
+
+    def inverse(self):
+        raise NotImplementedError
+
+
+class NoOpTransform(Transform):
+    def apply_image(self, img):
+        return img
+
+    def apply_coords(self, coords):
+        return coords
+
+    def inverse(self):
+        return self
+
+    def __getattr__(self, name):
+        if name.startswith("apply_"):
+            return lambda x: x
+        raise AttributeError(name)
+
+
+class HFlipTransform(Transform):
+    def __init__(self, width):
+        self.width = width
+
+    def apply_image(self, img):
+        import numpy as np
+        return np.flip(img, axis=1)
+
+    def apply_coords(self, coords):
+        coords[:, 0] = self.width - coords[:, 0]
+        return coords
+
+    def inverse(self):
+        return self
+
+
+class VFlipTransform(Transform):
+    def __init__(self, height):
+        self.height = height
+
+    def inverse(self):
+        return self
+
+
+class ResizeTransform(Transform):
+    """[ext] detectron2.data.transforms.ResizeTransform: uint8 images through PIL (the real library is installed)."""
+    def __init__(self, h, w, new_h, new_w, interp=None):
+        self.h, self.w, self.new_h, self.new_w, self.interp = h, w, new_h, new_w, interp
+
+    def apply_image(self, img, interp=None):
+        import numpy as np
+        from PIL import Image
+        assert img.shape[:2] == (self.h, self.w) and img.dtype == np.uint8
+        return np.asarray(Image.fromarray(img).resize((self.new_w, self.new_h), Image.BILINEAR))
+
+    def apply_coords(self, coords):
+        coords[:, 0] = coords[:, 0] * (self.new_w * 1.0 / self.w)
+        coords[:, 1] = coords[:, 1] * (self.new_h * 1.0 / self.h)
+        return coords
+
+    def inverse(self):
+        return ResizeTransform(self.new_h, self.new_w, self.h, self.w, self.interp)
+
+
+class TransformList(Transform):
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __getattr__(self, name):
+        if name.startswith("apply_"):
+            def run(x, _n=name):
+                for t in self.transforms:
+                    x = getattr(t, _n)(x)
+                return x
+            return run
+        raise AttributeError(name)
+
+    def __add__(self, other):
+        others = other.transforms if isinstance(other, TransformList) else [other]
+        return TransformList(self.transforms + others)
+
+    def __radd__(self, other):
+        others = other.transforms if isinstance(other, TransformList) else [other]
+        return TransformList(others + self.transforms)
+
+    def inverse(self):
+        return TransformList([t.inverse() for t in self.transforms[::-1]])
+
+
+class D2ResizeShortestEdge:
+    """[ext] detectron2 ResizeShortestEdge with an int short_edge_length ("range" over (s, s))."""
+    def __init__(self, short_edge_length, max_size=sys.maxsize, sample_style="range", interp=None):
+        self.short_edge_length, self.max_size = short_edge_length, max_size
+
+    def get_transform(self, image):
+        h, w = image.shape[:2]
+        size = self.short_edge_length
+        scale = size * 1.0 / min(h, w)
+        newh, neww = (size, scale * w) if h < w else (scale * h, size)
+        if max(newh, neww) > self.max_size:
+            scale = self.max_size * 1.0 / max(newh, neww)
+            newh, neww = newh * scale, neww * scale
+        return ResizeTransform(h, w, int(newh + 0.5), int(neww + 0.5))
+
+
+class D2RandomFlip:
+    def __init__(self, prob=0.5, *, horizontal=True, vertical=False):
+        self.prob, self.horizontal = prob, horizontal
+
+    def get_transform(self, image):
+        h, w = image.shape[:2]
+        assert self.prob >= 1.0 and self.horizontal
+        return HFlipTransform(w)
+
+
+def apply_augmentations(augmentations, image):
+    tfms = []
+    for aug in augmentations:
+        t = aug.get_transform(image)
+        image = t.apply_image(image)
+        tfms.append(t)
+    return image, TransformList(tfms)
+
+
 def install():
     """Install every shim module and make ``tridet`` importable without running its package __init__ chains."""
     if "detectron2" in sys.modules and getattr(sys.modules["detectron2"], "_dd3d_shim", False):
@@ -500,7 +641,14 @@ def install():
     _mod("fvcore.nn.smooth_l1_loss", smooth_l1_loss=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("training only")))
     _mod("pyquaternion", Quaternion=Quaternion)
     _mod("mpi4py", MPI=types.SimpleNamespace(COMM_WORLD=None))
-    _mod("cv2")
+    _mod("cv2", INTER_NEAREST=0, INTER_LINEAR=1, INTER_CUBIC=2)
+    _mod("fvcore.transforms", NoOpTransform=NoOpTransform)
+    _mod("fvcore.transforms.transform", HFlipTransform=HFlipTransform, VFlipTransform=VFlipTransform, NoOpTransform=NoOpTransform,
+         Transform=Transform, TransformList=TransformList)
+    _mod("detectron2.data")
+    _mod("detectron2.data.detection_utils", read_image=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("read_image")))
+    _mod("detectron2.data.transforms", RandomFlip=D2RandomFlip, ResizeShortestEdge=D2ResizeShortestEdge, ResizeTransform=ResizeTransform,
+         apply_augmentations=apply_augmentations)
     # tridet packages as bare namespaces (their __init__ chains pull in data / TTA / visualisation code)
     for pkg in ("tridet", "tridet.modeling", "tridet.modeling.dd3d", "tridet.utils", "tridet.structures"):
         m = _mod(pkg)
