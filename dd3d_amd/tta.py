@@ -20,7 +20,7 @@ from dd3d_amd.inputs import DeviceResizer, shortest_edge_size
 from dd3d_amd.modeling.dd3d import DD3D
 from dd3d_amd.structures import Boxes, Boxes3D, Instances
 
-__all__ = ["DatasetMapperTTA", "DD3DWithTTA"]
+__all__ = ["DatasetMapperTTA", "DD3DWithTTA", "NuscenesDD3DWithTTA"]
 
 # CAMERA_TO_VEHICLE_ROTATION (tridet/layers/bev_nms.py:27-32) as the (w, x, y, z) quaternion of [[0,0,1],[-1,0,0],[0,-1,0]]
 _CAM_TO_VEHICLE_QUAT = (0.5, -0.5, 0.5, -0.5)
@@ -111,7 +111,8 @@ class _MergeNMS:
     def __init__(self, device):
         self.device = device
 
-    def __call__(self, boxes, boxes3d_vec, proj_ctr, depth, scores, scores_3d, classes, inv_K, do_nms, nms_thresh, do_bev, bev_thresh, num_classes):
+    def __call__(self, boxes, boxes3d_vec, proj_ctr, depth, scores, scores_3d, classes, inv_K, do_nms, nms_thresh, do_bev, bev_thresh, num_classes,
+                 attributes=None, speeds=None):
         dev, n = self.device, boxes.shape[0]
         if n > 8192:
             raise NotImplementedError(f"TTA merge of {n} boxes exceeds the 8192-box sorter")
@@ -122,6 +123,8 @@ class _MergeNMS:
         cand[0, 6] = classes.to(torch.int32).view(torch.float32)
         cand[0, 7] = torch.arange(n, dtype=torch.int32, device=dev).view(torch.float32)
         cand[0, 10:14], cand[0, 14:16], cand[0, 16], cand[0, 17:20] = boxes3d_vec[:, 0:4].T, proj_ctr.T, depth, boxes3d_vec[:, 7:10].T
+        if attributes is not None:
+            cand[0, 20], cand[0, 21] = attributes.to(torch.int32).view(torch.float32), speeds
         counts = torch.tensor([[n]], dtype=torch.int32, device=dev)
         ncap = (n + 63) // 64 * 64
         a = hip.NmsArgs()
@@ -195,13 +198,14 @@ class DD3DWithTTA(nn.Module):
         return [self._inference_one_image(_with_size(x)) for x in batched_inputs]
 
     @torch.no_grad()
-    def _inference_one_image(self, x):
-        orig_shape = (x["height"], x["width"])
+    def _merged_detections(self, x, with_nusc=False):
+        """Union of the augmented forwards mapped back to the original frame, after the merge NMS (+ BEV NMS): (det [k][DET_FIELDS] in
+        the layout of dd3d_nms_finalize, inverse original intrinsics (3, 3) on the host)."""
         augmented_inputs = self.tta_mapper(x)
         tfms = [a.pop("transforms") for a in augmented_inputs]
         outputs = self._batch_inference(augmented_inputs)
         dev = self.model.device
-        boxes, vecs, scores, scores_3d, classes = [], [], [], [], []
+        boxes, vecs, scores, scores_3d, classes, attrs, speeds = [], [], [], [], [], [], []
         orig_K = None
         for inp, out, tfm in zip(augmented_inputs, outputs, tfms):
             boxes.append(tfm.inverse_box(out.pred_boxes.tensor.cpu().numpy()))
@@ -212,28 +216,105 @@ class DD3DWithTTA(nn.Module):
             p = vecs[-1][:, 4:7] @ K.T
             vecs[-1] = np.concatenate([vecs[-1], p[:, :2] / p[:, 2:3]], axis=1)  # columns 10, 11: proj_ctr
             scores.append(out.scores), scores_3d.append(out.scores_3d), classes.append(out.pred_classes)
+            if with_nusc:
+                attrs.append(out.pred_attributes), speeds.append(out.pred_speeds)
         boxes = torch.from_numpy(np.concatenate(boxes, 0)).to(dev)
         vecs = torch.from_numpy(np.concatenate(vecs, 0).astype(np.float32)).to(dev)
         scores, scores_3d, classes = torch.cat(scores), torch.cat(scores_3d), torch.cat(classes)
+        attrs = torch.cat(attrs) if with_nusc else torch.zeros_like(classes)
+        speeds = torch.cat(speeds) if with_nusc else torch.zeros_like(scores)
         n = boxes.shape[0]
-        bev = (not self.model.only_box2d) and self.model.do_bev_nms
+        bev = (not self.model.only_box2d) and bool(self.model.do_bev_nms)
         if bev and not self.model.do_nms and n > 0:
             # bev_nms alone returns its keep list in descending score order; the aggregate kernel preserves input order
             order = torch.argsort(scores_3d, descending=True, stable=True)
             boxes, vecs, scores, scores_3d, classes = boxes[order], vecs[order], scores[order], scores_3d[order], classes[order]
+            attrs, speeds = attrs[order], speeds[order]
         inv_K = torch.from_numpy(np.linalg.inv(orig_K).astype(np.float32))
-        merged = Instances(orig_shape)
         if n == 0 or not (self.model.do_nms or bev):
-            merged.pred_boxes = Boxes(boxes)
-            merged.pred_boxes3d = Boxes3D(vecs[:, 0:4], vecs[:, 10:12], vecs[:, 6:7], vecs[:, 7:10], inv_K.to(dev)[None].expand(n, 3, 3))
-            merged.pred_classes, merged.scores, merged.scores_3d = classes, scores, scores_3d
-            return {"instances": merged}
+            det = torch.zeros((n, hip.DET_FIELDS), dtype=torch.float32, device=dev)
+            if n:
+                det[:, 0:4], det[:, 4], det[:, 5], det[:, 6] = boxes, scores, scores_3d, classes.float()
+                det[:, 10:14], det[:, 14:16], det[:, 16], det[:, 17:20] = vecs[:, 0:4], vecs[:, 10:12], vecs[:, 6], vecs[:, 7:10]
+                det[:, 20], det[:, 21] = attrs.float(), speeds
+            return det, inv_K
         det = self._merge(boxes, vecs, vecs[:, 10:12], vecs[:, 6], scores, scores_3d, classes, inv_K, self.model.do_nms, self.nms_thresh, bev,
-                          self.model.bev_nms_iou_thresh, self.model.num_classes)
-        k = det.shape[0]
-        merged.pred_boxes = Boxes(det[:, 0:4].contiguous())
-        merged.pred_boxes3d = Boxes3D(det[:, 10:14].contiguous(), det[:, 14:16].contiguous(), det[:, 16:17].contiguous(), det[:, 17:20].contiguous(),
-                                      inv_K.to(dev)[None].expand(k, 3, 3))
-        merged.pred_classes = det[:, 6].to(torch.int64)
-        merged.scores, merged.scores_3d = det[:, 4].contiguous(), det[:, 5].contiguous()
-        return {"instances": merged}
+                          self.model.bev_nms_iou_thresh, self.model.num_classes, attrs, speeds)
+        return det, inv_K
+
+    def _instances(self, det, inv_K, image_size, with_nusc=False, with_global=False):
+        dev, k = self.model.device, det.shape[0]
+        r = Instances(image_size)
+        r.pred_boxes = Boxes(det[:, 0:4].contiguous())
+        r.pred_boxes3d = Boxes3D(det[:, 10:14].contiguous(), det[:, 14:16].contiguous(), det[:, 16:17].contiguous(), det[:, 17:20].contiguous(),
+                                 inv_K.to(dev)[None].expand(k, 3, 3))
+        r.pred_classes = det[:, 6].to(torch.int64)
+        r.scores, r.scores_3d = det[:, 4].contiguous(), det[:, 5].contiguous()
+        if with_nusc:
+            r.pred_attributes, r.pred_speeds = det[:, 20].to(torch.int64), det[:, 21].contiguous()
+        if with_global:
+            from dd3d_amd.structures import GenericBoxes3D
+            r.pred_boxes3d_global = GenericBoxes3D(det[:, 22:26].contiguous(), det[:, 26:29].contiguous(), det[:, 17:20].contiguous())
+        return r
+
+    def _inference_one_image(self, x):
+        det, inv_K = self._merged_detections(x)
+        return {"instances": self._instances(det, inv_K, (x["height"], x["width"]))}
+
+
+class NuscenesDD3DWithTTA(DD3DWithTTA):
+    """nuscenes_dd3d_tta.py:21-178: DD3DWithTTA per camera image (attributes / speeds ride through the merge), then the cross-camera
+    sample aggregation (postprocessing.py:58-108) over the merged per-image detections."""
+    def __init__(self, cfg, model, tta_mapper=None):
+        from dd3d_amd.modeling.nuscenes_dd3d import NuscenesDD3D
+        assert isinstance(model, NuscenesDD3D), \
+            "NuscenesDD3DWithTTA only supports on NuscenesDD3D. Got a model of type {}".format(type(model))
+        super().__init__(cfg, model, tta_mapper)
+
+    @torch.no_grad()
+    def __call__(self, batched_inputs):
+        from dd3d_amd.modeling.nuscenes_dd3d import get_group_idxs
+        xs = []
+        for d in batched_inputs:
+            r = copy.copy(d)
+            if "image" not in r:
+                raise NotImplementedError("reading images from file_name is the data pipeline's job (detectron2 read_image)")
+            if "height" not in r and "width" not in r:
+                r["height"], r["width"] = r["image"].shape[1], r["image"].shape[2]
+            xs.append(r)
+        merged = [self._merged_detections(x, with_nusc=True) for x in xs]
+        G, dev = len(xs), self.model.device
+        groups = get_group_idxs([x["sample_token"] for x in batched_inputs], self.model.num_images_per_sample)
+        group_of = [0] * G
+        for gi, idxs in enumerate(groups.values()):
+            for i in idxs:
+                group_of[i] = gi
+        cap = max(1, max(d.shape[0] for d, _ in merged))
+        if G * cap > 8192:
+            raise NotImplementedError(f"sample aggregation over {G} x {cap} boxes exceeds the 8192-box sorter")
+        det_in = torch.zeros((G, cap, hip.DET_FIELDS), dtype=torch.float32, device=dev)
+        for i, (d, _) in enumerate(merged):
+            det_in[i, :d.shape[0]] = d
+        count_in = torch.tensor([d.shape[0] for d, _ in merged], dtype=torch.int32, device=dev)
+        inv_K = torch.stack([k for _, k in merged]).reshape(G, 9).to(dev)
+        pose = torch.tensor([[float(v) for v in x["pose"].quat.elements] + [float(v) for v in x["pose"].tvec] for x in batched_inputs],
+                            dtype=torch.float32, device=dev)
+        group = torch.tensor(group_of, dtype=torch.int32, device=dev)
+        ncap = (G * cap + 63) // 64 * 64
+        work = dict(work=torch.zeros((G * cap, 16), dtype=torch.float32, device=dev), sbox=torch.zeros((G * cap, 8), dtype=torch.float32, device=dev),
+                    mask=torch.zeros((ncap, ncap // 64), dtype=torch.int64, device=dev), meta=torch.zeros((4, ), dtype=torch.int32, device=dev),
+                    det_out=torch.zeros_like(det_in), count_out=torch.zeros_like(count_in), out_size=torch.ones((G, 4), dtype=torch.float32, device=dev))
+        b = hip.BevArgs()
+        b.det_in, b.count_in, b.inv_K, b.pose, b.group = det_in.data_ptr(), count_in.data_ptr(), inv_K.data_ptr(), pose.data_ptr(), group.data_ptr()
+        b.out_size, b.G, b.det_cap, b.num_classes = work["out_size"].data_ptr(), G, cap, int(self.model.num_classes)
+        b.iou_thresh, b.max_dets = float(self.model.bev_nms_iou_thresh), int(self.model.max_num_dets_per_sample)
+        b.write_global, b.do_postprocess = 1, 0
+        b.work, b.sbox, b.mask, b.meta = work["work"].data_ptr(), work["sbox"].data_ptr(), work["mask"].data_ptr(), work["meta"].data_ptr()
+        b.det_out, b.count_out = work["det_out"].data_ptr(), work["count_out"].data_ptr()
+        hip.check(hip.lib().dd3d_bev_nms_aggregate(C.byref(b), hip.current_stream()), "tta sample aggregate")
+        counts = work["count_out"].cpu().tolist()
+        out = []
+        for i, x in enumerate(xs):
+            d = work["det_out"][i, :counts[i]]
+            out.append({"instances": self._instances(d, merged[i][1], (x["height"], x["width"]), with_nusc=True, with_global=True)})
+        return out

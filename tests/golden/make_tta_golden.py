@@ -31,6 +31,60 @@ def tta_case():
     return {"image": torch.from_numpy(raw), "intrinsics": K, "height": 110, "width": 260}
 
 
+NUSC_TTA_OVERRIDES = {
+    "DD3D": {"INFERENCE": {"DO_POSTPROCESS": False}, "FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}},
+             "NUSC": {"INFERENCE": {"MAX_NUM_DETS_PER_SAMPLE": 120}}},
+    "TEST": {"IMS_PER_BATCH": 4, "AUG": {"ENABLED": True, "MIN_SIZES": [96, 128], "MAX_SIZE": 100000, "FLIP": True}},
+    "INPUT": {"FORMAT": "BGR"},
+}
+
+
+def nusc_tta_case():
+    """One 6-camera sample of raw 100 x 178 frames (camera poses of dd3d_amd.synthetic)."""
+    from dd3d_amd.synthetic import NUSC_K, make_inputs
+    base = make_inputs(6, 100, 178, dataset="nusc", seed=2000)
+    K = torch.tensor(NUSC_K) * torch.tensor([[178 / 1600], [100 / 900], [1.0]])
+    return [dict(x, intrinsics=K.clone(), height=100, width=178) for x in base]
+
+
+def nusc_main():
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_state_dict
+    cfg = get_cfg("dd3d_nusc_dla34", _merge(TRAINING_ONLY_KEYS, NUSC_TTA_OVERRIDES))
+    sd = make_state_dict(META_ARCH_REGISTRY.get("NuscenesDD3D")(cfg), calib=load_calib("dla34_nusc"))
+    ref_shims.install()
+    for pkg in ("tridet.data", "tridet.data.augmentations"):
+        m = sys.modules.get(pkg) or types.ModuleType(pkg)
+        m.__path__ = [os.path.join(ref_shims.REFERENCE_ROOT, *pkg.split("."))]
+        sys.modules[pkg] = m
+    importlib.import_module("tridet.data.augmentations.flip_transform")
+    importlib.import_module("tridet.data.augmentations.resize_transform")
+    from tridet.modeling.dd3d.nuscenes_dd3d import NuscenesDD3D
+    from tridet.modeling.dd3d.nuscenes_dd3d_tta import NuscenesDD3DWithTTA
+    from tridet.structures.pose import Pose as RefPose
+    ref = NuscenesDD3D(cfg)
+    ref.load_state_dict(sd, strict=True)
+    ref.eval()
+    xs = nusc_tta_case()
+    for x in xs:
+        x["pose"] = RefPose(wxyz=x["pose"].quat.elements, tvec=x["pose"].tvec)
+    with torch.no_grad():
+        res = NuscenesDD3DWithTTA(cfg, ref)(xs)
+    out = {}
+    for i, r in enumerate(res):
+        inst = r["instances"]
+        out[f"n{i}"] = np.array(len(inst))
+        if len(inst) == 0:
+            continue
+        out[f"boxes{i}"], out[f"scores_3d{i}"] = inst.pred_boxes.tensor.numpy(), inst.scores_3d.numpy()
+        out[f"classes{i}"], out[f"attributes{i}"], out[f"speeds{i}"] = inst.pred_classes.numpy(), inst.pred_attributes.numpy(), inst.pred_speeds.numpy()
+        out[f"vectorize{i}"], out[f"global{i}"] = inst.pred_boxes3d.vectorize().numpy(), inst.pred_boxes3d_global.vectorize().numpy()
+    path = os.path.join(HERE, "tta_nusc_dla34.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, [int(out[f"n{i}"]) for i in range(len(res))])
+
+
 def main():
     import dd3d_amd.modeling  # noqa: F401
     from dd3d_amd import META_ARCH_REGISTRY, get_cfg
@@ -63,4 +117,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "nusc" in sys.argv[1:]:
+        nusc_main()
+    else:
+        main()

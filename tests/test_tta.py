@@ -68,3 +68,55 @@ def test_hip_tta_matches_reference_golden(hiplib):
     with pytest.raises(AssertionError, match="postprocess_in_inference"):
         model.postprocess_in_inference = True
         DD3DWithTTA(cfg, model)
+
+
+# ------------------------------------------------------------------------------------------------ NuscenesDD3DWithTTA
+GN = np.load(os.path.join(os.path.dirname(__file__), "golden", "tta_nusc_dla34.npz"))
+
+
+def _nusc_bundle():
+    from tests.golden.make_tta_golden import NUSC_TTA_OVERRIDES
+    from tests.util import bundle
+    return bundle("dd3d_nusc_dla34", "dla34_nusc", NUSC_TTA_OVERRIDES)
+
+
+def _check_nusc(i, boxes, scores_3d, classes, attrs, speeds, vec, glob, tol):
+    n = int(GN[f"n{i}"])
+    assert len(boxes) == n, (i, len(boxes), n)
+    if n == 0:
+        return
+    assert np.array_equal(classes, GN[f"classes{i}"]) and np.array_equal(attrs, GN[f"attributes{i}"])
+    assert np.allclose(boxes, GN[f"boxes{i}"], rtol=tol, atol=tol * 200) and np.allclose(scores_3d, GN[f"scores_3d{i}"], rtol=tol, atol=1e-6)
+    assert np.allclose(speeds, GN[f"speeds{i}"], rtol=tol, atol=1e-5) and np.allclose(vec[:, 4:], GN[f"vectorize{i}"][:, 4:], rtol=tol, atol=tol * 80)
+    g, gg = glob, GN[f"global{i}"]
+    assert np.allclose(g[:, 4:], gg[:, 4:], rtol=tol, atol=max(tol, 2e-7) * 1500)  # world-frame translations ~1e3 m
+    assert float(np.minimum(np.abs(g[:, :4] - gg[:, :4]).max(1), np.abs(g[:, :4] + gg[:, :4]).max(1)).max()) < max(tol, 1e-5) * 10
+
+
+def test_nuscenes_tta_oracle_matches_reference_golden():
+    from oracle import dd3d_oracle as O
+    from oracle import tta_oracle as T
+    from tests.golden.make_tta_golden import nusc_tta_case
+    cfg, sd = _nusc_bundle()
+    with torch.no_grad():
+        out, merged = T.nuscenes_tta_forward(sd, cfg, nusc_tta_case())
+    assert sum(len(m["scores"]) for m in merged) > sum(int(GN[f"n{i}"]) for i in range(6)) == 120  # aggregation + the 120 cap act
+    for i, r in enumerate(out):
+        _check_nusc(i, r["pred_boxes"].numpy(), r["scores_3d"].numpy(), r["pred_classes"].numpy(), r["pred_attributes"].numpy(), r["pred_speeds"].numpy(),
+                    O.boxes3d_vectorize(r["pred_boxes3d"]).numpy(), r["pred_boxes3d_global"].numpy(), 1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_nuscenes_tta_matches_reference_golden(hiplib):
+    from dd3d_amd.tta import NuscenesDD3DWithTTA
+    from tests.golden.make_tta_golden import nusc_tta_case
+    from tests.util import gpu_model
+    cfg, sd = _nusc_bundle()
+    model = gpu_model(cfg, sd, use_graph=False)
+    res = NuscenesDD3DWithTTA(cfg, model)(nusc_tta_case())
+    assert len(res) == 6
+    for i, r in enumerate(res):
+        o = r["instances"]
+        assert tuple(o.image_size) == (100, 178)
+        _check_nusc(i, o.pred_boxes.tensor.cpu().numpy(), o.scores_3d.cpu().numpy(), o.pred_classes.cpu().numpy(), o.pred_attributes.cpu().numpy(),
+                    o.pred_speeds.cpu().numpy(), o.pred_boxes3d.vectorize().cpu().numpy(), o.pred_boxes3d_global.vectorize().cpu().numpy(), 1e-3)
