@@ -161,6 +161,59 @@ __global__ void image_overlap_kernel(const float* boxes, const float* qboxes, fl
   out[idx] = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Result formatting (kitti_3d_evaluator.py:205-264 convert_3d_box_to_kitti, nuscenes_evaluator.py:196-198 velocity): one thread per
+// detection, float64 like the reference's numpy / pyquaternion arithmetic.  The reference converts box by box on the host with one
+// device->host copy per field per box; here a whole batch is one launch and one copy.
+// out[i] = (W, L, H, x, y, z, rot_y, alpha, vx, vy).
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_unit(double& w, double& x, double& y, double& z) {
+  // pyquaternion _normalise(): only when |1 - sum of squares| >= 1e-14
+  const double ss = w * w + x * x + y * y + z * z;
+  if (!(fabs(1.0 - ss) < 1e-14) && ss > 0.0) {
+    const double n = sqrt(ss);
+    w /= n; x /= n; y /= n; z /= n;
+  }
+}
+
+__global__ void __launch_bounds__(256) format_boxes_kernel(const float* __restrict__ box3d, const float* __restrict__ quat_global,
+                                                           const float* __restrict__ speed, double* __restrict__ out, int n, double inv_w,
+                                                           double inv_x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* b = box3d + (long)i * 10;
+  const double PI = 3.141592653589793;
+  double w = b[0], x = b[1], y = b[2], z = b[3];
+  const float tx = b[4], tz = b[6], sw = b[7], sl = b[8], sh = b[9];
+  const float ty = b[5] + sh / 2.0f;  // tvec += [0, H/2, 0] stays float32 (in-place add on a float32 array)
+  // inversion * quat with inversion = (inv_w, inv_x, 0, 0): rows of pyquaternion's _q_matrix() times q
+  double rw = inv_w * w - inv_x * x, rx = inv_x * w + inv_w * x, ry = inv_w * y - inv_x * z, rz = inv_x * y + inv_w * z;
+  quat_unit(rw, rx, ry, rz);
+  const double nv = sqrt(rx * rx + ry * ry + rz * rz);
+  const bool axis_z_pos = nv < 1e-17 ? false : (rz / nv > 0.0);
+  double ang = 2.0 * atan2(nv, rw) + PI;  // _wrap_angle: ((theta + pi) % 2pi) - pi, -pi -> pi
+  ang = fmod(ang, 2.0 * PI) - PI;  // the operand is positive, where Python's % is fmod
+  if (ang == -PI) ang = PI;
+  const double rot_y = axis_z_pos ? -ang : ang;
+  const double theta = atan2(fabs((double)tx), fabs((double)tz));
+  double alpha = tx < 0.f ? rot_y + theta : rot_y - theta;
+  if (alpha > PI) alpha -= 2.0 * PI;
+  else if (alpha < -PI) alpha += 2.0 * PI;
+  alpha = rint(alpha * 100.0) / 100.0;  // np.around(alpha, 2)
+  double* o = out + (long)i * 10;
+  o[0] = sw; o[1] = sl; o[2] = sh; o[3] = tx; o[4] = ty; o[5] = tz; o[6] = rot_y; o[7] = alpha;
+  double vx = 0.0, vy = 0.0;
+  if (quat_global != nullptr && speed != nullptr) {
+    // speed * Quaternion(q).rotation_matrix.T[0]: first column of (Q Qbar^T)[1:, 1:]
+    double gw = quat_global[i * 4 + 0], gx = quat_global[i * 4 + 1], gy = quat_global[i * 4 + 2], gz = quat_global[i * 4 + 3];
+    quat_unit(gw, gx, gy, gz);
+    const double s = speed[i];
+    vx = s * (gx * gx + gw * gw - gz * gz - gy * gy);
+    vy = s * (gy * gx + gz * gw + gw * gz + gx * gy);
+  }
+  o[8] = vx; o[9] = vy;
+}
+
 }  // namespace dd3d
 
 extern "C" int dd3d_rotate_iou_eval(const float* boxes, const float* qboxes, float* out, int32_t N, int32_t K, int32_t criterion, void* stream) {
@@ -191,4 +244,16 @@ extern "C" int dd3d_image_box_overlap(const float* boxes, const float* qboxes, f
   hipLaunchKernelGGL(image_overlap_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), boxes, qboxes, out,
                      N, K, criterion);
   return check_launch("image_overlap_kernel");
+}
+
+extern "C" int dd3d_format_boxes3d(const float* box3d, const float* quat_global, const float* speed, double* out, int32_t n, void* stream) {
+  using namespace dd3d;
+  if (n == 0) return DD3D_OK;
+  DD3D_REQUIRE(box3d && out && n > 0, "dd3d_format_boxes3d: null pointer or negative size");
+  DD3D_REQUIRE((quat_global == nullptr) == (speed == nullptr), "dd3d_format_boxes3d: quat_global and speed go together");
+  // Quaternion(axis=[1,0,0], radians=pi/2).inverse = conj(cos(pi/4), sin(pi/4), 0, 0) / sum of squares
+  const double c = cos(M_PI / 4.0), sn = sin(M_PI / 4.0), ss = c * c + sn * sn;
+  hipLaunchKernelGGL(format_boxes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), box3d, quat_global,
+                     speed, out, n, c / ss, -sn / ss);
+  return check_launch("format_boxes_kernel");
 }

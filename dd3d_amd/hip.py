@@ -108,7 +108,8 @@ class BevArgs(C.Structure):
 EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
-    "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8"
+    "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8",
+    "dd3d_format_boxes3d"
 ]
 
 
@@ -155,6 +156,7 @@ def lib():
     L.dd3d_image_box_overlap.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p]
     L.dd3d_aligned_bilinear_scale.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_float, C.c_void_p]
     L.dd3d_resize_bilinear_u8.argtypes = [C.POINTER(ResizeArgs), C.c_void_p]
+    L.dd3d_format_boxes3d.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the .so is stale
     assert L.dd3d_abi_version() == 1, "libdd3d_hip.so ABI version mismatch; rebuild"

@@ -356,6 +356,17 @@ int dd3d_d3_box_overlap(const float* boxes, const float* qboxes, float* rinc, in
                         int32_t camera_coordinate, void* stream);
 int dd3d_image_box_overlap(const float* boxes, const float* qboxes, float* out, int32_t N, int32_t K, int32_t criterion, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Result formatting for the evaluators.  Replaces the per-box host loops of
+ * tridet/evaluators/kitti_3d_evaluator.py:205-264 (convert_3d_box_to_kitti, called once per detection at :120 and per annotation
+ * at :145) and tridet/evaluators/nuscenes_evaluator.py:196-198 (global velocity = speed * first column of R(quat_global)).
+ *   box3d        [n][10] float32 = Boxes3D.vectorize(): quat (w,x,y,z), tvec (3), size (W,L,H)   (boxes3d.py:142-144)
+ *   quat_global  [n][4] float32 and speed [n] float32, or both NULL (KITTI)
+ *   out          [n][10] float64 = (W, L, H, x, y, z, rot_y, alpha, vx, vy); alpha rounded to 2 decimals like the reference
+ * Arithmetic is float64 (the reference's numpy / pyquaternion path), x / y / z stay float32 values like the reference's in-place add.
+ * ------------------------------------------------------------------------------------------------ */
+int dd3d_format_boxes3d(const float* box3d, const float* quat_global, const float* speed, double* out, int32_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

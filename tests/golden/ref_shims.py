@@ -412,6 +412,15 @@ class Quaternion:
                 s = 2.0 * np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1])
                 q = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
             self.q = np.asarray(q, dtype=np.float64)
+        elif "axis" in kwargs:
+            # pyquaternion._from_axis_angle: axis normalised unless |1 - |axis|^2| <= 1e-12; q = (cos(a/2), axis sin(a/2))
+            import math
+            axis = np.asarray(kwargs["axis"], dtype=np.float64)
+            angle = kwargs["radians"] if "radians" in kwargs else kwargs.get("angle", np.deg2rad(kwargs.get("degrees", 0.0)))
+            mag_sq = float(axis @ axis)
+            if abs(1.0 - mag_sq) > 1e-12:
+                axis = axis / math.sqrt(mag_sq)
+            self.q = np.concatenate([[math.cos(angle / 2.0)], axis * math.sin(angle / 2.0)])
         elif len(args) == 1 and isinstance(args[0], Quaternion):
             self.q = args[0].q.copy()
         elif len(args) == 1:
@@ -436,6 +445,29 @@ class Quaternion:
     def inverse(self):
         import numpy as np
         return Quaternion(self.q * np.array([1.0, -1.0, -1.0, -1.0]) / float(self.q @ self.q))
+
+    def _normalise(self):
+        """pyquaternion: in place, only when the quaternion is not unit within 1e-14."""
+        import math
+        ss = float(self.q @ self.q)
+        if not abs(1.0 - ss) < 1e-14 and ss > 0:
+            self.q = self.q / math.sqrt(ss)
+
+    @property
+    def axis(self):
+        import numpy as np
+        self._normalise()
+        n = np.linalg.norm(self.q[1:])
+        return np.zeros(3) if n < 1e-17 else self.q[1:] / n
+
+    @property
+    def angle(self):
+        import math
+        import numpy as np
+        self._normalise()
+        theta = 2.0 * math.atan2(np.linalg.norm(self.q[1:]), self.q[0])
+        r = ((theta + math.pi) % (2 * math.pi)) - math.pi  # _wrap_angle
+        return math.pi if r == -math.pi else r
 
     @property
     def rotation_matrix(self):
