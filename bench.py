@@ -8,7 +8,9 @@ A step = one forward pass of the hot path (uint8 image already resident in HBM -
 batch of synthetic 384x1280 KITTI-shaped frames, ``--batch`` images per GPU (default 1 = BASELINE.json configs[1]
 "DD3D-DLA34 KITTI3D 384x1280 bs=1 fp32 inference"; one image per GPU per step as the north star shards them).
 For N > 1 every rank forwards its own images and the step includes the RCCL all_gather of the decoded candidates and
-the batched NMS over all N*batch images (dd3d_amd/parallel.py).
+the batched NMS over all N*batch images (dd3d_amd/parallel.py).  Steps are issued through PipelinedForward (two plan slots: the
+exchange + NMS of step i run on a second stream under the trunk of step i+1; `--pipeline 0` issues one step at a time); every one
+of the K timed steps is complete before the closing synchronize.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch,
 conv_igemm_bf16x3_kernel<2,2,4,2,2,2,1,false> in the default split-bf16 arithmetic): algorithmic FLOPs of one launch / its mean
@@ -43,6 +45,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DD3D_BENCH_PIPELINE", "2")),
+                    help="plan slots of dd3d_amd.parallel.PipelinedForward (exchange + NMS of step i overlap the trunk of step i+1); "
+                         "0 = one step at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=5)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_tower_hbm_bytes.json"),
@@ -75,7 +80,7 @@ def main():
     args = parse_args()
     from dd3d_amd import build_model, get_cfg, hip
     from dd3d_amd.engine import ConvOp
-    from dd3d_amd.parallel import DistributedForward, init_distributed
+    from dd3d_amd.parallel import DistributedForward, PipelinedForward, init_distributed
     from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
     import torch.distributed as dist
 
@@ -90,9 +95,14 @@ def main():
     model.load_state_dict(sd)
     B = args.batch
     inputs = make_inputs(B, args.height, args.width, seed=1000 + rank * B)
-    runner = DistributedForward(model, B, *_padded(model, args.height, args.width), use_graph=not args.no_graph)
-    plan = runner.plan
-    model.stage_inputs(inputs, plan=plan)  # H2D once: inputs are resident in HBM when the timed region starts
+    if args.pipeline > 0:
+        runner = PipelinedForward(model, B, *_padded(model, args.height, args.width), depth=args.pipeline)
+        plan = runner.plan
+        runner.stage_all(inputs)
+    else:
+        runner = DistributedForward(model, B, *_padded(model, args.height, args.width), use_graph=not args.no_graph)
+        plan = runner.plan
+        model.stage_inputs(inputs, plan=plan)  # H2D once: inputs are resident in HBM when the timed region starts
     torch.cuda.synchronize()
 
     def barrier():
@@ -131,7 +141,7 @@ def main():
             "workload": f"DD3D-DLA34 KITTI3D {args.height}x{args.width} bs={B}/GPU fp32 inference (BASELINE.json configs[1]); "
                         "uint8 image in HBM -> normalise/pad -> DLA-34 -> FPN P3-P7 -> FCOS2D/3D heads -> select/decode -> NMS",
             "global_batch": world * B, "parallelism": f"dp{world}" + ("+rccl_allgather_candidates" if world > 1 else ""),
-            "hip_graph": not args.no_graph, "gflop_per_image": GFLOP_PER_IMAGE,
+            "hip_graph": not args.no_graph, "pipeline_slots": args.pipeline, "gflop_per_image": GFLOP_PER_IMAGE,
             "achieved_tflops_per_gpu": round(value / world * GFLOP_PER_IMAGE / 1e3, 2),
             "math": "bf16x3" if x3 else "f32",
             "frac_of_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4),

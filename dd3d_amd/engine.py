@@ -438,7 +438,7 @@ class PlanBase:
 
     def capture(self):
         """Capture the whole launch sequence into one hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture)."""
-        assert self.world_size == 1, "graph capture is per-phase in multi-GPU mode (see dd3d_amd.parallel)"
+        assert not getattr(self, "exchange", False), "graph capture is per-phase in multi-GPU mode (see dd3d_amd.parallel)"
         self.launch()  # warm-up: sets kernel attributes, faults pages
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -463,8 +463,11 @@ class PlanBase:
 
 class ForwardPlan(PlanBase):
     """Static launch plan of DD3D.forward (inference) for one (B, Hp, Wp)."""
-    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0):
+    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0, exchange=None):
         super().__init__(device or model.device, dry_run=dry_run)
+        # the candidate exchange between select/decode and NMS exists when there are several ranks; `exchange=True` keeps its
+        # buffers and the two-phase launch for one rank too (single-GPU check of the RCCL transport, tests/gpu_rccl_check.py)
+        self.exchange = world_size > 1 if exchange is None else bool(exchange)
         self._trunk(model, B, Hp, Wp)
         # ---- heads + post-processing
         self._heads(model, self.features)
@@ -913,7 +916,7 @@ class ForwardPlan(PlanBase):
         # NMS over G images (G = B locally; B * world_size after the RCCL gather, see dd3d_amd.parallel)
         self.G = G = B * world_size
         self.world_size = world_size
-        if world_size > 1:
+        if self.exchange:
             self.cand_all = torch.zeros((G, hip.CAND_FIELDS, NS), dtype=torch.float32, device=dev)
             self.counts_all = torch.zeros((G, L), dtype=torch.int32, device=dev)
             self.outsize_all = torch.zeros((G, 4), dtype=torch.float32, device=dev)

@@ -87,12 +87,13 @@ class DD3D(nn.Module):
         inf.DO_BEV_NMS, inf.BEV_NMS_IOU_THRESH = bool(self.do_bev_nms), float(self.bev_nms_iou_thresh)
         return (bool(self.postprocess_in_inference), bool(self.do_nms), bool(self.do_bev_nms))
 
-    def get_plan(self, B, Hp, Wp, world_size=1, rank=0):
-        key = (B, Hp, Wp, world_size, rank, self.math) + self._sync_flags()
+    def get_plan(self, B, Hp, Wp, world_size=1, rank=0, exchange=None):
+        exchange = world_size > 1 if exchange is None else bool(exchange)
+        key = (B, Hp, Wp, world_size, rank, exchange, self.math) + self._sync_flags()
         plan = self._plans.get(key)
         if plan is None:
-            plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank)
-            if self.use_graph and world_size == 1:
+            plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank, exchange=exchange)
+            if self.use_graph and not exchange:
                 plan.capture()
             self._plans[key] = plan
         return plan
@@ -151,7 +152,7 @@ class DD3D(nn.Module):
         if n_max > plan.det_cap:
             raise RuntimeError(f"{n_max} detections exceed the detection buffer ({plan.det_cap}); raise det_cap")
         det = plan.det[:, :max(n_max, 1)]
-        inv_K = plan.inv_K.view(-1, 3, 3)
+        inv_K = plan.inv_K.view(-1, 3, 3).clone()  # the results must not alias a buffer the next forward overwrites
         results = []
         for i, (inp, isz) in enumerate(zip(batched_inputs, image_sizes)):
             g = first + i

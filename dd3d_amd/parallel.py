@@ -58,15 +58,17 @@ def gather_candidates(pairs, group=None):
 class DistributedForward:
     """Drives a ``ForwardPlan(world_size=W)``: [hipGraph: preprocess .. select/decode] -> RCCL all_gather ->
     [batched NMS over all W*B images].  Every rank ends up with every image's detections and returns its own."""
-    def __init__(self, model, B, Hp, Wp, use_graph=True):
+    def __init__(self, model, B, Hp, Wp, use_graph=True, force_exchange=False):
         self.model = model
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # one rank: the whole forward is one hipGraph, unless `force_exchange` keeps the two-phase step (RCCL check on one GPU)
+        self.exchange = self.world > 1 or bool(force_exchange)
         model.use_graph = use_graph
-        self.plan = p = model.get_plan(B, Hp, Wp, world_size=self.world, rank=self.rank)  # world 1: the whole forward is one hipGraph
+        self.plan = p = model.get_plan(B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
         self.B = B
         self.pre_graph = self.post_graph = None
-        if use_graph and self.world > 1:
+        if use_graph and self.exchange:
             # the collective sits between two captured halves
             p.launch()
             torch.cuda.synchronize()
@@ -78,7 +80,7 @@ class DistributedForward:
 
     def step(self):
         p = self.plan
-        if self.world == 1:
+        if not self.exchange:
             p.run()
             return
         if self.pre_graph is not None:
@@ -95,3 +97,94 @@ class DistributedForward:
         plan, image_sizes = self.model.stage_inputs(batched_inputs, plan=self.plan)
         self.step()
         return self.model.collect(plan, batched_inputs, image_sizes, first=self.rank * self.B)
+
+
+class PipelinedForward:
+    """Throughput mode of the same step: `depth` plan slots (each with its own buffers and its own pair of captured hipGraph
+    halves); the trunk + heads + select/decode of step i+1 run on the compute stream while the candidate exchange (RCCL) and the NMS
+    stages of step i run on the post stream, so the collective and the latency-bound tail never stall the MFMA kernels.
+    Results are identical to `DistributedForward` (same kernels, same buffers per slot); only the order on the device changes.
+
+        h = runner.submit(batched_inputs)   # stages the inputs, enqueues both halves, returns at once
+        out = runner.result(h)              # waits for that step only
+    """
+    def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False):
+        from dd3d_amd.engine import ForwardPlan
+        assert depth >= 1
+        self.model = model
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.exchange = self.world > 1 or bool(force_exchange)
+        self.B = B
+        model._sync_flags()
+        self.compute_stream, self.post_stream = torch.cuda.Stream(), torch.cuda.Stream()
+        self.slots = []
+        for _ in range(depth):
+            p = ForwardPlan(model, B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
+            p.launch()  # warm-up outside capture
+            torch.cuda.synchronize()
+            pre, post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(pre):
+                p.launch(0, p.num_pre_nms_ops)
+            with torch.cuda.graph(post):
+                p.launch(p.num_pre_nms_ops)
+            slot = type("Slot", (), {})()
+            slot.plan, slot.pre_graph, slot.post_graph = p, pre, post
+            slot.pre_done, slot.post_done, slot.released = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            slot.post_done.record()
+            slot.released.record()
+            slot.inputs = slot.image_sizes = None
+            self.slots.append(slot)
+        torch.cuda.synchronize()
+        self.plan = self.slots[0].plan
+        self._next = 0
+
+    def _enqueue(self, slot):
+        cs, ps = self.compute_stream, self.post_stream
+        with torch.cuda.stream(cs):
+            slot.pre_graph.replay()
+            slot.pre_done.record(cs)
+        ps.wait_event(slot.pre_done)
+        ps.wait_event(slot.released)
+        with torch.cuda.stream(ps):
+            if self.exchange:
+                gather_candidates(slot.plan.gather_pairs())
+            slot.post_graph.replay()
+            slot.post_done.record(ps)
+
+    def _acquire(self):
+        slot = self.slots[self._next % len(self.slots)]
+        self._next += 1
+        # the slot's previous step must be over before its buffers are rewritten (a no-op wait when it finished long ago)
+        self.compute_stream.wait_event(slot.post_done)
+        self.compute_stream.wait_event(slot.released)
+        return slot
+
+    def step(self):
+        """One step on inputs already resident in the slot's buffers (bench: `stage_all`)."""
+        slot = self._acquire()
+        self._enqueue(slot)
+        return slot
+
+    def stage_all(self, batched_inputs):
+        for slot in self.slots:
+            self.model.stage_inputs(batched_inputs, plan=slot.plan)
+        torch.cuda.synchronize()
+
+    def submit(self, batched_inputs):
+        slot = self._acquire()
+        with torch.cuda.stream(self.compute_stream):
+            _, slot.image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan)
+        slot.inputs = batched_inputs
+        self._enqueue(slot)
+        return slot
+
+    def result(self, slot):
+        slot.post_done.synchronize()
+        out = self.model.collect(slot.plan, slot.inputs, slot.image_sizes, first=self.rank * self.B)
+        slot.released.record()  # the copies out of the detection buffer are enqueued: later steps of this slot order after them
+        return out
+
+    def synchronize(self):
+        self.compute_stream.synchronize()
+        self.post_stream.synchronize()

@@ -46,6 +46,24 @@ def _worker(rank, world, port, ret):
         counts = runner.plan.det_count.cpu().tolist()
         ok &= len(counts) == world * B and all(c > 0 for c in counts)
         dist.barrier()
+    # throughput mode: two plan slots, exchange + NMS of one step under the trunk of the next, several steps in flight
+    from dd3d_amd.parallel import PipelinedForward
+    stream = [make_inputs(B, H, W, seed=50 + 10 * i + rank * B) for i in range(4)]
+    refs = [single(x) for x in stream]
+    piped = PipelinedForward(model, B, H + (-H) % 128, W + (-W) % 128, depth=2)
+    handles = [piped.submit(x) for x in stream[:2]]
+    outs = []
+    for x in stream[2:]:
+        outs.append(piped.result(handles.pop(0)))
+        handles.append(piped.submit(x))
+    outs += [piped.result(h) for h in handles]
+    for out, ref in zip(outs, refs):
+        for o, r in zip(out, ref):
+            a, b = o["instances"], r["instances"]
+            ok &= len(a) == len(b) and len(a) > 0
+            ok &= torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores_3d, b.scores_3d)
+            ok &= torch.equal(a.pred_boxes3d.quat, b.pred_boxes3d.quat)
+    dist.barrier()
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

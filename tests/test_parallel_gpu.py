@@ -1,5 +1,6 @@
 """N > 1 code path on the GPU: two processes share the one GPU of the test box; gloo (host-staged) carries the candidate gather,
-everything else -- the two captured hipGraph halves, NMS over all W*B images, rank-offset collect -- is the product path."""
+everything else -- the two captured hipGraph halves, NMS over all W*B images, rank-offset collect -- is the product path.  The RCCL
+transport itself is exercised with a single-rank "nccl" group between the same two graph halves."""
 import os
 import subprocess
 import sys
@@ -14,3 +15,19 @@ def test_two_ranks_on_one_gpu_match_single_rank(hiplib):
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_dist_check.py"), "2"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "dist check: {" in r.stdout and "False" not in r.stdout.split("dist check:")[-1]
+
+
+def test_rccl_transport_single_rank(hiplib):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_rccl_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rccl check: ok=True" in r.stdout
+
+
+@pytest.mark.parametrize("mode", ["", "nccl"])
+def test_pipelined_forward_equals_stepwise(hiplib, mode):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tests", "gpu_pipeline_check.py")] + ([mode] if mode else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ok=True" in r.stdout
