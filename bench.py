@@ -8,9 +8,10 @@ A step = one forward pass of the hot path (uint8 image already resident in HBM -
 batch of synthetic 384x1280 KITTI-shaped frames, ``--batch`` images per GPU (default 1 = BASELINE.json configs[1]
 "DD3D-DLA34 KITTI3D 384x1280 bs=1 fp32 inference"; one image per GPU per step as the north star shards them).
 For N > 1 every rank forwards its own images and the step includes the RCCL all_gather of the decoded candidates and
-the batched NMS over all N*batch images (dd3d_amd/parallel.py).  Steps are issued through PipelinedForward (two plan slots: the
-exchange + NMS of step i run on a second stream under the trunk of step i+1; `--pipeline 0` issues one step at a time); every one
-of the K timed steps is complete before the closing synchronize.
+the batched NMS over all N*batch images (dd3d_amd/parallel.py).  Steps are issued through PipelinedForward (default: four plan
+slots on four compute streams + one exchange/NMS stream, so several single-image steps are in flight and share the chip, and the
+collective runs under the next steps' trunks; `--pipeline 0` issues one step at a time and that figure is also reported in
+`config`); every one of the K timed steps does all of its work and is complete before the closing synchronize.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch,
 conv_igemm_bf16x3_kernel<2,2,4,2,2,2,1,false> in the default split-bf16 arithmetic): algorithmic FLOPs of one launch / its mean
@@ -45,9 +46,11 @@ def parse_args():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DD3D_BENCH_PIPELINE", "2")),
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DD3D_BENCH_PIPELINE", "4")),
                     help="plan slots of dd3d_amd.parallel.PipelinedForward (exchange + NMS of step i overlap the trunk of step i+1); "
                          "0 = one step at a time")
+    ap.add_argument("--compute-streams", type=int, default=int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "4")),
+                    help="PipelinedForward: streams the slots' trunks are issued on (> 1 lets consecutive steps share the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=5)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_tower_hbm_bytes.json"),
@@ -96,7 +99,8 @@ def main():
     B = args.batch
     inputs = make_inputs(B, args.height, args.width, seed=1000 + rank * B)
     if args.pipeline > 0:
-        runner = PipelinedForward(model, B, *_padded(model, args.height, args.width), depth=args.pipeline)
+        runner = PipelinedForward(model, B, *_padded(model, args.height, args.width), depth=args.pipeline,
+                                  compute_streams=min(args.compute_streams, args.pipeline))
         plan = runner.plan
         runner.stage_all(inputs)
     else:
@@ -128,6 +132,21 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    # for transparency: the same forward issued strictly one step at a time on one stream (not part of the timed region)
+    serial_ms = None
+    if world == 1 and args.pipeline > 0:
+        slot = runner.slots[0]
+        for _ in range(5):
+            slot.pre_graph.replay()
+            slot.post_graph.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            slot.pre_graph.replay()
+            slot.post_graph.replay()
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t1) / 50 * 1e3
+
     x3 = plan.math == hip.MATH_BF16X3
     # "f32x3bf16": every f32 operand split exactly into 3 bf16 terms, 6 cross products on the bf16 matrix pipe, f32
     # accumulation -- agrees with the f32-MFMA path to f32 rounding level (tests/test_conv_gpu.py); stem / N<=32 convs are f32 MFMA
@@ -141,9 +160,14 @@ def main():
             "workload": f"DD3D-DLA34 KITTI3D {args.height}x{args.width} bs={B}/GPU fp32 inference (BASELINE.json configs[1]); "
                         "uint8 image in HBM -> normalise/pad -> DLA-34 -> FPN P3-P7 -> FCOS2D/3D heads -> select/decode -> NMS",
             "global_batch": world * B, "parallelism": f"dp{world}" + ("+rccl_allgather_candidates" if world > 1 else ""),
-            "hip_graph": not args.no_graph, "pipeline_slots": args.pipeline, "gflop_per_image": GFLOP_PER_IMAGE,
+            "hip_graph": not args.no_graph, "pipeline_slots": args.pipeline, "compute_streams": args.compute_streams if args.pipeline else 1, "gflop_per_image": GFLOP_PER_IMAGE,
             "achieved_tflops_per_gpu": round(value / world * GFLOP_PER_IMAGE / 1e3, 2),
             "math": "bf16x3" if x3 else "f32",
+            "issue": (f"{args.pipeline} plan slots on {min(args.compute_streams, args.pipeline)} compute streams + 1 exchange/NMS stream "
+                      "(dd3d_amd.parallel.PipelinedForward): several single-image steps in flight share the chip; every step does all "
+                      "of its work and all K steps are complete at the closing synchronize") if args.pipeline else "one step at a time",
+            "ms_per_step_one_at_a_time": None if serial_ms is None else round(serial_ms, 4),
+            "images_per_s_one_at_a_time": None if serial_ms is None else round(B / serial_ms * 1e3, 2),
             "frac_of_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4),
         },
     }

@@ -108,16 +108,18 @@ class PipelinedForward:
         h = runner.submit(batched_inputs)   # stages the inputs, enqueues both halves, returns at once
         out = runner.result(h)              # waits for that step only
     """
-    def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False):
+    def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1):
         from dd3d_amd.engine import ForwardPlan
-        assert depth >= 1
+        assert depth >= 1 and compute_streams >= 1
         self.model = model
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.exchange = self.world > 1 or bool(force_exchange)
         self.B = B
         model._sync_flags()
-        self.compute_stream, self.post_stream = torch.cuda.Stream(), torch.cuda.Stream()
+        # compute_streams > 1: consecutive steps' trunks are issued on different streams and may share the chip
+        self.compute_streams = [torch.cuda.Stream() for _ in range(compute_streams)]
+        self.post_stream = torch.cuda.Stream()
         self.slots = []
         for _ in range(depth):
             p = ForwardPlan(model, B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
@@ -134,13 +136,14 @@ class PipelinedForward:
             slot.post_done.record()
             slot.released.record()
             slot.inputs = slot.image_sizes = None
+            slot.compute_stream = self.compute_streams[len(self.slots) % compute_streams]
             self.slots.append(slot)
         torch.cuda.synchronize()
         self.plan = self.slots[0].plan
         self._next = 0
 
     def _enqueue(self, slot):
-        cs, ps = self.compute_stream, self.post_stream
+        cs, ps = slot.compute_stream, self.post_stream
         with torch.cuda.stream(cs):
             slot.pre_graph.replay()
             slot.pre_done.record(cs)
@@ -156,8 +159,8 @@ class PipelinedForward:
         slot = self.slots[self._next % len(self.slots)]
         self._next += 1
         # the slot's previous step must be over before its buffers are rewritten (a no-op wait when it finished long ago)
-        self.compute_stream.wait_event(slot.post_done)
-        self.compute_stream.wait_event(slot.released)
+        slot.compute_stream.wait_event(slot.post_done)
+        slot.compute_stream.wait_event(slot.released)
         return slot
 
     def step(self):
@@ -173,7 +176,7 @@ class PipelinedForward:
 
     def submit(self, batched_inputs):
         slot = self._acquire()
-        with torch.cuda.stream(self.compute_stream):
+        with torch.cuda.stream(slot.compute_stream):
             _, slot.image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan)
         slot.inputs = batched_inputs
         self._enqueue(slot)
@@ -186,5 +189,6 @@ class PipelinedForward:
         return out
 
     def synchronize(self):
-        self.compute_stream.synchronize()
+        for cs in self.compute_streams:
+            cs.synchronize()
         self.post_stream.synchronize()
