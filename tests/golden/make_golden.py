@@ -37,15 +37,19 @@ CASES = {
     "dla34_nusc_128x224_b6": ("dd3d_nusc_dla34", "dla34_nusc", 6, 128, 224, False),
     # DD3D.INFERENCE.DO_BEV_NMS on top (per-image BEV NMS before the resize, core.py:135-150)
     "dla34_nusc_128x224_b6_bevnms": ("dd3d_nusc_dla34", "dla34_nusc", 6, 128, 224, False),
+    # BASELINE.json configs[3]: NuscenesDD3D on the V2-99 backbone (levels p2-p6, canvas padded to /64)
+    "v99_nusc_64x128_b6": ("dd3d_nusc_v99", "v99_nusc", 6, 64, 128, False),
 }
 # the 128x224 images yield few candidates at the default threshold; lower it so that the BEV stages have work to do.  The
 # second case also trips the per-sample cap (nuscenes_dd3d.py:333, postprocessing.py:93-94).
 EXTRA_OVERRIDES = {
     "dla34_nusc_128x224_b6": {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}}},
+    "v99_nusc_64x128_b6": {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}}},
     "dla34_nusc_128x224_b6_bevnms": {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}, "INFERENCE": {"DO_BEV_NMS": True},
                                               "NUSC": {"INFERENCE": {"MAX_NUM_DETS_PER_SAMPLE": 60}}}},
 }
 DETECTIONS_ONLY = {"dla34_nusc_128x224_b6_bevnms"}  # same head maps as the case above
+NO_FEATURES = {"v99_nusc_64x128_b6"}  # the V2-99 features are covered by the KITTI case; keeps the fixture small
 
 
 def build_reference_model(cfg):
@@ -158,7 +162,7 @@ def main(only=None):
                     out[f"attr{l}"], out[f"speed{l}"] = ref.attr_logits(t).numpy(), ref.speed(t).numpy()
             out["images"] = il.tensor.numpy()
             for l in range(len(feats) if name not in DETECTIONS_ONLY else 0):
-                if l >= 2:  # the fine levels are large; their content is covered by the head maps below
+                if l >= 2 and name not in NO_FEATURES:  # the fine levels are large; their content is covered by the head maps below
                     out[f"feat{l}"] = feats[l].numpy()
                 out[f"logits{l}"], out[f"box2d_reg{l}"], out[f"centerness{l}"] = logits[l].numpy(), box2d_reg[l].numpy(), centerness[l].numpy()
                 out[f"quat{l}"], out[f"ctr{l}"], out[f"depth{l}"] = quat[l].numpy(), ctr[l].numpy(), depth[l].numpy()

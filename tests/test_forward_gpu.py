@@ -171,7 +171,8 @@ def test_error_behaviour(hiplib, kitti_dla34):
 
 
 @pytest.mark.parametrize(
-    "name", ["dla34_kitti_128x256_b1", "dla34_kitti_128x384_b2_ragged", "v99_kitti_128x256_b1", "dla34_nusc_128x224_b6", "dla34_nusc_128x224_b6_bevnms"]
+    "name", ["dla34_kitti_128x256_b1", "dla34_kitti_128x384_b2_ragged", "v99_kitti_128x256_b1", "dla34_nusc_128x224_b6", "dla34_nusc_128x224_b6_bevnms",
+             "v99_nusc_64x128_b6"]
 )
 def test_hip_matches_reference_golden(hiplib, name):
     """HIP path vs the committed golden vectors (produced by the reference's own DD3D.forward, tests/golden/make_golden.py):
