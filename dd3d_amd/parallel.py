@@ -26,8 +26,12 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            # DD3D_DIST_BACKEND=gloo: test transport for driving the N > 1 path with several ranks on ONE GPU (host-staged gather);
+            # the ranks then share the visible devices round-robin
+            backend = os.environ.get("DD3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            if backend != "nccl":
+                local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():

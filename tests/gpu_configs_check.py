@@ -18,9 +18,8 @@ from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict  # noqa:
 
 CASES = [("dd3d_kitti_v99", "v99_kitti", "kitti", 1, 384, 1280), ("dd3d_kitti_v99", "v99_kitti", "kitti", 4, 384, 1280),
          ("dd3d_nusc_dla34", "dla34_nusc", "nusc", 6, 896, 1600), ("dd3d_kitti_dla34", "dla34_kitti", "kitti", 8, 384, 1280),
-         # BASELINE.json configs[3] per GPU: V2-99 on one 6-camera nuScenes sample (900 x 1600 -> 896 x 1593, padded to /64); synthetic
-         # weights with the KITTI calibration of the same layer names
-         ("dd3d_nusc_v99", "v99_kitti", "nusc", 6, 896, 1600)]
+         # BASELINE.json configs[3] per GPU: V2-99 on one 6-camera nuScenes sample (900 x 1600 -> 896 x 1593, padded to /64)
+         ("dd3d_nusc_v99", "v99_nusc", "nusc", 6, 896, 1600)]
 
 
 def main():
