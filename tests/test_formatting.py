@@ -135,7 +135,7 @@ def _instances(rec, device, nusc):
 
 
 @pytest.mark.gpu
-def test_gpu_convert_matches_reference(golden):
+def test_gpu_convert_matches_reference(golden, hiplib):
     from dd3d_amd.evaluators import convert_3d_box_to_kitti, format_boxes3d
     from dd3d_amd.structures import GenericBoxes3D
     v = torch.tensor(golden["convert"]["box3d_vec"], dtype=torch.float32, device="cuda")
@@ -150,7 +150,7 @@ def test_gpu_convert_matches_reference(golden):
 
 
 @pytest.mark.gpu
-def test_gpu_kitti_process_matches_reference(golden, tmp_path):
+def test_gpu_kitti_process_matches_reference(golden, tmp_path, hiplib):
     from dd3d_amd.evaluators import KITTI3DEvaluator
     k = golden["kitti"]
     ev = KITTI3DEvaluator("kitti_3d_val", dataset_dicts=k["dataset_dicts"], class_names=k["class_names"])
@@ -170,7 +170,7 @@ def test_gpu_kitti_process_matches_reference(golden, tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_nusc_process_matches_reference(golden):
+def test_gpu_nusc_process_matches_reference(golden, hiplib):
     from dd3d_amd.evaluators import NuscenesEvaluator
     n = golden["nusc"]
     ev = NuscenesEvaluator("/nonexistent", "nusc_val", None)
