@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--compute-streams", type=int, default=int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "4")),
                     help="PipelinedForward: streams the slots' trunks are issued on (> 1 lets consecutive steps share the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-forwards", type=int, default=5)
+    ap.add_argument("--cpu-forwards", type=int, default=200, help="upper bound; the CPU leg stops after ~12 s of work")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_tower_hbm_bytes.json"),
                     help="optional PMC-derived HBM bytes per launch of the dominant kernel (see profiles/README.md)")
     return ap.parse_args()
@@ -225,7 +225,7 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(cfg, sd, args, budget_s=25.0):
+def cpu_baseline(cfg, sd, args, budget_s=12.0):
     """The oracle (oracle/dd3d_oracle.py, a torch-CPU fp32 restatement of the reference forward) on the host cores:
     one warm-up at 1/16 of the pixels, then single-image forwards of the bench workload until ~``budget_s`` of CPU
     time is spent (at least one, at most ``--cpu-forwards``)."""
