@@ -233,3 +233,30 @@ def test_checkpointer_load_like_fvcore(kitti_dla34, tmp_path):
     third = build_model(cfg)
     Checkpointer(third).load(out)
     assert all(torch.equal(a, b) for a, b in zip(third.state_dict().values(), dst.state_dict().values()))
+
+
+def test_header_is_plain_c_and_matches_the_ctypes_mirrors(tmp_path):
+    """include/dd3d_hip.h is the drop-in boundary: it must compile as C99 on its own, and every argument struct must have the
+    size and field offsets of its ctypes mirror in dd3d_amd/hip.py (a silent layout drift would corrupt kernel arguments)."""
+    import ctypes as C
+    import subprocess
+    from dd3d_amd import hip
+    mirrors = {"dd3d_conv_launch": hip.ConvLaunch, "dd3d_smallc_args": hip.SmallcArgs, "dd3d_resize_args": hip.ResizeArgs,
+               "dd3d_select_args": hip.SelectArgs, "dd3d_nms_args": hip.NmsArgs, "dd3d_bev_args": hip.BevArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dd3d_hip.h"', 'int main(void) {',
+             '  printf("dd3d_conv_seg %zu\\n", sizeof(dd3d_conv_seg));']
+    for cname, cls in mirrors.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname.rstrip("_")}));')  # `in_` mirrors C `in`
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "abi")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    out = dict(l.split() for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(out["dd3d_conv_seg"]) == hip.CONV_SEG_DTYPE.itemsize
+    for cname, cls in mirrors.items():
+        assert int(out[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
