@@ -260,3 +260,15 @@ def test_header_is_plain_c_and_matches_the_ctypes_mirrors(tmp_path):
         assert int(out[cname]) == C.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_integration_doc_stub_matches_the_abi():
+    """The reference-side ctypes stub printed in INTEGRATION.md must list dd3d_nms_args' fields exactly as the tested binding does."""
+    from dd3d_amd import hip
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class NmsArgs(C.Structure)"):doc.index("def nms_and_top_k_hip")]
+    fields = re.findall(r'\("([A-Za-z_0-9]+)", C\.(c_[a-z0-9_]+)\)', block)
+    import ctypes as C
+    assert [(n, getattr(C, t)) for n, t in fields] == list(hip.NmsArgs._fields_)
+    for name in re.findall(r"`(dd3d_[a-z0-9_]+)`", doc):
+        assert name in hip.EXPORTS or name in ("dd3d_hip", "dd3d_nms_args", "dd3d_amd"), name
