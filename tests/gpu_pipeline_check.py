@@ -1,7 +1,7 @@
 """PipelinedForward (two plan slots, exchange + NMS of step i under the trunk of step i+1) must return, for a stream of different
 inputs, exactly what the one-step-at-a-time forward returns; with `nccl` the exchange goes through a single-rank RCCL group.
 
-    python tests/gpu_pipeline_check.py [nccl]
+    python tests/gpu_pipeline_check.py [nccl | streams]
 """
 import os
 import socket
@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
-    use_nccl = len(sys.argv) > 1 and sys.argv[1] == "nccl"
+    mode = sys.argv[1] if len(sys.argv) > 1 else ""
+    use_nccl = mode == "nccl"
+    depth, streams = (4, 4) if mode == "streams" else (2, 1)  # "streams": the bench default, consecutive steps share the chip
     from dd3d_amd import build_model, get_cfg
     from dd3d_amd.parallel import PipelinedForward
     from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
@@ -34,12 +36,12 @@ def main():
     stream = [make_inputs(B, H, W, seed=10 + 7 * i) for i in range(7)]
     stream[3][1]["height"], stream[3][1]["width"] = 99, 201
     ref = [model(x) for x in stream]
-    runner = PipelinedForward(model, B, H + (-H) % 128, W + (-W) % 128, depth=2, force_exchange=use_nccl)
+    runner = PipelinedForward(model, B, H + (-H) % 128, W + (-W) % 128, depth=depth, force_exchange=use_nccl, compute_streams=streams)
     ok = True
-    # three steps in flight before the first result is read; then interleaved
-    handles = [runner.submit(x) for x in stream[:2]]
+    # `depth` steps in flight before the first result is read; then interleaved
+    handles = [runner.submit(x) for x in stream[:depth]]
     outs = []
-    for i in range(2, len(stream)):
+    for i in range(depth, len(stream)):
         outs.append(runner.result(handles.pop(0)))
         handles.append(runner.submit(stream[i]))
     outs += [runner.result(h) for h in handles]
@@ -60,7 +62,7 @@ def main():
     slot.inputs, slot.image_sizes = stream[0], [(H, W)] * B
     last = runner.result(slot)
     ok &= all(torch.equal(o["instances"].scores_3d, q["instances"].scores_3d) for o, q in zip(last, ref[0]))
-    print(f"pipeline check ({'nccl exchange' if use_nccl else 'single rank'}): ok={bool(ok)} detections={n_det}")
+    print(f"pipeline check ({'nccl exchange' if use_nccl else 'single rank'}, {depth} slots / {streams} compute streams): ok={bool(ok)} detections={n_det}")
     if use_nccl:
         dist.destroy_process_group()
     assert ok
