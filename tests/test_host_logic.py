@@ -272,3 +272,52 @@ def test_integration_doc_stub_matches_the_abi():
     assert [(n, getattr(C, t)) for n, t in fields] == list(hip.NmsArgs._fields_)
     for name in re.findall(r"`(dd3d_[a-z0-9_]+)`", doc):
         assert name in hip.EXPORTS or name in ("dd3d_hip", "dd3d_nms_args", "dd3d_amd"), name
+
+
+def test_kernel_register_budgets(hiplib, tmp_path):
+    """Static resource check of the built gfx950 code objects (llvm-readelf on the bundles of libdd3d_hip.so): the kernels on the
+    hot path must not spill to scratch and must fit the occupancy their launch geometry assumes.  Known exceptions are listed so
+    that a change that adds a new one fails here instead of showing up as an unexplained slowdown on the GPU."""
+    import shutil
+    import subprocess
+    from dd3d_amd import hip
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("ROCm llvm tools not installed")
+    so = str(tmp_path / "lib.so")
+    shutil.copy(hip.lib_path(), so)
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", so], check=True, capture_output=True)  # extracts next to `so`
+    kernels = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "hipv4-amdgcn-amd-amdhsa--gfx950" not in f:
+            continue
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        cur = {}
+        for line in notes.splitlines():
+            m = re.match(r"\s*-?\s*\.(agpr_count|name|private_segment_fixed_size|vgpr_count|group_segment_fixed_size):\s+(\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "agpr_count" and cur.get("name"):
+                kernels[cur["name"]] = cur
+                cur = {}
+            cur[m.group(1)] = m.group(2)
+        if cur.get("name"):
+            kernels[cur["name"]] = cur
+    assert len(kernels) > 80, len(kernels)
+    def short(mangled):  # _ZN4dd3d24conv_igemm_bf16x3_kernelILi2ELi2E...Lb0EEEv... -> ("conv_igemm_bf16x3_kernel", (2, 2, ..., 0))
+        m = re.match(r"_ZN4dd3d(\d+)", mangled)
+        name = mangled[m.end():m.end() + int(m.group(1))]
+        targs = re.match(r"I((?:L[ib]\d+E)+)E", mangled[m.end() + int(m.group(1)):])
+        return name, tuple(int(x) for x in re.findall(r"L[ib](\d+)E", targs.group(1))) if targs else ()
+
+    table = {short(k): v for k, v in kernels.items()}
+    vg = lambda k: int(table[k]["vgpr_count"]) + int(table[k].get("agpr_count", 0))  # noqa: E731
+    scratch = {k: int(v["private_segment_fixed_size"]) for k, v in table.items() if int(v["private_segment_fixed_size"]) > 0}
+    # rotated-IoU clipping keeps its polygon in a local array; the split-K variant of the 256x128 tile spills 9 registers
+    allowed = {("bev_mask_kernel", ()), ("rotate_iou_eval_kernel", ()), ("conv_igemm_bf16x3_kernel", (2, 2, 4, 2, 2, 2, 1, 1))}
+    assert set(scratch) <= allowed, scratch
+    towers = ("conv_igemm_bf16x3_kernel", (2, 2, 4, 2, 2, 2, 1, 0))  # 8 waves / block, two waves per SIMD
+    assert vg(towers) <= 256 and towers not in scratch, table[towers]
+    for k in table:  # every 8-wave split-bf16 tile shares a SIMD between two waves
+        if k[0] == "conv_igemm_bf16x3_kernel" and k[1][2] * k[1][3] == 8:
+            assert vg(k) <= 256, (k, vg(k))
