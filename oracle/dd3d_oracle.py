@@ -575,13 +575,13 @@ def dd3d_forward(sd, cfg, batched_inputs, hook=None, stop_after_heads=False):
     logits, box2d_reg, centerness, cls_tower_out = fcos2d_head(
         sd, features, cfg["DD3D"]["FCOS2D"]["NUM_CLS_CONVS"], hook=hook
     )
-    quat, ctr, depth, size, conf = fcos3d_head(sd, features, cfg["DD3D"]["FCOS3D"]["NUM_CONVS"], hook=hook)
-    stages.update(
-        logits=logits, box2d_reg=box2d_reg, centerness=centerness, quat=quat, ctr=ctr, depth=depth, size=size, conf=conf
-    )
+    stages.update(logits=logits, box2d_reg=box2d_reg, centerness=centerness)
+    if cfg["MODEL"]["BOX3D_ON"]:  # core.py:38-42,90-92: without it the model is `only_box2d`
+        quat, ctr, depth, size, conf = fcos3d_head(sd, features, cfg["DD3D"]["FCOS3D"]["NUM_CONVS"], hook=hook)
+        stages.update(quat=quat, ctr=ctr, depth=depth, size=size, conf=conf)
     if stop_after_heads:
         return None, stages
-    inv_intrinsics = intrinsics.inverse()  # core.py:93
+    inv_intrinsics = intrinsics.inverse()  # core.py:93 (the reference's ImageList.intrinsics fails without 'intrinsics' in the inputs)
     stages["inv_intrinsics"] = inv_intrinsics
     if cfg["DD3D"]["INFERENCE"]["DO_BEV_NMS"]:  # core.py:135-150 lives with the other BEV code
         from oracle.nuscenes_oracle import nuscenes_postprocess_from_heads
@@ -603,10 +603,11 @@ def dd3d_postprocess_from_heads(cfg, heads, locations, inv_intrinsics, image_siz
         r, info = fcos2d_inference_level(heads["logits"][l], heads["box2d_reg"][l], heads["centerness"][l], locations[l], cfg)
         for inst in r:
             inst["fpn_levels"] = torch.ones(len(inst["scores"]), dtype=torch.long) * l  # fcos2d.py:263-264
-        fcos3d_inference_level(
-            heads["quat"][l], heads["ctr"][l], heads["depth"][l], heads["size"][l], heads["conf"][l], inv_intrinsics, r,
-            info, cfg
-        )
+        if "quat" in heads:  # core.py:117-125 (not only_box2d)
+            fcos3d_inference_level(
+                heads["quat"][l], heads["ctr"][l], heads["depth"][l], heads["size"][l], heads["conf"][l], inv_intrinsics, r,
+                info, cfg
+            )
         pred.append(r)
         infos.append(info)
     B = len(image_sizes)
@@ -614,7 +615,8 @@ def dd3d_postprocess_from_heads(cfg, heads, locations, inv_intrinsics, image_siz
     stages = {"candidates": per_image, "level_info": infos}
     inf = cfg["DD3D"]["INFERENCE"]
     if inf["DO_NMS"]:
-        per_image = [nms_and_top_k(x, cfg, "scores_3d") for x in per_image]  # core.py:125,134-135
+        score_key = "scores_3d" if "quat" in heads else "scores"  # core.py:125-127
+        per_image = [nms_and_top_k(x, cfg, score_key) for x in per_image]  # core.py:134-135
     stages["after_nms"] = per_image
     results = []
     for inst, inp, isz in zip(per_image, batched_inputs, image_sizes):

@@ -190,8 +190,49 @@ def main(only=None):
         print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", [len(r["instances"]) for r in results])
 
 
+BOX2D_ONLY_OVERRIDES = {"MODEL": {"BOX3D_ON": False}}
+
+
+def box2d_only_golden():
+    """MODEL.BOX3D_ON False (core.py:38-42: `only_box2d`): no FCOS3D head, NMS ranked by the 2D score (core.py:125-127), no
+    `pred_boxes3d` / `scores_3d` fields.  ('intrinsics' stay in the inputs: the reference's ImageList.intrinsics property fails
+    on None, image_list.py:57-62, so core.py:68-71's "no intrinsics" branch cannot run.)
+        python tests/golden/make_golden.py box2d_only  ->  tests/golden/dla34_kitti_box2d_only_128x256_b2.npz"""
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_state_dict
+    cfg = get_cfg("dd3d_kitti_dla34", _merge(dict(TRAINING_ONLY_KEYS), BOX2D_ONLY_OVERRIDES))
+    ours = META_ARCH_REGISTRY.get("DD3D")(cfg)
+    sd = make_state_dict(ours, calib=load_calib("dla34_kitti"))
+    assert not any(k.startswith("fcos3d_head") for k in sd)
+    ref = build_reference_model(cfg)
+    ref.load_state_dict(sd, strict=True)
+    assert ref.only_box2d
+    out = {}
+    inputs = case_inputs(2, 128, 256, False, "kitti", reference_pose=True)
+    inputs[1]["height"], inputs[1]["width"] = 97, 203
+    with torch.no_grad():
+        feats = ref.backbone(torch.stack([ref.preprocess_image(x["image"].float()) for x in inputs]))
+        logits, box2d_reg, centerness, _ = ref.fcos2d_head([feats[f] for f in ref.in_features])
+        for l in range(len(logits)):
+            out[f"logits{l}"], out[f"box2d_reg{l}"], out[f"centerness{l}"] = logits[l].numpy(), box2d_reg[l].numpy(), centerness[l].numpy()
+        results = ref(inputs)
+    for i, r in enumerate(results):
+        inst = r["instances"]
+        assert not inst.has("pred_boxes3d") and not inst.has("scores_3d")
+        out[f"det{i}_image_size"] = np.array(inst.image_size)
+        out[f"det{i}_boxes"], out[f"det{i}_scores"] = inst.pred_boxes.tensor.numpy(), inst.scores.numpy()
+        out[f"det{i}_classes"], out[f"det{i}_levels"] = inst.pred_classes.numpy(), inst.fpn_levels.numpy()
+        out[f"det{i}_locations"] = inst.locations.numpy()
+    path = os.path.join(HERE, "dla34_kitti_box2d_only_128x256_b2.npz")
+    np.savez_compressed(path, **out)
+    print("box2d_only ->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", [len(out[f"det{i}_scores"]) for i in range(2)])
+
+
 if __name__ == "__main__":
-    if "dense_depth" in sys.argv[1:]:
+    if "box2d_only" in sys.argv[1:]:
+        box2d_only_golden()
+    elif "dense_depth" in sys.argv[1:]:
         dense_depth_golden()
     else:
         main(set(sys.argv[1:]))

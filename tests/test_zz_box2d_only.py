@@ -1,0 +1,90 @@
+"""MODEL.BOX3D_ON = False (core.py:38-42,90-92,117-127: `only_box2d`): no FCOS3D head, NMS ranked by the 2D score, no 3D fields.
+Golden from the reference's own DD3D with that flag (tests/golden/make_golden.py box2d_only).  (Named to run last.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.make_golden import BOX2D_ONLY_OVERRIDES, case_inputs
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "dla34_kitti_box2d_only_128x256_b2.npz")
+
+
+def _inputs():
+    inputs = case_inputs(2, 128, 256, False, "kitti")
+    inputs[1]["height"], inputs[1]["width"] = 97, 203
+    return inputs
+
+
+def test_oracle_box2d_only_matches_reference_golden():
+    from oracle import dd3d_oracle as O
+    from tests.util import bundle
+    cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti", BOX2D_ONLY_OVERRIDES)
+    assert not any(k.startswith("fcos3d_head") for k in sd)
+    g = np.load(GOLD)
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    with torch.no_grad():
+        res, st = O.dd3d_forward(sd, cfg, _inputs())
+    assert "quat" not in st
+    for l in range(5):
+        for k in ("logits", "box2d_reg", "centerness"):
+            assert torch.allclose(st[k][l], t(f"{k}{l}"), rtol=1e-5, atol=2e-5), (k, l)
+    for i, r in enumerate(res):
+        assert "pred_boxes3d" not in r and "scores_3d" not in r
+        assert len(r["scores"]) == len(g[f"det{i}_scores"]) > 0
+        assert torch.equal(r["pred_classes"], t(f"det{i}_classes")) and torch.equal(r["fpn_levels"], t(f"det{i}_levels"))
+        assert torch.equal(r["locations"], t(f"det{i}_locations"))
+        assert torch.allclose(r["pred_boxes"], t(f"det{i}_boxes"), rtol=1e-5, atol=1e-4) and torch.allclose(r["scores"], t(f"det{i}_scores"), rtol=1e-5)
+
+
+def test_plan_of_the_2d_only_model_builds(hiplib):
+    """Host side: two towers per level (10 segments per layer), two predictor groups, no 3D stage."""
+    from dd3d_amd import META_ARCH_REGISTRY
+    from dd3d_amd.engine import ConvOp, ForwardPlan
+    from tests.util import bundle
+    cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti", BOX2D_ONLY_OVERRIDES)
+    model = META_ARCH_REGISTRY.get("DD3D")(cfg)
+    model.load_state_dict(sd)
+    assert model.only_box2d and not hasattr(model, "fcos3d_head")
+    plan = ForwardPlan(model, 2, 128, 256, device="cpu", dry_run=True)
+    towers = [op for op in plan.ops if isinstance(op, ConvOp) and op.name.startswith("towers.")]
+    assert len(towers) == 4 and all(c.info["nsegs"] == 10 for c in towers)
+    assert plan.b3d_maps is None
+
+
+@pytest.mark.gpu
+def test_hip_box2d_only_matches_reference_golden(hiplib):
+    from tests.util import bundle, gpu_model, max_abs
+    cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti", BOX2D_ONLY_OVERRIDES)
+    g = np.load(GOLD)
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    model = gpu_model(cfg, sd, use_graph=False)
+    inputs = _inputs()
+    plan, image_sizes = model.stage_inputs(inputs)
+    plan.run()
+    torch.cuda.synchronize()
+    C = cfg.DD3D.NUM_CLASSES
+    nhwc = lambda x: x.permute(0, 2, 3, 1).contiguous()  # noqa: E731
+    for l in range(5):
+        assert max_abs(plan.cls_maps[l].nchw(0, C), t(f"logits{l}")) < 1e-4 * max(1.0, float(t(f"logits{l}").abs().max()))
+        assert max_abs(plan.b2d_maps[l].nchw(0, 4), t(f"box2d_reg{l}")) < 1e-4 * max(1.0, float(t(f"box2d_reg{l}").abs().max()))
+        assert max_abs(plan.b2d_maps[l].nchw(4, 1), t(f"centerness{l}")) < 1e-4 * max(1.0, float(t(f"centerness{l}").abs().max()))
+    # integer parity on identical head maps: write the reference's maps into the plan and rerun from select/decode on
+    for l in range(5):
+        plan.cls_maps[l].t.zero_()
+        plan.cls_maps[l].t[..., :C] = nhwc(t(f"logits{l}")).to(plan.device)
+        plan.b2d_maps[l].t.zero_()
+        plan.b2d_maps[l].t[..., 0:4] = nhwc(t(f"box2d_reg{l}")).to(plan.device)
+        plan.b2d_maps[l].t[..., 4:5] = nhwc(t(f"centerness{l}")).to(plan.device)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
+    torch.cuda.synchronize()
+    out = model.collect(plan, inputs, image_sizes)
+    for i in range(2):
+        o = out[i]["instances"]
+        assert not o.has("pred_boxes3d") and not o.has("scores_3d")
+        assert tuple(o.image_size) == tuple(g[f"det{i}_image_size"].tolist())
+        assert torch.equal(o.pred_classes.cpu(), t(f"det{i}_classes")) and torch.equal(o.fpn_levels.cpu(), t(f"det{i}_levels"))
+        assert torch.equal(o.locations.cpu(), t(f"det{i}_locations"))
+        assert max_abs(o.pred_boxes.tensor, t(f"det{i}_boxes")) < 1e-3 * max(1.0, float(t(f"det{i}_boxes").abs().max()))
+        assert max_abs(o.scores, t(f"det{i}_scores")) < 1e-3
