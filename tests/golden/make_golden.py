@@ -229,8 +229,53 @@ def box2d_only_golden():
     print("box2d_only ->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", [len(out[f"det{i}_scores"]) for i in range(2)])
 
 
+VARIANTS = {
+    # post-head switches the experiments leave at their defaults (configs/models/dd3d.yaml): each branch of
+    # fcos2d.py:296-300, tensor2d.py:20-24, fcos3d.py:32-46,385-390 taken at least once
+    "ctr_half_distance": {"DD3D": {"FEATURE_LOCATIONS_OFFSET": "half", "FCOS2D": {"INFERENCE": {"THRESH_WITH_CTR": False, "PRE_NMS_THRESH": 0.1}},
+                                   "FCOS3D": {"PREDICT_DISTANCE": True, "SCALE_DEPTH_BY_FOCAL_LENGTHS": False}}},
+    "egocentric_agnostic": {"DD3D": {"FCOS3D": {"PREDICT_ALLOCENTRIC_ROT": False, "CLASS_AGNOSTIC_BOX3D": True}}},
+}
+
+
+def variants_golden():
+    """python tests/golden/make_golden.py variants  ->  tests/golden/dla34_kitti_variant_<name>.npz"""
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_state_dict
+    for name, over in VARIANTS.items():
+        cfg = get_cfg("dd3d_kitti_dla34", _merge(dict(TRAINING_ONLY_KEYS), over))
+        ours = META_ARCH_REGISTRY.get("DD3D")(cfg)
+        sd = make_state_dict(ours, calib=load_calib("dla34_kitti"))
+        ref = build_reference_model(cfg)
+        ref.load_state_dict(sd, strict=True)
+        inputs = case_inputs(1, 128, 256, False, "kitti", reference_pose=True)
+        out = {}
+        with torch.no_grad():
+            feats = ref.backbone(torch.stack([ref.preprocess_image(x["image"].float()) for x in inputs]))
+            feats = [feats[f] for f in ref.in_features]
+            logits, box2d_reg, centerness, _ = ref.fcos2d_head(feats)
+            quat, ctr, depth, size, conf, _ = ref.fcos3d_head(feats)
+            for l in range(len(feats)):
+                out[f"logits{l}"], out[f"box2d_reg{l}"], out[f"centerness{l}"] = logits[l].numpy(), box2d_reg[l].numpy(), centerness[l].numpy()
+                out[f"quat{l}"], out[f"ctr{l}"], out[f"depth{l}"] = quat[l].numpy(), ctr[l].numpy(), depth[l].numpy()
+                out[f"size{l}"], out[f"conf{l}"] = size[l].numpy(), conf[l].numpy()
+            inst = ref(inputs)[0]["instances"]
+        out["det0_image_size"] = np.array(inst.image_size)
+        out["det0_boxes"], out["det0_scores"], out["det0_scores_3d"] = inst.pred_boxes.tensor.numpy(), inst.scores.numpy(), inst.scores_3d.numpy()
+        out["det0_classes"], out["det0_levels"], out["det0_locations"] = inst.pred_classes.numpy(), inst.fpn_levels.numpy(), inst.locations.numpy()
+        b3 = inst.pred_boxes3d
+        out["det0_quat"], out["det0_proj_ctr"], out["det0_depth"], out["det0_size"] = b3.quat.numpy(), b3.proj_ctr.numpy(), b3.depth.numpy(), b3.size.numpy()
+        out["det0_tvec"] = b3.tvec.numpy()
+        path = os.path.join(HERE, f"dla34_kitti_variant_{name}.npz")
+        np.savez_compressed(path, **out)
+        print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", len(inst))
+
+
 if __name__ == "__main__":
-    if "box2d_only" in sys.argv[1:]:
+    if "variants" in sys.argv[1:]:
+        variants_golden()
+    elif "box2d_only" in sys.argv[1:]:
         box2d_only_golden()
     elif "dense_depth" in sys.argv[1:]:
         dense_depth_golden()
