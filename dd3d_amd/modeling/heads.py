@@ -49,8 +49,10 @@ class FCOS2DHead(nn.Module):
         in_channels = in_channels[0]
         if cfg.DD3D.FCOS2D.USE_DEFORMABLE:
             raise ValueError("Not supported yet.")
+        if self._version == "v1":  # fcos2d.py:58-70: legacy tower layout (conv with bias, separate norm / ReLU modules)
+            raise NotImplementedError("FCOS2D _VERSION v1 is not built (no reference config uses it; configs/models/dd3d.yaml sets v2)")
         if self._version != "v2":
-            raise ValueError(f"Invalid FCOS2D version: {self._version}")  # v1 is legacy; no reference config uses it
+            raise ValueError(f"Invalid FCOS2D version: {self._version}")
         norm = cfg.DD3D.FCOS2D.NORM
         self.cls_tower = _make_tower(in_channels, cfg.DD3D.FCOS2D.NUM_CLS_CONVS, norm, self.num_levels)
         self.box2d_tower = _make_tower(in_channels, cfg.DD3D.FCOS2D.NUM_BOX_CONVS, norm, self.num_levels)

@@ -167,7 +167,7 @@ def _tower(sd, p, x, level, num_convs, hook=None):
 
 
 def fcos2d_head(sd, features, num_convs=4, prefix="fcos2d_head", hook=None):
-    """fcos2d.py:130-156 FCOS2DHead.forward (v2, USE_SCALE True)."""
+    """fcos2d.py:130-156 FCOS2DHead.forward (v2; the Scale modules exist in the state dict iff USE_SCALE, fcos2d.py:104-108,146-148)."""
     logits, box2d_reg, centerness, cls_tower_out = [], [], [], []
     for l, f in enumerate(features):
         ct = _tower(sd, prefix + ".cls_tower", f, l, num_convs, hook)
@@ -175,26 +175,32 @@ def fcos2d_head(sd, features, num_convs=4, prefix="fcos2d_head", hook=None):
         logits.append(conv2d(sd, prefix + ".cls_logits", ct, padding=1))
         centerness.append(conv2d(sd, prefix + ".centerness", bt, padding=1))
         reg = conv2d(sd, prefix + ".box2d_reg", bt, padding=1)
-        reg = reg * sd[f"{prefix}.scales_box2d_reg.{l}.scale"]  # Scale, normalization.py:12-18
+        if f"{prefix}.scales_box2d_reg.{l}.scale" in sd:
+            reg = reg * sd[f"{prefix}.scales_box2d_reg.{l}.scale"]  # Scale, normalization.py:12-18
         box2d_reg.append(F.relu(reg))
         cls_tower_out.append(ct)
     return logits, box2d_reg, centerness, cls_tower_out
 
 
 def fcos3d_head(sd, features, num_convs=4, prefix="fcos3d_head", hook=None):
-    """fcos3d.py:160-188 FCOS3DHead.forward (PER_LEVEL_PREDICTORS False, USE_SCALE True)."""
+    """fcos3d.py:160-188 FCOS3DHead.forward.  PER_LEVEL_PREDICTORS / USE_SCALE are read off the state dict: one predictor per level
+    exists iff PER_LEVEL_PREDICTORS (fcos3d.py:104), the Scale / Offset modules exist iff USE_SCALE (fcos3d.py:128-139)."""
     quat, ctr, depth, size, conf = [], [], [], [], []
+    per_level = f"{prefix}.box3d_quat.1.weight" in sd
+    use_scale = f"{prefix}.scales_proj_ctr.0.scale" in sd
     for l, f in enumerate(features):
         t = _tower(sd, prefix + ".box3d_tower", f, l, num_convs, hook)
-        q = conv2d(sd, prefix + ".box3d_quat.0", t, padding=1)
-        c = conv2d(sd, prefix + ".box3d_ctr.0", t, padding=1)
-        d = conv2d(sd, prefix + ".box3d_depth.0", t, padding=1)
-        s = conv2d(sd, prefix + ".box3d_size.0", t, padding=1)
-        cf = conv2d(sd, prefix + ".box3d_conf.0", t, padding=1)
-        c = c * sd[f"{prefix}.scales_proj_ctr.{l}.scale"]
-        s = s * sd[f"{prefix}.scales_size.{l}.scale"]
-        cf = cf * sd[f"{prefix}.scales_conf.{l}.scale"]
-        d = d * sd[f"{prefix}.scales_depth.{l}.scale"] + sd[f"{prefix}.offsets_depth.{l}.bias"]  # fcos3d.py:180
+        _l = l if per_level else 0  # fcos3d.py:166
+        q = conv2d(sd, f"{prefix}.box3d_quat.{_l}", t, padding=1)
+        c = conv2d(sd, f"{prefix}.box3d_ctr.{_l}", t, padding=1)
+        d = conv2d(sd, f"{prefix}.box3d_depth.{_l}", t, padding=1)
+        s = conv2d(sd, f"{prefix}.box3d_size.{_l}", t, padding=1)
+        cf = conv2d(sd, f"{prefix}.box3d_conf.{_l}", t, padding=1)
+        if use_scale:  # fcos3d.py:175-180
+            c = c * sd[f"{prefix}.scales_proj_ctr.{l}.scale"]
+            s = s * sd[f"{prefix}.scales_size.{l}.scale"]
+            cf = cf * sd[f"{prefix}.scales_conf.{l}.scale"]
+            d = d * sd[f"{prefix}.scales_depth.{l}.scale"] + sd[f"{prefix}.offsets_depth.{l}.bias"]
         quat.append(q), ctr.append(c), depth.append(d), size.append(s), conf.append(cf)
     return quat, ctr, depth, size, conf
 

@@ -235,6 +235,9 @@ VARIANTS = {
     "ctr_half_distance": {"DD3D": {"FEATURE_LOCATIONS_OFFSET": "half", "FCOS2D": {"INFERENCE": {"THRESH_WITH_CTR": False, "PRE_NMS_THRESH": 0.1}},
                                    "FCOS3D": {"PREDICT_DISTANCE": True, "SCALE_DEPTH_BY_FOCAL_LENGTHS": False}}},
     "egocentric_agnostic": {"DD3D": {"FCOS3D": {"PREDICT_ALLOCENTRIC_ROT": False, "CLASS_AGNOSTIC_BOX3D": True}}},
+    # head construction switches (fcos2d.py:104-108, fcos3d.py:104,116,128-139,166): no Scale / Offset modules (the depth predictor
+    # then has a bias), one predictor set per level
+    "plain_heads": {"DD3D": {"FCOS2D": {"USE_SCALE": False}, "FCOS3D": {"USE_SCALE": False, "PER_LEVEL_PREDICTORS": True}}},
 }
 
 
