@@ -180,6 +180,9 @@ class FPN(nn.Module):
 def build_dla_backbone(cfg, input_shape):
     """dla.py:445-459 (cfg = cfg.FE.BACKBONE)."""
     assert input_shape.channels == 3, "Only supports 3-channel input for now."
+    if cfg.NAME not in DLA_NAME_TO_BUILDER:  # dla.py:430-441 also lists the Bottleneck / BottleneckX variants (DLA-46-C ... DLA-169)
+        raise NotImplementedError(f"DLA variant {cfg.NAME!r} is not built; available: {sorted(DLA_NAME_TO_BUILDER)} "
+                                  "(the only one the reference's configs select)")
     return DLA_NAME_TO_BUILDER[cfg.NAME](cfg)
 
 
