@@ -123,6 +123,7 @@ class SmallcConvOp:
         self.name = name
         self.w3 = pack_smallc_bf16x3(conv_weight, cin_p).to(plan.device)
         self.keep = [scale, bias]
+        self.desc = dict(kind="smallc_conv", weight=conv_weight, stride=stride, pad=pad, vin=vin, vout=vout, scale=scale, bias=bias, relu=bool(relu))
         a = hip.SmallcArgs()
         a.in_, a.out, a.w3 = vin.ptr, vout.ptr, self.w3.data_ptr()
         a.scale, a.bias, a.lo = scale.data_ptr(), bias.data_ptr(), None
@@ -259,6 +260,7 @@ class ConvOp:
             assert a["n_limit"] <= meta["N"]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
             self.keep += [w, s["scale"], s["bias"], s.get("lo")]
+        self.desc = dict(kind="conv", segs=segs, meta=meta, stride=stride, pad=pad, relu=bool(relu), in_relu=bool(in_relu))
         self.segs_host = arr  # kept alive: single-segment launches hand the descriptor over by value (seg0_host)
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
@@ -291,8 +293,10 @@ class ConvOp:
 
 
 class CallOp:
-    def __init__(self, fn, name=""):
-        self.fn, self.name, self.macs = fn, name, 0
+    """A non-convolution launch.  `desc` says what it computes on which views (kind + operands); tools and the CPU plan emulator of
+    the tests read it, the launch itself does not."""
+    def __init__(self, fn, name="", desc=None):
+        self.fn, self.name, self.macs, self.desc = fn, name, 0, desc
 
     def __call__(self, lib, stream):
         self.fn(lib, stream)
@@ -375,7 +379,7 @@ class PlanBase:
         def _f(lib, st, vin=vin, vout=vout):
             hip.check(lib.dd3d_maxpool2x2_nhwc(vin.ptr, vout.ptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, st), name)
 
-        self.ops.append(CallOp(_f, name))
+        self.ops.append(CallOp(_f, name, dict(kind="maxpool2x2", vin=vin, vout=vout)))
 
     def upsample_add(self, fine, coarse, name="fpn_topdown"):
         assert fine.C == coarse.C and coarse.H * 2 == fine.H and coarse.W * 2 == fine.W
@@ -385,7 +389,7 @@ class PlanBase:
                 lib.dd3d_upsample2x_add_nhwc(fine.ptr, coarse.ptr, fine.B, fine.H, fine.W, fine.C, fine.pitch, coarse.pitch, st), name
             )
 
-        self.ops.append(CallOp(_f, name))
+        self.ops.append(CallOp(_f, name, dict(kind="upsample2x_add", fine=fine, coarse=coarse)))
 
     # ------------------------------------------------------------------ side branches
     def branch(self, b):
@@ -500,7 +504,7 @@ class ForwardPlan(PlanBase):
             )
             hip.check(lib.dd3d_invert_intrinsics(self.in_K.data_ptr(), self.inv_K.data_ptr(), B, st), "invert_intrinsics")
 
-        self.ops.append(CallOp(_pre, "preprocess"))
+        self.ops.append(CallOp(_pre, "preprocess", dict(kind="preprocess", img=img, mean=list(mean), std=list(std))))
 
         # ---- backbone + FPN
         from dd3d_amd.modeling.dla import DLA
@@ -641,7 +645,7 @@ class ForwardPlan(PlanBase):
                 def _pool(lib, st, vin=prev, vout=dstv):
                     hip.check(lib.dd3d_maxpool3x3s2_ceil_nhwc(vin.ptr, vout.ptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, st), "pool3")
 
-                self.ops.append(CallOp(_pool, f"{sname}.pool"))
+                self.ops.append(CallOp(_pool, f"{sname}.pool", dict(kind="maxpool3x3s2_ceil", vin=prev, vout=dstv)))
             H, W = cat.H, cat.W
             for k, (mname, m) in enumerate(mods):
                 src = cat.view(0, m.in_ch)
@@ -677,7 +681,7 @@ class ForwardPlan(PlanBase):
                 name
             )
 
-        self.ops.append(CallOp(_f, name))
+        self.ops.append(CallOp(_f, name, dict(kind="ese", x=x, identity=identity, out=out, weight=w, bias=b)))
 
     # ------------------------------------------------------------------ FPN ([ext] detectron2 FPN.forward)
     def _fpn(self, fpn, feats):

@@ -88,6 +88,10 @@ class VoVNet(nn.Module):
         if cfg.NAME not in _STAGE_SPECS:
             raise NotImplementedError(f"VoVNet spec {cfg.NAME} (depthwise variants) is not used by any reference config")
         spec = _STAGE_SPECS[cfg.NAME]
+        if any(c % 32 for c in spec["stage_conv_ch"] + spec["stage_out_ch"]):
+            # the implicit-GEMM kernels address channel slices of the OSA concat buffers in 32-channel K chunks
+            raise NotImplementedError(f"VoVNet spec {cfg.NAME}: channel counts that are not multiples of 32 are not built "
+                                      "(V-19-eSE, V-39-eSE, V-57-eSE and V-99-eSE are; the reference's configs use V-99-eSE)")
         norm = cfg.NORM
         stem_ch = spec["stem"]
         self._out_features = list(out_features)

@@ -275,8 +275,39 @@ def variants_golden():
         print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", len(inst))
 
 
+def vovnet_specs_golden():
+    """Other VoVNet specs (vovnet.py:41-87) through the reference's own backbone + heads; a compact fixture (coarse-level logits + the
+    detections).   python tests/golden/make_golden.py vovnet_specs  ->  tests/golden/vovnet_spec_<name>.npz"""
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_state_dict
+    for spec in ("V-19-eSE", "V-39-eSE", "V-57-eSE"):
+        cfg = get_cfg("dd3d_kitti_v99", _merge(dict(TRAINING_ONLY_KEYS), {"FE": {"BACKBONE": {"NAME": spec}}}))
+        ours = META_ARCH_REGISTRY.get("DD3D")(cfg)
+        sd = make_state_dict(ours, calib=load_calib("v99_kitti"))
+        ref = build_reference_model(cfg)
+        ref.load_state_dict(sd, strict=True)
+        inputs = case_inputs(1, 64, 128, False, "kitti", reference_pose=True)
+        out = {}
+        with torch.no_grad():
+            feats = ref.backbone(torch.stack([ref.preprocess_image(x["image"].float()) for x in inputs]))
+            feats = [feats[f] for f in ref.in_features]
+            logits, _, _, _ = ref.fcos2d_head(feats)
+            _, _, depth, _, _, _ = ref.fcos3d_head(feats)
+            for l in (2, 3, 4):
+                out[f"feat{l}"], out[f"logits{l}"], out[f"depth{l}"] = feats[l].numpy(), logits[l].numpy(), depth[l].numpy()
+            inst = ref(inputs)[0]["instances"]
+        out["det0_boxes"], out["det0_scores_3d"], out["det0_classes"] = inst.pred_boxes.tensor.numpy(), inst.scores_3d.numpy(), inst.pred_classes.numpy()
+        out["det0_locations"], out["det0_depth"] = inst.locations.numpy(), inst.pred_boxes3d.depth.numpy()
+        path = os.path.join(HERE, f"vovnet_spec_{spec.replace('-', '').lower()}.npz")
+        np.savez_compressed(path, **out)
+        print(spec, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", len(inst))
+
+
 if __name__ == "__main__":
-    if "variants" in sys.argv[1:]:
+    if "vovnet_specs" in sys.argv[1:]:
+        vovnet_specs_golden()
+    elif "variants" in sys.argv[1:]:
         variants_golden()
     elif "box2d_only" in sys.argv[1:]:
         box2d_only_golden()

@@ -1,0 +1,90 @@
+"""CPU emulator of a (dry-run) launch plan -- TEST INFRASTRUCTURE.  Executes the ops of dd3d_amd.engine.ForwardPlan with plain torch
+on the plan's own (CPU) buffers, reading what each op computes from its `desc`: packed filters, folded norm / Scale / Offset vectors,
+channel-slice views, concat-by-placement, residual sources.  What it checks is the HOST side of the engine (the part that changes with
+the configuration); the kernels' arithmetic is checked on the GPU.  Stops at the first op it has no description for (select/decode)."""
+import torch
+import torch.nn.functional as F
+
+
+def unpack_filter(wp, meta):
+    """Inverse of dd3d_amd.engine.pack_filter: Wp[Npad][Kpad], k = (c/CC)*(T*CC) + tap*CC + c%CC  ->  OIHW [N][Cin][KH][KW]."""
+    N, Cin, KH, KW = meta["N"], meta["Cin"], meta["KH"], meta["KW"]
+    CC, T = min(Cin, 32), KH * KW
+    w = wp[:N, :T * Cin].reshape(N, Cin // CC, T, CC)  # [n][chunk][tap][c % CC]
+    return w.permute(0, 1, 3, 2).reshape(N, Cin, KH, KW)
+
+
+def _store(view, y_nchw, n):
+    view.buf.t[..., view.c0:view.c0 + n] = y_nchw.permute(0, 2, 3, 1)
+
+
+def _conv(d):
+    meta = d["meta"]
+    for s in d["segs"]:
+        x = s["in"].nchw()
+        if d["in_relu"]:
+            x = F.relu(x)
+        n = int(s.get("n_limit") or meta["N"])
+        w = unpack_filter(s["w"], dict(meta, N=n))
+        acc = F.conv2d(x, w, None, stride=d["stride"], padding=d["pad"])
+        y = acc * s["scale"][:n].view(1, -1, 1, 1) + s["bias"][:n].view(1, -1, 1, 1)
+        if s.get("res") is not None:
+            y = y + s["res"].buf.t[..., s["res"].c0:s["res"].c0 + n].permute(0, 3, 1, 2)
+        lo = torch.full((n, ), float("-inf")) if s.get("lo") is None else s["lo"][:n].clone()
+        if d["relu"]:
+            lo = lo.clamp(min=0.0)
+        _store(s["out"], torch.maximum(y, lo.view(1, -1, 1, 1)), n)
+
+
+def _smallc(d):
+    w = d["weight"].detach().float()
+    x = d["vin"].nchw()[:, :w.shape[1]]
+    n = w.shape[0]
+    y = F.conv2d(x, w, None, stride=d["stride"], padding=d["pad"]) * d["scale"][:n].view(1, -1, 1, 1) + d["bias"][:n].view(1, -1, 1, 1)
+    _store(d["vout"], F.relu(y) if d["relu"] else y, n)
+
+
+def _preprocess(plan, d):
+    img = d["img"].t
+    img.zero_()
+    mean, std = torch.tensor(d["mean"]), torch.tensor(d["std"])
+    for b in range(plan.B):
+        h, w = plan.in_sizes[b].tolist()
+        img[b, :h, :w, :3] = (plan.in_u8[b, :, :h, :w].float().permute(1, 2, 0) - mean) / std
+    plan.inv_K.copy_(torch.linalg.inv(plan.in_K.view(-1, 3, 3)).reshape(-1, 9))
+
+
+def emulate(plan, stop_before=("select_decode", )):
+    """Run the plan's ops in order on its CPU buffers; returns the names of the ops executed."""
+    done = []
+    for op in plan.ops:
+        if op.name in stop_before:
+            break
+        d = getattr(op, "desc", None)
+        if d is None:
+            raise NotImplementedError(f"op {op.name!r} carries no description")
+        k = d["kind"]
+        if k == "conv":
+            _conv(d)
+        elif k == "smallc_conv":
+            _smallc(d)
+        elif k == "preprocess":
+            _preprocess(plan, d)
+        elif k == "maxpool2x2":
+            _store(d["vout"], F.max_pool2d(d["vin"].nchw(), 2), d["vin"].C)
+        elif k == "maxpool3x3s2_ceil":
+            _store(d["vout"], F.max_pool2d(d["vin"].nchw(), 3, 2, ceil_mode=True), d["vin"].C)
+        elif k == "upsample2x_add":
+            f, c = d["fine"], d["coarse"]
+            _store(f, f.nchw() + F.interpolate(c.nchw(), scale_factor=2, mode="nearest"), f.C)
+        elif k == "ese":
+            x = d["x"].nchw()
+            gate = F.relu6(F.linear(x.mean((2, 3)), d["weight"].view(x.shape[1], x.shape[1]), d["bias"]) + 3.0) / 6.0
+            y = x * gate[:, :, None, None]
+            if d["identity"] is not None:
+                y = y + d["identity"].nchw()
+            _store(d["out"], y, x.shape[1])
+        else:
+            raise NotImplementedError(k)
+        done.append(op.name)
+    return done

@@ -1,0 +1,100 @@
+"""Host side of the engine for configurations beyond the ones benchmarked: the launch plan (dry run, CPU buffers) is executed by the
+torch emulator of tests/plan_emulator.py -- packed filters, folded norms, concat-by-placement, residual wiring, pooling / top-down /
+eSE ops exactly as the plan describes them -- and every backbone stage, FPN level and head map must equal the oracle's (which is pinned
+against the reference).  Covers VoVNet specs no GPU test has run yet."""
+import pytest
+import torch
+
+from tests.plan_emulator import emulate
+
+CASES = {
+    "dla34_kitti": ("dd3d_kitti_dla34", "dla34_kitti", None, "kitti", 1, 128, 256),
+    "dla34_nusc": ("dd3d_nusc_dla34", "dla34_nusc", None, "nusc", 6, 128, 128),  # one complete 6-camera sample
+    "v99_kitti": ("dd3d_kitti_v99", "v99_kitti", None, "kitti", 1, 64, 128),
+    "v39_kitti": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-39-eSE"}}}, "kitti", 1, 64, 128),
+    "v19_kitti": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-eSE"}}}, "kitti", 1, 64, 128),
+    "v57_kitti": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-57-eSE"}}}, "kitti", 1, 64, 128),
+    "dla34_plain_heads": ("dd3d_kitti_dla34", "dla34_kitti",
+                          {"DD3D": {"FCOS2D": {"USE_SCALE": False}, "FCOS3D": {"USE_SCALE": False, "PER_LEVEL_PREDICTORS": True}}}, "kitti", 1, 128, 256),
+    "dla34_box2d_only": ("dd3d_kitti_dla34", "dla34_kitti", {"MODEL": {"BOX3D_ON": False}}, "kitti", 1, 128, 256),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_emulated_plan_matches_oracle(hiplib, name):
+    from dd3d_amd import META_ARCH_REGISTRY
+    from dd3d_amd.engine import ForwardPlan
+    from dd3d_amd.synthetic import make_inputs
+    from oracle import dd3d_oracle as O
+    from oracle import nuscenes_oracle as N
+    from tests.util import bundle
+    exp, tag, over, ds, B, H, W = CASES[name]
+    cfg, sd = bundle(exp, tag, over)
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.load_state_dict(sd, strict=True)
+    div = model.backbone.size_divisibility
+    inputs = make_inputs(B, H, W, dataset=ds)
+    plan = ForwardPlan(model, B, H + (-H) % div, W + (-W) % div, device="cpu", dry_run=True)
+    model.stage_inputs(inputs, plan=plan)
+    with torch.no_grad():
+        done = emulate(plan)
+        if cfg.MODEL.META_ARCHITECTURE == "NuscenesDD3D":
+            _, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
+        else:
+            _, st = O.dd3d_forward(sd, cfg, inputs, stop_after_heads=True)
+    assert "predictors" in done
+
+    def close(got, ref, what):
+        err = float((got - ref).abs().max())
+        assert got.shape == ref.shape and err < 1e-4 * max(1.0, float(ref.abs().max())), (what, err)
+
+    close(plan.bufs["img4"].nchw(0, 3), st["images"], "images")
+    for k, v in st.get("bottom_up", {}).items():
+        if k in plan.bottom_up:
+            close(plan.bottom_up[k].nchw(), v, k)
+    C = cfg.DD3D.NUM_CLASSES
+    for l in range(len(st["features"])):
+        close(plan.features[l].nchw(), st["features"][l], f"feature {l}")
+        close(plan.cls_maps[l].nchw(0, C), st["logits"][l], f"logits {l}")
+        close(plan.b2d_maps[l].nchw(0, 4), st["box2d_reg"][l], f"box2d_reg {l}")
+        close(plan.b2d_maps[l].nchw(4, 1), st["centerness"][l], f"centerness {l}")
+        if "quat" in st:
+            fused = torch.cat([st["quat"][l], st["ctr"][l], st["depth"][l], st["size"][l], st["conf"][l]], 1)
+            close(plan.b3d_maps[l].nchw(0, fused.shape[1]), fused, f"box3d {l}")
+        if "attr" in st:
+            na = st["attr"][l].shape[1]
+            close(plan.cls_maps[l].nchw(C, na), st["attr"][l], f"attr {l}")
+            close(plan.cls_maps[l].nchw(C + na, 1), st["speed"][l], f"speed {l}")
+
+
+def test_unbuilt_vovnet_spec_fails_loudly():
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    import dd3d_amd.modeling  # noqa: F401
+    cfg = get_cfg("dd3d_kitti_v99", {"FE": {"BACKBONE": {"NAME": "V-19-slim-eSE"}}})
+    with pytest.raises(NotImplementedError, match="multiples of 32"):
+        META_ARCH_REGISTRY.get("DD3D")(cfg)
+
+
+@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE"])
+def test_oracle_vovnet_specs_match_reference_golden(spec):
+    """The oracle the emulated plans are compared with is itself pinned for these specs: compact goldens from the reference's own
+    VoVNet + FPN + heads (tests/golden/make_golden.py vovnet_specs)."""
+    import os
+    import numpy as np
+    from oracle import dd3d_oracle as O
+    from tests.golden.make_golden import case_inputs
+    from tests.util import bundle
+    cfg, sd = bundle("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": spec}}})
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"vovnet_spec_{spec.replace('-', '').lower()}.npz"))
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    with torch.no_grad():
+        res, st = O.dd3d_forward(sd, cfg, case_inputs(1, 64, 128, False, "kitti"))
+    for l in (2, 3, 4):
+        assert torch.allclose(st["features"][l], t(f"feat{l}"), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(st["logits"][l], t(f"logits{l}"), rtol=1e-5, atol=2e-5) and torch.allclose(st["depth"][l], t(f"depth{l}"), rtol=1e-5, atol=2e-5)
+    r = res[0]
+    assert len(r["scores"]) == len(g["det0_scores_3d"])
+    if len(r["scores"]):
+        assert torch.equal(r["pred_classes"], t("det0_classes")) and torch.equal(r["locations"], t("det0_locations"))
+        assert torch.allclose(r["pred_boxes"], t("det0_boxes"), rtol=1e-5, atol=1e-4) and torch.allclose(r["scores_3d"], t("det0_scores_3d"), rtol=1e-5)
+        assert torch.allclose(r["pred_boxes3d"]["depth"], t("det0_depth"), rtol=1e-5)
