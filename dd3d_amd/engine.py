@@ -1051,5 +1051,6 @@ class DenseDepthPlan(ForwardPlan):
                 hip.check(lib.dd3d_aligned_bilinear_scale(src.t.data_ptr(), o.data_ptr(), self.inv_K.data_ptr(), B, f.H, f.W, 4, stride, half,
                                                           factor, st), "aligned_bilinear")
 
-            self.ops.append(CallOp(_up, f"dd_upsample.{l}"))
+            self.ops.append(CallOp(_up, f"dd_upsample.{l}", dict(kind="aligned_bilinear_scale", src=self.dd_raw[l], out=o, factor=stride,
+                                                                   offset_half=half, focal_factor=factor)))
 

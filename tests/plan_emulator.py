@@ -84,6 +84,14 @@ def emulate(plan, stop_before=("select_decode", )):
             if d["identity"] is not None:
                 y = y + d["identity"].nchw()
             _store(d["out"], y, x.shape[1])
+        elif k == "aligned_bilinear_scale":
+            from oracle.dense_depth_oracle import aligned_bilinear
+            y = aligned_bilinear(d["src"].nchw(0, 1), d["factor"], "half" if d["offset_half"] else "none")[:, 0]
+            if d["focal_factor"] > 0:  # dense_depth.py:147-150
+                inv_K = plan.inv_K.view(-1, 3, 3)
+                pixel_size = torch.sqrt(inv_K[:, 0, 0]**2 + inv_K[:, 1, 1]**2)
+                y = y / (pixel_size * d["focal_factor"]).view(-1, 1, 1)
+            d["out"].copy_(y)
         else:
             raise NotImplementedError(k)
         done.append(op.name)

@@ -17,6 +17,9 @@ CASES = {
     "dla34_plain_heads": ("dd3d_kitti_dla34", "dla34_kitti",
                           {"DD3D": {"FCOS2D": {"USE_SCALE": False}, "FCOS3D": {"USE_SCALE": False, "PER_LEVEL_PREDICTORS": True}}}, "kitti", 1, 128, 256),
     "dla34_box2d_only": ("dd3d_kitti_dla34", "dla34_kitti", {"MODEL": {"BOX3D_ON": False}}, "kitti", 1, 128, 256),
+    "dla34_class_agnostic": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"FCOS3D": {"CLASS_AGNOSTIC_BOX3D": True}}}, "kitti", 1, 128, 256),
+    "v99_nusc": ("dd3d_nusc_v99", "v99_nusc", None, "nusc", 6, 64, 128),  # BASELINE.json configs[3]'s architecture
+    "dla34_ragged": ("dd3d_kitti_dla34", "dla34_kitti", None, "ragged", 2, 128, 384),
 }
 
 
@@ -33,7 +36,10 @@ def test_emulated_plan_matches_oracle(hiplib, name):
     model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
     model.load_state_dict(sd, strict=True)
     div = model.backbone.size_divisibility
-    inputs = make_inputs(B, H, W, dataset=ds)
+    if ds == "ragged":  # images of different sizes in one padded batch (image_list.py:120-142)
+        inputs = make_inputs(1, H, W) + make_inputs(1, H - 37, W - 101, seed=7)
+    else:
+        inputs = make_inputs(B, H, W, dataset=ds)
     plan = ForwardPlan(model, B, H + (-H) % div, W + (-W) % div, device="cpu", dry_run=True)
     model.stage_inputs(inputs, plan=plan)
     with torch.no_grad():
@@ -98,3 +104,24 @@ def test_oracle_vovnet_specs_match_reference_golden(spec):
         assert torch.equal(r["pred_classes"], t("det0_classes")) and torch.equal(r["locations"], t("det0_locations"))
         assert torch.allclose(r["pred_boxes"], t("det0_boxes"), rtol=1e-5, atol=1e-4) and torch.allclose(r["scores_3d"], t("det0_scores_3d"), rtol=1e-5)
         assert torch.allclose(r["pred_boxes3d"]["depth"], t("det0_depth"), rtol=1e-5)
+
+
+def test_emulated_dense_depth_plan_matches_oracle(hiplib):
+    from dd3d_amd import META_ARCH_REGISTRY
+    from dd3d_amd.engine import DenseDepthPlan
+    from oracle import dense_depth_oracle as D
+    from tests.test_dense_depth import _case
+    cfg, sd, inputs = _case()
+    model = META_ARCH_REGISTRY.get("DD3DDenseDepth")(cfg)
+    model.load_state_dict(sd, strict=True)
+    plan = DenseDepthPlan(model, 2, 128, 256, device="cpu", dry_run=True)
+    for i, x in enumerate(inputs):  # the staging part of DD3DDenseDepth.predict_dense_depth
+        plan.in_u8[i, :, :x["image"].shape[1], :x["image"].shape[2]].copy_(x["image"])
+    plan.in_sizes.copy_(torch.tensor([[int(x["image"].shape[-2]), int(x["image"].shape[-1])] for x in inputs], dtype=torch.int32))
+    plan.in_K.copy_(torch.stack([x["intrinsics"].float() for x in inputs], 0).reshape(2, 9))
+    with torch.no_grad():
+        done = emulate(plan, stop_before=())
+        maps, _ = D.dense_depth_forward(sd, cfg, inputs)
+    assert done[-1] == "dd_upsample.4" and len(maps) == len(plan.depth_maps) == 5
+    for l, (got, ref) in enumerate(zip(plan.depth_maps, maps)):
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), l
