@@ -98,12 +98,17 @@ def main():
     model.load_state_dict(sd)
     B = args.batch
     inputs = make_inputs(B, args.height, args.width, seed=1000 + rank * B)
+    pipeline_error = None
     if args.pipeline > 0:
-        runner = PipelinedForward(model, B, *_padded(model, args.height, args.width), depth=args.pipeline,
-                                  compute_streams=min(args.compute_streams, args.pipeline))
-        plan = runner.plan
-        runner.stage_all(inputs)
-    else:
+        try:
+            runner = PipelinedForward(model, B, *_padded(model, args.height, args.width), depth=args.pipeline,
+                                      compute_streams=min(args.compute_streams, args.pipeline))
+            plan = runner.plan
+            runner.stage_all(inputs)
+        except Exception as e:  # symmetric across ranks (same code, same sizes): every rank falls back together; reported in the JSON
+            pipeline_error = f"{type(e).__name__}: {e}"
+            args.pipeline = 0
+    if args.pipeline <= 0:
         runner = DistributedForward(model, B, *_padded(model, args.height, args.width), use_graph=not args.no_graph)
         plan = runner.plan
         model.stage_inputs(inputs, plan=plan)  # H2D once: inputs are resident in HBM when the timed region starts
@@ -166,6 +171,7 @@ def main():
             "issue": (f"{args.pipeline} plan slots on {min(args.compute_streams, args.pipeline)} compute streams + 1 exchange/NMS stream "
                       "(dd3d_amd.parallel.PipelinedForward): several single-image steps in flight share the chip; every step does all "
                       "of its work and all K steps are complete at the closing synchronize") if args.pipeline else "one step at a time",
+            "pipeline_error": pipeline_error,
             "ms_per_step_one_at_a_time": None if serial_ms is None else round(serial_ms, 4),
             "images_per_s_one_at_a_time": None if serial_ms is None else round(B / serial_ms * 1e3, 2),
             "frac_of_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4),
