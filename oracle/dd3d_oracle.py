@@ -135,14 +135,18 @@ def fpn_forward(sd, bottom_up, in_features, in_strides, top_block="p6p7", prefix
     stages = [int(math.log2(s)) for s in in_strides]
     results = []
     prev = None
+
+    def norm_of(conv):  # [ext] FPN.__init__: `use_bias = norm == ""`: the norm modules exist iff FE.FPN.NORM is set
+        return f"{conv}.norm" if f"{conv}.norm.weight" in sd else None
+
     for idx in range(len(in_features)):
         name = in_features[-idx - 1]
         st = stages[-idx - 1]
-        lat = conv2d(sd, f"{prefix}.fpn_lateral{st}", bottom_up[name], norm=f"{prefix}.fpn_lateral{st}.norm", hook=hook)
+        lat = conv2d(sd, f"{prefix}.fpn_lateral{st}", bottom_up[name], norm=norm_of(f"{prefix}.fpn_lateral{st}"), hook=hook)
         if idx > 0:
             lat = lat + F.interpolate(prev, scale_factor=2.0, mode="nearest")
         prev = lat
-        out = conv2d(sd, f"{prefix}.fpn_output{st}", prev, padding=1, norm=f"{prefix}.fpn_output{st}.norm", hook=hook)
+        out = conv2d(sd, f"{prefix}.fpn_output{st}", prev, padding=1, norm=norm_of(f"{prefix}.fpn_output{st}"), hook=hook)
         results.insert(0, (f"p{st}", out))
     results = OrderedDict(results)
     if top_block:

@@ -275,19 +275,30 @@ def variants_golden():
         print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KB; detections", len(inst))
 
 
+STRUCTURAL = {  # name -> (experiment, calibration tag, overrides): construction switches outside the experiments' settings
+    "V-19-eSE": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-eSE"}}}),
+    "V-39-eSE": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-39-eSE"}}}),
+    "V-57-eSE": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-57-eSE"}}}),
+    "fpn-without-norm": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"NORM": ""}}}),
+    "swapped-head-norms": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"FCOS2D": {"NORM": "FrozenBN"}, "FCOS3D": {"NORM": "BN"}}}),
+    "bn-backbone": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"BACKBONE": {"NORM": "BN"}}}),
+}
+
+
 def vovnet_specs_golden():
-    """Other VoVNet specs (vovnet.py:41-87) through the reference's own backbone + heads; a compact fixture (coarse-level logits + the
-    detections).   python tests/golden/make_golden.py vovnet_specs  ->  tests/golden/vovnet_spec_<name>.npz"""
+    """Other VoVNet specs (vovnet.py:41-87) and norm placements through the reference's own backbone + heads; compact fixtures (coarse-
+    level features / logits / depth + the detections).   python tests/golden/make_golden.py vovnet_specs  ->  tests/golden/vovnet_spec_<name>.npz"""
     import dd3d_amd.modeling  # noqa: F401
     from dd3d_amd import META_ARCH_REGISTRY, get_cfg
     from dd3d_amd.synthetic import load_calib, make_state_dict
-    for spec in ("V-19-eSE", "V-39-eSE", "V-57-eSE"):
-        cfg = get_cfg("dd3d_kitti_v99", _merge(dict(TRAINING_ONLY_KEYS), {"FE": {"BACKBONE": {"NAME": spec}}}))
+    for spec, (exp, tag, over) in STRUCTURAL.items():
+        cfg = get_cfg(exp, _merge(dict(TRAINING_ONLY_KEYS), over))
         ours = META_ARCH_REGISTRY.get("DD3D")(cfg)
-        sd = make_state_dict(ours, calib=load_calib("v99_kitti"))
+        sd = make_state_dict(ours, calib=load_calib(tag))
         ref = build_reference_model(cfg)
         ref.load_state_dict(sd, strict=True)
-        inputs = case_inputs(1, 64, 128, False, "kitti", reference_pose=True)
+        H, W = (64, 128) if "v99" in exp else (128, 256)
+        inputs = case_inputs(1, H, W, False, "kitti", reference_pose=True)
         out = {}
         with torch.no_grad():
             feats = ref.backbone(torch.stack([ref.preprocess_image(x["image"].float()) for x in inputs]))

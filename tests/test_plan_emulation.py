@@ -20,6 +20,10 @@ CASES = {
     "dla34_class_agnostic": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"FCOS3D": {"CLASS_AGNOSTIC_BOX3D": True}}}, "kitti", 1, 128, 256),
     "v99_nusc": ("dd3d_nusc_v99", "v99_nusc", None, "nusc", 6, 64, 128),  # BASELINE.json configs[3]'s architecture
     "dla34_ragged": ("dd3d_kitti_dla34", "dla34_kitti", None, "ragged", 2, 128, 384),
+    "dla34_fpn_without_norm": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"NORM": ""}}}, "kitti", 1, 128, 256),
+    "dla34_swapped_head_norms": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"FCOS2D": {"NORM": "FrozenBN"}, "FCOS3D": {"NORM": "BN"}}},
+                                 "kitti", 1, 128, 256),
+    "dla34_bn_backbone": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"BACKBONE": {"NORM": "BN"}}}, "kitti", 1, 128, 256),
 }
 
 
@@ -81,20 +85,22 @@ def test_unbuilt_vovnet_spec_fails_loudly():
         META_ARCH_REGISTRY.get("DD3D")(cfg)
 
 
-@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE"])
+@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE", "fpn-without-norm", "swapped-head-norms", "bn-backbone"])
 def test_oracle_vovnet_specs_match_reference_golden(spec):
-    """The oracle the emulated plans are compared with is itself pinned for these specs: compact goldens from the reference's own
-    VoVNet + FPN + heads (tests/golden/make_golden.py vovnet_specs)."""
+    """The oracle the emulated plans are compared with is itself pinned for these construction variants: compact goldens from the
+    reference's own backbone + FPN + heads (tests/golden/make_golden.py vovnet_specs)."""
     import os
     import numpy as np
     from oracle import dd3d_oracle as O
-    from tests.golden.make_golden import case_inputs
+    from tests.golden.make_golden import STRUCTURAL, case_inputs
     from tests.util import bundle
-    cfg, sd = bundle("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": spec}}})
+    exp, tag, over = STRUCTURAL[spec]
+    cfg, sd = bundle(exp, tag, over)
+    H, W = (64, 128) if "v99" in exp else (128, 256)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"vovnet_spec_{spec.replace('-', '').lower()}.npz"))
     t = lambda k: torch.from_numpy(g[k])  # noqa: E731
     with torch.no_grad():
-        res, st = O.dd3d_forward(sd, cfg, case_inputs(1, 64, 128, False, "kitti"))
+        res, st = O.dd3d_forward(sd, cfg, case_inputs(1, H, W, False, "kitti"))
     for l in (2, 3, 4):
         assert torch.allclose(st["features"][l], t(f"feat{l}"), rtol=1e-5, atol=1e-5)
         assert torch.allclose(st["logits"][l], t(f"logits{l}"), rtol=1e-5, atol=2e-5) and torch.allclose(st["depth"][l], t(f"depth{l}"), rtol=1e-5, atol=2e-5)
