@@ -170,12 +170,12 @@ def _tower(sd, p, x, level, num_convs, hook=None):
     return x
 
 
-def fcos2d_head(sd, features, num_convs=4, prefix="fcos2d_head", hook=None):
+def fcos2d_head(sd, features, num_convs=4, prefix="fcos2d_head", hook=None, num_box_convs=None):
     """fcos2d.py:130-156 FCOS2DHead.forward (v2; the Scale modules exist in the state dict iff USE_SCALE, fcos2d.py:104-108,146-148)."""
     logits, box2d_reg, centerness, cls_tower_out = [], [], [], []
     for l, f in enumerate(features):
         ct = _tower(sd, prefix + ".cls_tower", f, l, num_convs, hook)
-        bt = _tower(sd, prefix + ".box2d_tower", f, l, num_convs, hook)
+        bt = _tower(sd, prefix + ".box2d_tower", f, l, num_convs if num_box_convs is None else num_box_convs, hook)  # fcos2d.py:54
         logits.append(conv2d(sd, prefix + ".cls_logits", ct, padding=1))
         centerness.append(conv2d(sd, prefix + ".centerness", bt, padding=1))
         reg = conv2d(sd, prefix + ".box2d_reg", bt, padding=1)
@@ -583,7 +583,7 @@ def dd3d_forward(sd, cfg, batched_inputs, hook=None, stop_after_heads=False):
         for f, s in zip(features, strides)
     ]
     logits, box2d_reg, centerness, cls_tower_out = fcos2d_head(
-        sd, features, cfg["DD3D"]["FCOS2D"]["NUM_CLS_CONVS"], hook=hook
+        sd, features, cfg["DD3D"]["FCOS2D"]["NUM_CLS_CONVS"], hook=hook, num_box_convs=cfg["DD3D"]["FCOS2D"]["NUM_BOX_CONVS"]
     )
     stages.update(logits=logits, box2d_reg=box2d_reg, centerness=centerness)
     if cfg["MODEL"]["BOX3D_ON"]:  # core.py:38-42,90-92: without it the model is `only_box2d`

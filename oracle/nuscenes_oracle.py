@@ -236,7 +236,8 @@ def nuscenes_dd3d_forward(sd, cfg, batched_inputs):
         O.compute_features_locations(f.shape[-2], f.shape[-1], s, cfg["DD3D"]["FEATURE_LOCATIONS_OFFSET"])
         for f, s in zip(features, strides)
     ]
-    logits, box2d_reg, centerness, cls_tower_out = O.fcos2d_head(sd, features, cfg["DD3D"]["FCOS2D"]["NUM_CLS_CONVS"])
+    logits, box2d_reg, centerness, cls_tower_out = O.fcos2d_head(sd, features, cfg["DD3D"]["FCOS2D"]["NUM_CLS_CONVS"],
+                                                                     num_box_convs=cfg["DD3D"]["FCOS2D"]["NUM_BOX_CONVS"])
     quat, ctr, depth, size, conf = O.fcos3d_head(sd, features, cfg["DD3D"]["FCOS3D"]["NUM_CONVS"])
     attr = [O.conv2d(sd, "attr_logits", t, padding=1) for t in cls_tower_out]  # nuscenes_dd3d.py:371-374
     speed = [F.relu(O.conv2d(sd, "speed", t, padding=1)) for t in cls_tower_out]

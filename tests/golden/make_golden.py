@@ -282,6 +282,9 @@ STRUCTURAL = {  # name -> (experiment, calibration tag, overrides): construction
     "fpn-without-norm": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"NORM": ""}}}),
     "swapped-head-norms": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"FCOS2D": {"NORM": "FrozenBN"}, "FCOS3D": {"NORM": "BN"}}}),
     "bn-backbone": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"BACKBONE": {"NORM": "BN"}}}),
+    # towers of different depths, a narrower pyramid, fewer classes
+    "odd-towers": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"OUT_CHANNELS": 128}},
+                                                        "DD3D": {"NUM_CLASSES": 3, "FCOS2D": {"NUM_CLS_CONVS": 2, "NUM_BOX_CONVS": 3}, "FCOS3D": {"NUM_CONVS": 1}}}),
 }
 
 

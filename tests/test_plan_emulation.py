@@ -24,6 +24,9 @@ CASES = {
     "dla34_swapped_head_norms": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"FCOS2D": {"NORM": "FrozenBN"}, "FCOS3D": {"NORM": "BN"}}},
                                  "kitti", 1, 128, 256),
     "dla34_bn_backbone": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"BACKBONE": {"NORM": "BN"}}}, "kitti", 1, 128, 256),
+    "dla34_odd_towers": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"OUT_CHANNELS": 128}},
+                                                             "DD3D": {"NUM_CLASSES": 3, "FCOS2D": {"NUM_CLS_CONVS": 2, "NUM_BOX_CONVS": 3},
+                                                                      "FCOS3D": {"NUM_CONVS": 1}}}, "kitti", 1, 128, 256),
 }
 
 
@@ -85,7 +88,7 @@ def test_unbuilt_vovnet_spec_fails_loudly():
         META_ARCH_REGISTRY.get("DD3D")(cfg)
 
 
-@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE", "fpn-without-norm", "swapped-head-norms", "bn-backbone"])
+@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE", "fpn-without-norm", "swapped-head-norms", "bn-backbone", "odd-towers"])
 def test_oracle_vovnet_specs_match_reference_golden(spec):
     """The oracle the emulated plans are compared with is itself pinned for these construction variants: compact goldens from the
     reference's own backbone + FPN + heads (tests/golden/make_golden.py vovnet_specs)."""
