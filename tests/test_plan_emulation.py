@@ -134,3 +134,51 @@ def test_emulated_dense_depth_plan_matches_oracle(hiplib):
     assert done[-1] == "dd_upsample.4" and len(maps) == len(plan.depth_maps) == 5
     for l, (got, ref) in enumerate(zip(plan.depth_maps, maps)):
         assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), l
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_emulated_plan_matches_oracle_on_random_switch_combinations(hiplib, seed):
+    """Cross product of the construction switches (same generator as tests/golden/fuzz_reference.py, which checks the oracle against the
+    reference itself over these combinations): the dry-run plan executed on the CPU must reproduce the oracle's head maps."""
+    import random
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.engine import ForwardPlan
+    from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
+    from oracle import dd3d_oracle as O
+    from oracle import nuscenes_oracle as N
+    from tests.golden.fuzz_reference import random_case
+    import dd3d_amd.modeling  # noqa: F401
+    exp, tag, over, nusc, v99 = random_case(random.Random(100 + seed))
+    cfg = get_cfg(exp, over)
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    sd = make_state_dict(model, calib=load_calib(tag))
+    model.load_state_dict(sd, strict=True)
+    B, H, W = (6, 64, 128) if nusc else (1, 64 if v99 else 128, 128 if v99 else 256)
+    inputs = make_inputs(B, H, W, dataset="nusc" if nusc else "kitti")
+    div = model.backbone.size_divisibility
+    plan = ForwardPlan(model, B, H + (-H) % div, W + (-W) % div, device="cpu", dry_run=True)
+    model.stage_inputs(inputs, plan=plan)
+    with torch.no_grad():
+        emulate(plan)
+        _, st = N.nuscenes_dd3d_forward(sd, cfg, inputs) if nusc else O.dd3d_forward(sd, cfg, inputs, stop_after_heads=True)
+    C = cfg.DD3D.NUM_CLASSES
+
+    def close(got, ref, what):
+        err = float((got - ref).abs().max())
+        assert got.shape == ref.shape and err < 1e-4 * max(1.0, float(ref.abs().max())), (what, err, over)
+
+    for l in range(len(st["features"])):
+        close(plan.features[l].nchw(), st["features"][l], f"feature {l}")
+        close(plan.cls_maps[l].nchw(0, C), st["logits"][l], f"logits {l}")
+        close(plan.b2d_maps[l].nchw(0, 4), st["box2d_reg"][l], f"box2d_reg {l}")
+        close(plan.b2d_maps[l].nchw(4, 1), st["centerness"][l], f"centerness {l}")
+        if "quat" in st:
+            fused = torch.cat([st["quat"][l], st["ctr"][l], st["depth"][l], st["size"][l], st["conf"][l]], 1)
+            close(plan.b3d_maps[l].nchw(0, fused.shape[1]), fused, f"box3d {l}")
+    a = plan.select_args
+    inf, c3 = cfg.DD3D.FCOS2D.INFERENCE, cfg.DD3D.FCOS3D
+    assert (a.thresh_with_ctr, a.topk, a.loc_offset_half) == (int(inf.THRESH_WITH_CTR), int(inf.PRE_NMS_TOPK), int(cfg.DD3D.FEATURE_LOCATIONS_OFFSET == "half"))
+    assert abs(a.pre_nms_thresh - float(inf.PRE_NMS_THRESH)) < 1e-7
+    if cfg.MODEL.BOX3D_ON:
+        assert (a.class_agnostic_3d, a.allocentric, a.depth_is_distance, a.scale_depth_by_focal) == (
+            int(c3.CLASS_AGNOSTIC_BOX3D), int(c3.PREDICT_ALLOCENTRIC_ROT), int(c3.PREDICT_DISTANCE), int(c3.SCALE_DEPTH_BY_FOCAL_LENGTHS))
