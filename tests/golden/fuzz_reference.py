@@ -118,5 +118,52 @@ def main():
     print("all", n, "cases agree with the reference")
 
 
+def dense_depth_sweep():
+    """DD3DDenseDepth (training-mode forward of the reference with a recorder in place of the loss, as in make_golden.dense_depth_golden)
+    against oracle/dense_depth_oracle.py over the switches its forward reads."""
+    import itertools
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
+    from oracle import dense_depth_oracle as D
+    ref_shims.install()
+    sys.modules["detectron2.config.config"] = sys.modules["detectron2.config"]
+    from tridet.modeling.dd3d.dense_depth import DD3DDenseDepth
+    for offset, by_focal, use_scale, convs in itertools.product(("none", "half"), (True, False), (True, False), (1, 4)):
+        over = _merge(dict(TRAINING_ONLY_KEYS), {
+            "MODEL": {"META_ARCHITECTURE": "DD3DDenseDepth"},
+            "DD3D": {"IN_FEATURES": ["p3", "p4", "p5", "p6", "p7"], "FEATURE_LOCATIONS_OFFSET": offset,
+                     "FCOS3D": {"DEPTH_HEAD": {"LOSS_TYPE": "L1", "LOSS_WEIGHT": 1.0}, "SCALE_DEPTH_BY_FOCAL_LENGTHS": by_focal, "USE_SCALE": use_scale,
+                                "NUM_CONVS": convs}}})
+        cfg = get_cfg("dd3d_kitti_dla34", over)
+        sd = make_state_dict(META_ARCH_REGISTRY.get("DD3DDenseDepth")(cfg), calib=load_calib("dla34_kitti"))
+        ref = DD3DDenseDepth(cfg)
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        recorded = []
+
+        class Recorder(torch.nn.Module):
+            def forward(self, pred, gt, masks=None):
+                recorded.append(pred.detach().clone())
+                return {"loss_dense_depth": pred.sum() * 0.0}
+
+        ref.depth_loss = Recorder()
+        ref.in_strides = ref.fcos3d_head.in_strides  # see make_golden.dense_depth_golden
+        inputs = make_inputs(2, 128, 256)
+        inputs[1]["intrinsics"] = inputs[1]["intrinsics"] * torch.tensor([[1.25], [1.25], [1.0]])
+        ref_inputs = [dict(x, depth=torch.zeros(1, 128, 256)) for x in inputs]
+        with torch.no_grad():
+            ref(ref_inputs)
+            maps, _ = D.dense_depth_forward(sd, cfg, inputs)
+        assert len(recorded) == len(maps) == 5
+        for l, (a, b) in enumerate(zip(maps, recorded)):
+            compare(a, b, f"depth map {l}", atol=1e-5)
+        print(f"ok  dense depth  offset {offset:4s}  scale-by-focal {by_focal!s:5s}  use_scale {use_scale!s:5s}  tower convs {convs}", flush=True)
+    print("all dense-depth settings agree with the reference")
+
+
 if __name__ == "__main__":
-    main()
+    if "dense_depth" in sys.argv[1:]:
+        dense_depth_sweep()
+    else:
+        main()

@@ -115,12 +115,18 @@ def test_oracle_vovnet_specs_match_reference_golden(spec):
         assert torch.allclose(r["pred_boxes3d"]["depth"], t("det0_depth"), rtol=1e-5)
 
 
-def test_emulated_dense_depth_plan_matches_oracle(hiplib):
-    from dd3d_amd import META_ARCH_REGISTRY
+@pytest.mark.parametrize("offset,by_focal,use_scale,convs", [("none", True, True, 4), ("half", False, True, 1), ("half", True, False, 4), ("none", False, False, 1)])
+def test_emulated_dense_depth_plan_matches_oracle(hiplib, offset, by_focal, use_scale, convs):
+    """(The oracle agrees with the reference's DD3DDenseDepth on all 16 combinations of these switches: fuzz_reference.py dense_depth.)"""
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
     from dd3d_amd.engine import DenseDepthPlan
+    from dd3d_amd.synthetic import load_calib, make_state_dict
     from oracle import dense_depth_oracle as D
-    from tests.test_dense_depth import _case
-    cfg, sd, inputs = _case()
+    from tests.test_dense_depth import OVER, _case
+    _, _, inputs = _case()
+    cfg = get_cfg("dd3d_kitti_dla34", {"MODEL": OVER["MODEL"], "DD3D": dict(OVER["DD3D"], FEATURE_LOCATIONS_OFFSET=offset, FCOS3D={
+        "SCALE_DEPTH_BY_FOCAL_LENGTHS": by_focal, "USE_SCALE": use_scale, "NUM_CONVS": convs})})
+    sd = make_state_dict(META_ARCH_REGISTRY.get("DD3DDenseDepth")(cfg), calib=load_calib("dla34_kitti"))
     model = META_ARCH_REGISTRY.get("DD3DDenseDepth")(cfg)
     model.load_state_dict(sd, strict=True)
     plan = DenseDepthPlan(model, 2, 128, 256, device="cpu", dry_run=True)
