@@ -321,3 +321,30 @@ def test_kernel_register_budgets(hiplib, tmp_path):
     for k in table:  # every 8-wave split-bf16 tile shares a SIMD between two waves
         if k[0] == "conv_igemm_bf16x3_kernel" and k[1][2] * k[1][3] == 8:
             assert vg(k) <= 256, (k, vg(k))
+
+
+def test_cabi_argument_validation_without_a_gpu(hiplib):
+    """Error behaviour of the boundary: bad arguments are rejected on the host before any launch, with an error code and a message
+    from dd3d_last_error(); empty inputs are a no-op success."""
+    import ctypes as C
+    from dd3d_amd import hip
+    L = hiplib
+
+    def err():
+        return L.dd3d_last_error().decode()
+
+    a = hip.SelectArgs()
+    a.topk, a.num_levels, a.B, a.num_classes = 100000, 5, 1, 5
+    assert L.dd3d_fcos_select_decode(C.byref(a), None) != 0 and "topk=100000 exceeds" in err()
+    n = hip.NmsArgs()
+    n.G, n.num_levels, n.topk = 1, 5, 5000
+    assert L.dd3d_nms_finalize(C.byref(n), None) != 0 and "levels*topk=25000 exceeds" in err()
+    assert L.dd3d_format_boxes3d(None, None, None, None, 5, None) != 0 and "null pointer" in err()
+    assert L.dd3d_format_boxes3d(None, None, None, None, 0, None) == 0  # nothing to do
+    assert L.dd3d_rotate_iou_eval(None, None, None, 3, 3, -1, None) != 0 and "null pointer" in err()
+    assert L.dd3d_rotate_iou_eval(None, None, None, 0, 3, -1, None) == 0
+    cl = hip.ConvLaunch()
+    assert L.dd3d_conv2d_igemm_f32(C.byref(cl), None) != 0 and "null descriptor" in err()
+    assert L.dd3d_resize_bilinear_u8(C.byref(hip.ResizeArgs()), None) != 0 and "bad arguments" in err()
+    with pytest.raises(RuntimeError, match="null pointer"):
+        hip.check(L.dd3d_format_boxes3d(None, None, None, None, 5, None), "format_boxes3d")
