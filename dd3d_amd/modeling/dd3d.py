@@ -51,6 +51,7 @@ class DD3D(nn.Module):
         self.register_buffer("pixel_mean", torch.Tensor(list(cfg.MODEL.PIXEL_MEAN)).view(-1, 1, 1))
         self.register_buffer("pixel_std", torch.Tensor(list(cfg.MODEL.PIXEL_STD)).view(-1, 1, 1))
         self._plans = {}
+        self.max_cached_plans = 8  # launch plans kept per model (one per (batch, padded size, flags)); least recently used goes first
         self.use_graph = True
         self.math = None  # None: DD3D_MATH / the default ("bf16x3"); or "f32" / "bf16x3" (set before the first forward)
         self.training = False
@@ -90,13 +91,21 @@ class DD3D(nn.Module):
     def get_plan(self, B, Hp, Wp, world_size=1, rank=0, exchange=None):
         exchange = world_size > 1 if exchange is None else bool(exchange)
         key = (B, Hp, Wp, world_size, rank, exchange, self.math) + self._sync_flags()
-        plan = self._plans.get(key)
+        plan = self._plans.pop(key, None)
         if plan is None:
             plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank, exchange=exchange)
             if self.use_graph and not exchange:
                 plan.capture()
-            self._plans[key] = plan
+        self._plans[key] = plan  # (re-)inserted last = most recently used
+        self._evict_plans()
         return plan
+
+    def _evict_plans(self):
+        """Inputs of ever-changing size would otherwise pin a buffer set (0.5 - 3 GB) per size for the life of the model."""
+        while len(self._plans) > max(1, int(self.max_cached_plans)):
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()  # its last replay may still be running on the buffers about to be released
+            self._plans.pop(next(iter(self._plans)))
 
     # ------------------------------------------------------------------ host side of forward
     def stage_inputs(self, batched_inputs, plan=None):

@@ -87,12 +87,16 @@ class DD3DDenseDepth(nn.Module):
     def get_plan(self, B, Hp, Wp):
         from dd3d_amd.engine import DenseDepthPlan
         key = (B, Hp, Wp, self.math)
-        plan = self._plans.get(key)
+        plan = self._plans.pop(key, None)
         if plan is None:
             plan = DenseDepthPlan(self, B, Hp, Wp)
             if self.use_graph:
                 plan.capture()
-            self._plans[key] = plan
+        self._plans[key] = plan  # most recently used last; bounded like DD3D.get_plan
+        while len(self._plans) > 8:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self._plans.pop(next(iter(self._plans)))
         return plan
 
     @torch.no_grad()

@@ -348,3 +348,30 @@ def test_cabi_argument_validation_without_a_gpu(hiplib):
     assert L.dd3d_resize_bilinear_u8(C.byref(hip.ResizeArgs()), None) != 0 and "bad arguments" in err()
     with pytest.raises(RuntimeError, match="null pointer"):
         hip.check(L.dd3d_format_boxes3d(None, None, None, None, 5, None), "format_boxes3d")
+
+
+def test_plan_cache_is_bounded_lru(kitti_dla34, monkeypatch):
+    """model.get_plan keeps at most `max_cached_plans` plans, evicting the least recently used one."""
+    import dd3d_amd.modeling.dd3d as M
+    cfg, _, _ = kitti_dla34
+    built = []
+
+    class FakePlan:
+        def __init__(self, model, B, Hp, Wp, **kw):
+            self.key = (B, Hp, Wp)
+            built.append(self.key)
+
+        def capture(self):
+            pass
+
+    monkeypatch.setattr(M, "ForwardPlan", FakePlan)
+    model = M.DD3D(cfg)
+    model.max_cached_plans = 3
+    a = model.get_plan(1, 128, 256)
+    model.get_plan(1, 128, 384)
+    model.get_plan(1, 256, 256)
+    assert model.get_plan(1, 128, 256) is a and len(built) == 3  # hit: no rebuild, becomes most recent
+    model.get_plan(2, 128, 256)  # evicts (1, 128, 384), the least recently used
+    assert [p.key for p in model._plans.values()] == [(1, 256, 256), (1, 128, 256), (2, 128, 256)]
+    model.get_plan(1, 128, 384)
+    assert built[-1] == (1, 128, 384) and len(built) == 5 and len(model._plans) == 3
