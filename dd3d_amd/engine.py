@@ -14,6 +14,8 @@ Reference behaviour being reproduced: tridet/modeling/dd3d/core.py:64-164 (DD3D.
 import ctypes as C
 import math
 
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
@@ -514,7 +516,9 @@ class ForwardPlan(PlanBase):
         else:
             feats = self._vovnet(bb.bottom_up, img.view())
         self.bottom_up = feats
-        self.features = self._fpn(bb, feats)  # list of views, finest first
+        outs = self._fpn(bb, feats)  # name -> view, finest first
+        # the heads see DD3D.IN_FEATURES (core.py:32-34,84): all FPN outputs in every reference config, a subset is allowed
+        self.features = [outs[n] for n in getattr(model, "in_features", list(outs))]
         if self.fpn_tail_join is not None:
             self.join(self.fpn_tail_join)  # P6 / P7 (side branch) feed the towers
         self.strides = [s.stride for s in model.backbone_output_shape]
@@ -735,7 +739,7 @@ class ForwardPlan(PlanBase):
             self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
             results[f"p{st}"] = out
         self.fpn_tail_join = 3 if fpn.top_block is not None else None
-        return [results[n] for n in fpn._out_features]
+        return OrderedDict((n, results[n]) for n in fpn._out_features)
 
     # ------------------------------------------------------------------ heads (fcos2d.py:130-156, fcos3d.py:160-188)
     def _heads(self, model, feats):

@@ -30,8 +30,6 @@ class DD3D(nn.Module):
         backbone_output_shape = self.backbone.output_shape()
         self.in_features = cfg.DD3D.IN_FEATURES or list(backbone_output_shape.keys())
         self.backbone_output_shape = [backbone_output_shape[f] for f in self.in_features]
-        if list(self.in_features) != list(backbone_output_shape.keys()):
-            raise NotImplementedError("DD3D.IN_FEATURES must select every FPN output (all reference configs do)")
         self.feature_locations_offset = cfg.DD3D.FEATURE_LOCATIONS_OFFSET
 
         self.fcos2d_head = FCOS2DHead(cfg, self.backbone_output_shape)

@@ -560,7 +560,7 @@ def dd3d_backbone(sd, cfg, x, hook=None):
         fpn = fpn_forward(sd, bu, feats, strides, top_block="p6", hook=hook)
     else:
         raise KeyError(builder)
-    names = list(fpn.keys())
+    names = list(cfg["DD3D"]["IN_FEATURES"] or fpn.keys())  # core.py:32-34,84: the heads see DD3D.IN_FEATURES (default: every output)
     return [fpn[n] for n in names], [2**int(n[1:]) for n in names], bu
 
 

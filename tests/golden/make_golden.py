@@ -285,6 +285,8 @@ STRUCTURAL = {  # name -> (experiment, calibration tag, overrides): construction
     # towers of different depths, a narrower pyramid, fewer classes
     "odd-towers": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"OUT_CHANNELS": 128}},
                                                         "DD3D": {"NUM_CLASSES": 3, "FCOS2D": {"NUM_CLS_CONVS": 2, "NUM_BOX_CONVS": 3}, "FCOS3D": {"NUM_CONVS": 1}}}),
+    # heads on a subset of the pyramid (core.py:32-34,84)
+    "three-levels": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"IN_FEATURES": ["p3", "p4", "p5"]}}),
 }
 
 
@@ -308,8 +310,9 @@ def vovnet_specs_golden():
             feats = [feats[f] for f in ref.in_features]
             logits, _, _, _ = ref.fcos2d_head(feats)
             _, _, depth, _, _, _ = ref.fcos3d_head(feats)
-            for l in (2, 3, 4):
-                out[f"feat{l}"], out[f"logits{l}"], out[f"depth{l}"] = feats[l].numpy(), logits[l].numpy(), depth[l].numpy()
+            for l in range(len(feats)):
+                if feats[l].shape[-2] * feats[l].shape[-1] <= 200:  # the coarse levels: keeps the fixture small
+                    out[f"feat{l}"], out[f"logits{l}"], out[f"depth{l}"] = feats[l].numpy(), logits[l].numpy(), depth[l].numpy()
             inst = ref(inputs)[0]["instances"]
         out["det0_boxes"], out["det0_scores_3d"], out["det0_classes"] = inst.pred_boxes.tensor.numpy(), inst.scores_3d.numpy(), inst.pred_classes.numpy()
         out["det0_locations"], out["det0_depth"] = inst.locations.numpy(), inst.pred_boxes3d.depth.numpy()
