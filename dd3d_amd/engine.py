@@ -590,6 +590,59 @@ class ForwardPlan(PlanBase):
         self._tree(m.tree1, x, name + ".tree1", dst=t1, bottom=bottom, bottom_branch=bb)  # tree1 pools the same x: share `bottom`
         return self._tree(m.tree2, t1, name + ".tree2", dst=dst, cat=cat2)
 
+    def _block_any(self, m, x, residual, out, name):
+        """BasicBlock (dla.py:24-62) or Bottleneck (dla.py:65-100: 1x1 -> relu -> 3x3 (stride) -> relu -> 1x1, += residual, relu)."""
+        from dd3d_amd.modeling.dla import Bottleneck
+        if not isinstance(m, Bottleneck):
+            return self._block(m, x, residual, out, name)
+        c = m.conv1.out_channels
+        b1 = self.buf(name + ".b1", x.B, x.H, x.W, c)
+        self.conv_module(m.conv1, x, b1.view(), relu=True, name=name + ".conv1")
+        b2 = self.buf(name + ".b2", out.B, out.H, out.W, c)
+        self.conv_module(m.conv2, b1.view(), b2.view(), relu=True, name=name + ".conv2")
+        self.conv_module(m.conv3, b2.view(), out, relu=True, res=residual, name=name + ".conv3")
+
+    def _tree_generic(self, m, x, name, dst=None, cat=None, off=0):
+        """Tree.forward (dla.py:233-247) for any depth / block / root kind (the DLA-34 trees keep their own, side-branched lowering in
+        `_tree`).  The innermost root of a tree2 chain reads ONE buffer [x2 | x1 | bottom (level_root) | x1 of the enclosing trees, outermost
+        first] -- the reference's `children` list -- whose slices are written in place by their producers; `off` is the next free slice."""
+        B, Ho, Wo = x.B, x.H // m.stride, x.W // m.stride
+        oc, ic = m.out_channels, m.in_channels
+        bottom = None
+        if cat is None:  # this tree starts a chain: its innermost root fixes the buffer
+            inner = m
+            while inner.levels > 1:
+                inner = inner.tree2
+            cat = self.buf(name + ".cat", B, Ho, Wo, inner.root_dim)
+            off = 2 * oc
+            if m.level_root:
+                if m.stride == 1:
+                    raise NotImplementedError("level_root without downsample does not occur in any DLA")
+                bottom = cat.view(off, ic)
+                self.maxpool(x, bottom, name + ".pool")
+                off += ic
+        if m.levels == 1:
+            if bottom is None:
+                if m.stride > 1:
+                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic).view()
+                    self.maxpool(x, bottom, name + ".pool")
+                else:
+                    bottom = x
+            residual = bottom
+            if m.project is not None:
+                residual = self.buf(name + ".proj", B, Ho, Wo, oc).view()
+                self.conv_module(m.project, bottom, residual, name=name + ".project")
+            x1, x2 = cat.view(oc, oc), cat.view(0, oc)
+            self._block_any(m.tree1, x, residual, x1, name + ".tree1")
+            self._block_any(m.tree2, x1, x1, x2, name + ".tree2")
+            if dst is None:
+                dst = self.buf(name + ".out", B, Ho, Wo, oc).view()
+            self.conv_module(m.root.conv, cat.view(), dst, relu=True, res=x2 if m.root.residual else None, name=name + ".root")
+            return dst
+        t1 = cat.view(off, oc)
+        self._tree_generic(m.tree1, x, name + ".tree1", dst=t1)  # a chain of its own
+        return self._tree_generic(m.tree2, t1, name + ".tree2", dst=dst, cat=cat, off=off + oc)
+
     def _dla(self, dla, img):
         B, H, W = img.B, img.H, img.W
         ch = dla.channels
@@ -605,8 +658,11 @@ class ForwardPlan(PlanBase):
             self.conv_module(conv, x, y.view(), relu=True, name=f"level1.{i}")
             x = y.view()
         outs = {"level0": None, "level1": x}
+        from dd3d_amd.modeling.dla import BasicBlock
+        plain34 = dla.block is BasicBlock and max(dla.levels) <= 2 and not dla.residual_root  # DLA-34: the measured lowering
         for lvl in range(2, 6):
-            x = self._tree(getattr(dla, f"level{lvl}"), x, f"level{lvl}")
+            tree = getattr(dla, f"level{lvl}")
+            x = self._tree(tree, x, f"level{lvl}") if plain34 and not getattr(self.model, "force_generic_dla", False) else self._tree_generic(tree, x, f"level{lvl}")
             outs[f"level{lvl}"] = x
         return {k: outs[k] for k in dla._out_features}
 

@@ -38,28 +38,43 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
 
+class Bottleneck(nn.Module):
+    """dla.py:65-100: 1x1 (planes / 2) -> 3x3 (stride) -> 1x1, += residual, relu."""
+    expansion = 2
+
+    def __init__(self, inplanes, planes, stride=1, norm="BN"):
+        super().__init__()
+        bottle = planes // Bottleneck.expansion
+        self.conv1 = Conv2d(inplanes, bottle, 1, bias=norm == "", norm=get_norm(norm, bottle))
+        self.conv2 = Conv2d(bottle, bottle, 3, stride=stride, padding=1, bias=norm == "", norm=get_norm(norm, bottle))
+        self.conv3 = Conv2d(bottle, planes, 1, bias=norm == "", norm=get_norm(norm, planes))
+        self.stride = stride
+
+
 class Root(nn.Module):
-    """dla.py:146-167 (kernel_size 1, residual False in every config)."""
-    def __init__(self, in_channels, out_channels, norm="BN"):
+    """dla.py:146-167 (kernel_size 1); `residual`: += the first child, i.e. the tree2 block's output (DLA-102 / DLA-169)."""
+    def __init__(self, in_channels, out_channels, norm="BN", residual=False):
         super().__init__()
         self.conv = Conv2d(in_channels, out_channels, 1, bias=norm == "", norm=get_norm(norm, out_channels))
+        self.residual = residual
 
 
 class Tree(nn.Module):
     """dla.py:170-247."""
-    def __init__(self, levels, in_channels, out_channels, stride=1, level_root=False, root_dim=0, norm="BN"):
+    def __init__(self, levels, in_channels, out_channels, stride=1, level_root=False, root_dim=0, norm="BN", block=BasicBlock, root_residual=False):
         super().__init__()
         if root_dim == 0:
             root_dim = 2 * out_channels
         if level_root:
             root_dim += in_channels
         if levels == 1:
-            self.tree1 = BasicBlock(in_channels, out_channels, stride, norm=norm)
-            self.tree2 = BasicBlock(out_channels, out_channels, 1, norm=norm)
-            self.root = Root(root_dim, out_channels, norm=norm)
+            self.tree1 = block(in_channels, out_channels, stride, norm=norm)
+            self.tree2 = block(out_channels, out_channels, 1, norm=norm)
+            self.root = Root(root_dim, out_channels, norm=norm, residual=root_residual)
         else:
-            self.tree1 = Tree(levels - 1, in_channels, out_channels, stride, root_dim=0, norm=norm)
-            self.tree2 = Tree(levels - 1, out_channels, out_channels, root_dim=root_dim + out_channels, norm=norm)
+            self.tree1 = Tree(levels - 1, in_channels, out_channels, stride, root_dim=0, norm=norm, block=block, root_residual=root_residual)
+            self.tree2 = Tree(levels - 1, out_channels, out_channels, root_dim=root_dim + out_channels, norm=norm, block=block,
+                              root_residual=root_residual)
         self.level_root, self.root_dim, self.levels, self.stride = level_root, root_dim, levels, stride
         self.in_channels, self.out_channels = in_channels, out_channels
         self.project = None
@@ -68,17 +83,18 @@ class Tree(nn.Module):
 
 
 class DLA(nn.Module):
-    """dla.py:250-355 with BasicBlock."""
-    def __init__(self, levels, channels, out_features=None, norm="BN"):
+    """dla.py:250-355 with BasicBlock or Bottleneck blocks (the BottleneckX variants need grouped convolutions, not built)."""
+    def __init__(self, levels, channels, out_features=None, norm="BN", block=BasicBlock, residual_root=False):
         super().__init__()
-        self.levels, self.channels = levels, channels
+        self.levels, self.channels, self.block, self.residual_root = levels, channels, block, residual_root
         self.base_layer = Conv2d(3, channels[0], 7, stride=1, padding=3, bias=norm == "", norm=get_norm(norm, channels[0]))
         self.level0 = self._make_conv_level(channels[0], channels[0], levels[0], norm=norm)
         self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2, norm=norm)
-        self.level2 = Tree(levels[2], channels[1], channels[2], 2, level_root=False, norm=norm)
-        self.level3 = Tree(levels[3], channels[2], channels[3], 2, level_root=True, norm=norm)
-        self.level4 = Tree(levels[4], channels[3], channels[4], 2, level_root=True, norm=norm)
-        self.level5 = Tree(levels[5], channels[4], channels[5], 2, level_root=True, norm=norm)
+        kw = dict(norm=norm, block=block, root_residual=residual_root)
+        self.level2 = Tree(levels[2], channels[1], channels[2], 2, level_root=False, **kw)
+        self.level3 = Tree(levels[3], channels[2], channels[3], 2, level_root=True, **kw)
+        self.level4 = Tree(levels[4], channels[3], channels[4], 2, level_root=True, **kw)
+        self.level5 = Tree(levels[5], channels[4], channels[5], 2, level_root=True, **kw)
         for m in self.modules():
             if isinstance(m, Conv2d):
                 _msra_fill(m)
@@ -112,7 +128,21 @@ def dla34(cfg):
     return DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], out_features=list(cfg.OUT_FEATURES), norm=cfg.NORM)
 
 
-DLA_NAME_TO_BUILDER = {"DLA-34": dla34}  # the only DLA variant any reference config selects
+def _bottleneck_dla(levels, channels, residual_root=False):
+    def build(cfg):
+        return DLA(levels, channels, out_features=list(cfg.OUT_FEATURES), norm=cfg.NORM, block=Bottleneck, residual_root=residual_root)
+    return build
+
+
+# dla.py:359-441.  DLA-34 is the one the reference's configs select; the Bottleneck variants reuse the same kernels; the BottleneckX ones
+# (DLA-X-46-C, DLA-X-60-C, DLA-X-60, DLA-X-102, DLA-X-102-64) need grouped 3x3 convolutions and are not built.
+DLA_NAME_TO_BUILDER = {
+    "DLA-34": dla34,
+    "DLA-46-C": _bottleneck_dla([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256]),
+    "DLA-60": _bottleneck_dla([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024]),
+    "DLA-102": _bottleneck_dla([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], residual_root=True),
+    "DLA-169": _bottleneck_dla([1, 1, 2, 3, 5, 1], [16, 32, 128, 256, 512, 1024], residual_root=True),
+}
 
 
 class LastLevelP6P7(nn.Module):
@@ -181,8 +211,7 @@ def build_dla_backbone(cfg, input_shape):
     """dla.py:445-459 (cfg = cfg.FE.BACKBONE)."""
     assert input_shape.channels == 3, "Only supports 3-channel input for now."
     if cfg.NAME not in DLA_NAME_TO_BUILDER:  # dla.py:430-441 also lists the Bottleneck / BottleneckX variants (DLA-46-C ... DLA-169)
-        raise NotImplementedError(f"DLA variant {cfg.NAME!r} is not built; available: {sorted(DLA_NAME_TO_BUILDER)} "
-                                  "(the only one the reference's configs select)")
+        raise NotImplementedError(f"DLA variant {cfg.NAME!r} is not built (grouped-convolution BottleneckX); available: {sorted(DLA_NAME_TO_BUILDER)}")
     return DLA_NAME_TO_BUILDER[cfg.NAME](cfg)
 
 

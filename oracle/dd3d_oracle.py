@@ -73,13 +73,24 @@ def _basic_block(sd, p, x, stride, residual=None, hook=None):
     return F.relu(out + residual)
 
 
-def _root(sd, p, xs, hook=None):
-    """dla.py:146-167 Root: 1x1 conv over torch.cat(children, 1) + norm + relu (residual_root False)."""
-    return conv2d(sd, p + ".conv", torch.cat(xs, 1), norm=p + ".conv.norm", relu=True, hook=hook)
+def _bottleneck(sd, p, x, stride, residual=None, hook=None):
+    """dla.py:65-100 Bottleneck: conv1(1x1)+norm, relu, conv2(3x3,stride)+norm, relu, conv3(1x1)+norm, += residual, relu."""
+    if residual is None:
+        residual = x
+    out = conv2d(sd, p + ".conv1", x, norm=p + ".conv1.norm", relu=True, hook=hook)
+    out = conv2d(sd, p + ".conv2", out, stride=stride, padding=1, norm=p + ".conv2.norm", relu=True, hook=hook)
+    out = conv2d(sd, p + ".conv3", out, norm=p + ".conv3.norm", hook=hook)
+    return F.relu(out + residual)
 
 
-def _tree(sd, p, x, levels, in_ch, out_ch, stride, level_root, children=None, hook=None):
-    """dla.py:170-247 Tree.forward.  ``project`` exists iff in!=out and tree1 is a BasicBlock
+def _root(sd, p, xs, hook=None, residual=False):
+    """dla.py:146-167 Root: 1x1 conv over torch.cat(children, 1) + norm (+ children[0] iff residual) + relu."""
+    y = conv2d(sd, p + ".conv", torch.cat(xs, 1), norm=p + ".conv.norm", hook=hook)
+    return F.relu(y + xs[0] if residual else y)
+
+
+def _tree(sd, p, x, levels, in_ch, out_ch, stride, level_root, children=None, hook=None, block=_basic_block, root_residual=False):
+    """dla.py:170-247 Tree.forward.  ``project`` exists iff in!=out and tree1 is a block, not a Tree
     (dla.py:227-231); ``downsample`` = MaxPool2d(stride) iff stride>1 (dla.py:224-225)."""
     children = [] if children is None else children
     bottom = F.max_pool2d(x, stride, stride=stride) if stride > 1 else x
@@ -90,37 +101,49 @@ def _tree(sd, p, x, levels, in_ch, out_ch, stride, level_root, children=None, ho
     if level_root:
         children.append(bottom)
     if levels == 1:
-        x1 = _basic_block(sd, p + ".tree1", x, stride, residual, hook=hook)
-        x2 = _basic_block(sd, p + ".tree2", x1, 1, None, hook=hook)
-        return _root(sd, p + ".root", [x2, x1] + children, hook=hook)
+        x1 = block(sd, p + ".tree1", x, stride, residual, hook=hook)
+        x2 = block(sd, p + ".tree2", x1, 1, None, hook=hook)
+        return _root(sd, p + ".root", [x2, x1] + children, hook=hook, residual=root_residual)
     # levels > 1: tree1 is itself a Tree and ignores `residual` (dla.py:236-238 comment).
-    x1 = _tree(sd, p + ".tree1", x, levels - 1, in_ch, out_ch, stride, False, None, hook=hook)
+    x1 = _tree(sd, p + ".tree1", x, levels - 1, in_ch, out_ch, stride, False, None, hook=hook, block=block, root_residual=root_residual)
     children.append(x1)
-    return _tree(sd, p + ".tree2", x1, levels - 1, out_ch, out_ch, 1, False, children, hook=hook)
+    return _tree(sd, p + ".tree2", x1, levels - 1, out_ch, out_ch, 1, False, children, hook=hook, block=block, root_residual=root_residual)
 
 
 DLA34_LEVELS = [1, 1, 1, 2, 2, 1]  # dla.py:359-361
 DLA34_CHANNELS = [16, 32, 64, 128, 256, 512]
+# name -> (levels, channels, block, residual_root): dla.py:359-427 (the BottleneckX variants are not restated)
+DLA_SPECS = {
+    "DLA-34": (DLA34_LEVELS, DLA34_CHANNELS, _basic_block, False),
+    "DLA-46-C": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], _bottleneck, False),
+    "DLA-60": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, False),
+    "DLA-102": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, True),
+    "DLA-169": ([1, 1, 2, 3, 5, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, True),
+}
+
+
+def dla_forward(sd, x, name="DLA-34", out_features=("level3", "level4", "level5"), prefix="backbone.bottom_up", hook=None):
+    """dla.py:346-355 DLA.forward.  Layer construction: base_layer 7x7 s1 p3 (dla.py:271-280), level0/level1 = _make_conv_level
+    (dla.py:327-344: levels[i] convs, the first one strided), level2..5 = Tree (dla.py:283-294)."""
+    p = prefix
+    levels, ch, block, residual_root = DLA_SPECS[name]
+    outs = OrderedDict()
+    x = conv2d(sd, p + ".base_layer", x, padding=3, norm=p + ".base_layer.norm", relu=True, hook=hook)
+    for i in range(levels[0]):
+        x = conv2d(sd, f"{p}.level0.{i}", x, padding=1, norm=f"{p}.level0.{i}.norm", relu=True, hook=hook)
+    outs["level0"] = x
+    for i in range(levels[1]):
+        x = conv2d(sd, f"{p}.level1.{i}", x, stride=2 if i == 0 else 1, padding=1, norm=f"{p}.level1.{i}.norm", relu=True, hook=hook)
+    outs["level1"] = x
+    for lvl in range(2, 6):
+        x = _tree(sd, f"{p}.level{lvl}", x, levels[lvl], ch[lvl - 1], ch[lvl], 2, level_root=(lvl >= 3), hook=hook, block=block,
+                  root_residual=residual_root)
+        outs[f"level{lvl}"] = x
+    return OrderedDict((k, v) for k, v in outs.items() if k in out_features)
 
 
 def dla34_forward(sd, x, out_features=("level3", "level4", "level5"), prefix="backbone.bottom_up", hook=None):
-    """dla.py:346-355 DLA.forward with the dla34 spec (dla.py:359-361).  Layer construction:
-    base_layer 7x7 s1 p3 (dla.py:271-280), level0/level1 = _make_conv_level (dla.py:327-344),
-    level2..5 = Tree (dla.py:283-294)."""
-    p = prefix
-    ch = DLA34_CHANNELS
-    outs = OrderedDict()
-    x = conv2d(sd, p + ".base_layer", x, padding=3, norm=p + ".base_layer.norm", relu=True, hook=hook)
-    x = conv2d(sd, p + ".level0.0", x, padding=1, norm=p + ".level0.0.norm", relu=True, hook=hook)
-    outs["level0"] = x
-    x = conv2d(sd, p + ".level1.0", x, stride=2, padding=1, norm=p + ".level1.0.norm", relu=True, hook=hook)
-    outs["level1"] = x
-    for lvl in range(2, 6):
-        x = _tree(
-            sd, f"{p}.level{lvl}", x, DLA34_LEVELS[lvl], ch[lvl - 1], ch[lvl], 2, level_root=(lvl >= 3), hook=hook
-        )
-        outs[f"level{lvl}"] = x
-    return OrderedDict((k, v) for k, v in outs.items() if k in out_features)
+    return dla_forward(sd, x, "DLA-34", out_features, prefix, hook)
 
 
 # ----------------------------------------------------------------------------------------
@@ -550,7 +573,7 @@ def dd3d_backbone(sd, cfg, x, hook=None):
     if builder == "build_fcos_dla_fpn_backbone_p67":  # dla.py:536-561
         feats = cfg["FE"]["BACKBONE"]["OUT_FEATURES"]
         strides = [2**int(f[len("level"):]) for f in feats]
-        bu = dla34_forward(sd, x, tuple(feats), hook=hook)
+        bu = dla_forward(sd, x, cfg["FE"]["BACKBONE"]["NAME"], tuple(feats), hook=hook)
         fpn = fpn_forward(sd, bu, feats, strides, top_block="p6p7", hook=hook)
     elif builder == "build_fcos_vovnet_fpn_backbone_p6":
         from oracle.vovnet_oracle import vovnet_forward  # vovnet.py:428-454

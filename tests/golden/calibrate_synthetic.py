@@ -1,6 +1,6 @@
 """Offline calibration of the synthetic weights (dev tool; run once per architecture, result committed).
 
-    python tests/golden/calibrate_synthetic.py dd3d_kitti_dla34 dla34_kitti
+    python tests/golden/calibrate_synthetic.py dd3d_kitti_dla34 dla34_kitti [backbone NAME override, e.g. DLA-60]
 
 Runs the CPU oracle on synthetic image 0 at the benchmark resolution and records, for every norm layer, the
 (mean, std) of its input activation and, for every predictor conv, a (gain, bias) -- see
@@ -20,8 +20,8 @@ from dd3d_amd.synthetic import calib_path, make_inputs, make_state_dict  # noqa:
 from oracle import dd3d_oracle as O  # noqa: E402
 
 
-def main(experiment, tag, H=384, W=1280, dataset="kitti", target_frac=0.01):
-    cfg = get_cfg(experiment)
+def main(experiment, tag, H=384, W=1280, dataset="kitti", target_frac=0.01, backbone_name=None):
+    cfg = get_cfg(experiment, {"FE": {"BACKBONE": {"NAME": backbone_name}}} if backbone_name else None)
     model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
     sd0 = make_state_dict(model, seed=0, calib={})
     sd = {k: v.clone() for k, v in sd0.items()}
@@ -115,4 +115,4 @@ if __name__ == "__main__":
     exp = sys.argv[1] if len(sys.argv) > 1 else "dd3d_kitti_dla34"
     tag = sys.argv[2] if len(sys.argv) > 2 else "dla34_kitti"
     hw = (384, 1280) if "kitti" in exp else (896, 1600)
-    main(exp, tag, hw[0], hw[1], "kitti" if "kitti" in exp else "nusc")
+    main(exp, tag, hw[0], hw[1], "kitti" if "kitti" in exp else "nusc", backbone_name=sys.argv[3] if len(sys.argv) > 3 else None)  # e.g. DLA-60

@@ -285,6 +285,11 @@ STRUCTURAL = {  # name -> (experiment, calibration tag, overrides): construction
     # towers of different depths, a narrower pyramid, fewer classes
     "odd-towers": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"OUT_CHANNELS": 128}},
                                                         "DD3D": {"NUM_CLASSES": 3, "FCOS2D": {"NUM_CLS_CONVS": 2, "NUM_BOX_CONVS": 3}, "FCOS3D": {"NUM_CONVS": 1}}}),
+    # the Bottleneck DLA variants (dla.py:359-427): deeper trees, residual roots
+    "DLA-46-C": ("dd3d_kitti_dla34", "dla46c_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-46-C"}}}),
+    "DLA-60": ("dd3d_kitti_dla34", "dla60_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-60"}}}),
+    "DLA-102": ("dd3d_kitti_dla34", "dla102_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-102"}}}),
+    "DLA-169": ("dd3d_kitti_dla34", "dla169_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-169"}}}),
     # heads on a subset of the pyramid (core.py:32-34,84)
     "three-levels": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"IN_FEATURES": ["p3", "p4", "p5"]}}),
 }

@@ -126,7 +126,15 @@ def configurable(init_func):
     def wrapped(self, *args, **kwargs):
         first = args[0] if args else kwargs.get("cfg")
         if first is not None and hasattr(first, "keys") and hasattr(type(self), "from_config"):
-            explicit = type(self).from_config(*args, **kwargs)
+            # detectron2 _get_args_from_config: keyword arguments from_config does not name go to __init__ unchanged
+            import inspect
+            params = inspect.signature(type(self).from_config).parameters
+            if any(p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD) for p in params.values()):
+                explicit = type(self).from_config(*args, **kwargs)
+            else:
+                extra = {k: kwargs.pop(k) for k in list(kwargs) if k not in params}
+                explicit = type(self).from_config(*args, **kwargs)
+                explicit.update(extra)
             init_func(self, **explicit)
         else:
             init_func(self, *args, **kwargs)

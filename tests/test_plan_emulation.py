@@ -28,6 +28,11 @@ CASES = {
                                                              "DD3D": {"NUM_CLASSES": 3, "FCOS2D": {"NUM_CLS_CONVS": 2, "NUM_BOX_CONVS": 3},
                                                                       "FCOS3D": {"NUM_CONVS": 1}}}, "kitti", 1, 128, 256),
     "dla34_three_levels": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"IN_FEATURES": ["p3", "p4", "p5"]}}, "kitti", 1, 128, 256),
+    # Bottleneck DLA variants: deeper trees (up to five levels), residual roots -- the generic tree lowering
+    "dla46c_kitti": ("dd3d_kitti_dla34", "dla46c_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-46-C"}}}, "kitti", 1, 128, 256),
+    "dla60_kitti": ("dd3d_kitti_dla34", "dla60_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-60"}}}, "kitti", 1, 128, 256),
+    "dla102_kitti": ("dd3d_kitti_dla34", "dla102_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-102"}}}, "kitti", 1, 128, 256),
+    "dla169_kitti": ("dd3d_kitti_dla34", "dla169_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-169"}}}, "kitti", 1, 128, 256),
 }
 
 
@@ -89,7 +94,7 @@ def test_unbuilt_vovnet_spec_fails_loudly():
         META_ARCH_REGISTRY.get("DD3D")(cfg)
 
 
-@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE", "fpn-without-norm", "swapped-head-norms", "bn-backbone", "odd-towers", "three-levels"])
+@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE", "fpn-without-norm", "swapped-head-norms", "bn-backbone", "odd-towers", "three-levels", "DLA-46-C", "DLA-60", "DLA-102", "DLA-169"])
 def test_oracle_vovnet_specs_match_reference_golden(spec):
     """The oracle the emulated plans are compared with is itself pinned for these construction variants: compact goldens from the
     reference's own backbone + FPN + heads (tests/golden/make_golden.py vovnet_specs)."""
@@ -191,3 +196,27 @@ def test_emulated_plan_matches_oracle_on_random_switch_combinations(hiplib, seed
     if cfg.MODEL.BOX3D_ON:
         assert (a.class_agnostic_3d, a.allocentric, a.depth_is_distance, a.scale_depth_by_focal) == (
             int(c3.CLASS_AGNOSTIC_BOX3D), int(c3.PREDICT_ALLOCENTRIC_ROT), int(c3.PREDICT_DISTANCE), int(c3.SCALE_DEPTH_BY_FOCAL_LENGTHS))
+
+
+def test_generic_tree_lowering_reproduces_dla34(hiplib):
+    """The depth-generic DLA tree lowering (used for the Bottleneck variants) applied to DLA-34 gives the same features as the oracle, like
+    the side-branched lowering DLA-34 normally takes."""
+    from dd3d_amd import META_ARCH_REGISTRY
+    from dd3d_amd.engine import ForwardPlan
+    from dd3d_amd.synthetic import make_inputs
+    from oracle import dd3d_oracle as O
+    from tests.util import bundle
+    cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti", None)
+    model = META_ARCH_REGISTRY.get("DD3D")(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.force_generic_dla = True
+    inputs = make_inputs(1, 128, 256)
+    plan = ForwardPlan(model, 1, 128, 256, device="cpu", dry_run=True)
+    assert any(op.name.endswith("level3.tree2.root") for op in plan.ops) and not plan._side_streams
+    model.stage_inputs(inputs, plan=plan)
+    with torch.no_grad():
+        emulate(plan)
+        _, st = O.dd3d_forward(sd, cfg, inputs, stop_after_heads=True)
+    for l in range(5):
+        ref = st["features"][l]
+        assert float((plan.features[l].nchw() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), l
