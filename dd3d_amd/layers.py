@@ -64,12 +64,12 @@ class ModuleListDial(nn.ModuleList):
 
 class Conv2d(_NoForward):
     """[ext] detectron2.layers.Conv2d parameter layout: weight (O,I,kh,kw), optional bias, optional ``norm``."""
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, norm=None):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, norm=None, groups=1):
         super().__init__()
-        self.in_channels, self.out_channels = in_channels, out_channels
+        self.in_channels, self.out_channels, self.groups = in_channels, out_channels, groups
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
         self.weight = nn.Parameter(
-            torch.empty(out_channels, in_channels, kernel_size, kernel_size), requires_grad=False
+            torch.empty(out_channels, in_channels // groups, kernel_size, kernel_size), requires_grad=False
         )
         self.bias = nn.Parameter(torch.zeros(out_channels), requires_grad=False) if bias else None
         if norm is not None:

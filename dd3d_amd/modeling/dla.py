@@ -51,6 +51,21 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
 
+def bottleneck_x(cardinality):
+    """dla.py:103-143 BottleneckX: like Bottleneck with `planes * cardinality / 32` inner channels and a grouped 3x3 (groups =
+    cardinality).  The cardinality is a class attribute the reference's builders overwrite (dla.py:409); here it is a closure value."""
+    class BottleneckX(Bottleneck):
+        def __init__(self, inplanes, planes, stride=1, norm="BN"):
+            nn.Module.__init__(self)
+            bottle = planes * cardinality // 32
+            self.conv1 = Conv2d(inplanes, bottle, 1, bias=norm == "", norm=get_norm(norm, bottle))
+            self.conv2 = Conv2d(bottle, bottle, 3, stride=stride, padding=1, bias=norm == "", norm=get_norm(norm, bottle), groups=cardinality)
+            self.conv3 = Conv2d(bottle, planes, 1, bias=norm == "", norm=get_norm(norm, planes))
+            self.stride = stride
+
+    return BottleneckX
+
+
 class Root(nn.Module):
     """dla.py:146-167 (kernel_size 1); `residual`: += the first child, i.e. the tree2 block's output (DLA-102 / DLA-169)."""
     def __init__(self, in_channels, out_channels, norm="BN", residual=False):
@@ -83,7 +98,7 @@ class Tree(nn.Module):
 
 
 class DLA(nn.Module):
-    """dla.py:250-355 with BasicBlock or Bottleneck blocks (the BottleneckX variants need grouped convolutions, not built)."""
+    """dla.py:250-355 with BasicBlock, Bottleneck or BottleneckX blocks."""
     def __init__(self, levels, channels, out_features=None, norm="BN", block=BasicBlock, residual_root=False):
         super().__init__()
         self.levels, self.channels, self.block, self.residual_root = levels, channels, block, residual_root
@@ -128,20 +143,26 @@ def dla34(cfg):
     return DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], out_features=list(cfg.OUT_FEATURES), norm=cfg.NORM)
 
 
-def _bottleneck_dla(levels, channels, residual_root=False):
+def _bottleneck_dla(levels, channels, residual_root=False, cardinality=None):
     def build(cfg):
-        return DLA(levels, channels, out_features=list(cfg.OUT_FEATURES), norm=cfg.NORM, block=Bottleneck, residual_root=residual_root)
+        block = Bottleneck if cardinality is None else bottleneck_x(cardinality)
+        return DLA(levels, channels, out_features=list(cfg.OUT_FEATURES), norm=cfg.NORM, block=block, residual_root=residual_root)
     return build
 
 
 # dla.py:359-441.  DLA-34 is the one the reference's configs select; the Bottleneck variants reuse the same kernels; the BottleneckX ones
-# (DLA-X-46-C, DLA-X-60-C, DLA-X-60, DLA-X-102, DLA-X-102-64) need grouped 3x3 convolutions and are not built.
+# run their grouped 3x3 as a dense convolution with a block-diagonal filter (dd3d_amd.engine.dense_filter): correct, not fast.
 DLA_NAME_TO_BUILDER = {
     "DLA-34": dla34,
     "DLA-46-C": _bottleneck_dla([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256]),
     "DLA-60": _bottleneck_dla([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024]),
     "DLA-102": _bottleneck_dla([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], residual_root=True),
     "DLA-169": _bottleneck_dla([1, 1, 2, 3, 5, 1], [16, 32, 128, 256, 512, 1024], residual_root=True),
+    "DLA-X-46-C": _bottleneck_dla([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], cardinality=32),
+    "DLA-X-60-C": _bottleneck_dla([1, 1, 1, 2, 3, 1], [16, 32, 64, 64, 128, 256], cardinality=32),
+    "DLA-X-60": _bottleneck_dla([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], cardinality=32),
+    "DLA-X-102": _bottleneck_dla([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], residual_root=True, cardinality=32),
+    "DLA-X-102-64": _bottleneck_dla([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], residual_root=True, cardinality=64),
 }
 
 
@@ -211,7 +232,7 @@ def build_dla_backbone(cfg, input_shape):
     """dla.py:445-459 (cfg = cfg.FE.BACKBONE)."""
     assert input_shape.channels == 3, "Only supports 3-channel input for now."
     if cfg.NAME not in DLA_NAME_TO_BUILDER:  # dla.py:430-441 also lists the Bottleneck / BottleneckX variants (DLA-46-C ... DLA-169)
-        raise NotImplementedError(f"DLA variant {cfg.NAME!r} is not built (grouped-convolution BottleneckX); available: {sorted(DLA_NAME_TO_BUILDER)}")
+        raise NotImplementedError(f"unknown DLA variant {cfg.NAME!r}; available: {sorted(DLA_NAME_TO_BUILDER)}")
     return DLA_NAME_TO_BUILDER[cfg.NAME](cfg)
 
 

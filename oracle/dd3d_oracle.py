@@ -53,7 +53,8 @@ def conv2d(sd, name, x, stride=1, padding=0, norm=None, relu=False, hook=None):
     """[ext] detectron2 ``layers.Conv2d``: y = conv(x); y = norm(y); y = activation(y).
     ``norm`` is the state-dict prefix of the norm to apply (``<name>.norm`` or
     ``<name>.norm.<level>`` for a ModuleListDial, tridet/layers/normalization.py:30-40)."""
-    y = F.conv2d(x, sd[name + ".weight"], sd.get(name + ".bias"), stride=stride, padding=padding)
+    w = sd[name + ".weight"]
+    y = F.conv2d(x, w, sd.get(name + ".bias"), stride=stride, padding=padding, groups=x.shape[1] // w.shape[1])  # grouped: BottleneckX
     if norm is not None:
         y = batch_norm_eval(sd, norm, y, hook)
     if relu:
@@ -112,13 +113,20 @@ def _tree(sd, p, x, levels, in_ch, out_ch, stride, level_root, children=None, ho
 
 DLA34_LEVELS = [1, 1, 1, 2, 2, 1]  # dla.py:359-361
 DLA34_CHANNELS = [16, 32, 64, 128, 256, 512]
-# name -> (levels, channels, block, residual_root): dla.py:359-427 (the BottleneckX variants are not restated)
+# name -> (levels, channels, block, residual_root): dla.py:359-427
 DLA_SPECS = {
     "DLA-34": (DLA34_LEVELS, DLA34_CHANNELS, _basic_block, False),
     "DLA-46-C": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], _bottleneck, False),
     "DLA-60": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, False),
     "DLA-102": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, True),
     "DLA-169": ([1, 1, 2, 3, 5, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, True),
+    # BottleneckX (dla.py:103-143) = Bottleneck with `planes * cardinality / 32` inner channels and a grouped 3x3; conv2d reads the group
+    # count off the filter shape
+    "DLA-X-46-C": ([1, 1, 1, 2, 2, 1], [16, 32, 64, 64, 128, 256], _bottleneck, False),
+    "DLA-X-60-C": ([1, 1, 1, 2, 3, 1], [16, 32, 64, 64, 128, 256], _bottleneck, False),
+    "DLA-X-60": ([1, 1, 1, 2, 3, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, False),
+    "DLA-X-102": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, True),
+    "DLA-X-102-64": ([1, 1, 1, 3, 4, 1], [16, 32, 128, 256, 512, 1024], _bottleneck, True),
 }
 
 

@@ -290,6 +290,12 @@ STRUCTURAL = {  # name -> (experiment, calibration tag, overrides): construction
     "DLA-60": ("dd3d_kitti_dla34", "dla60_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-60"}}}),
     "DLA-102": ("dd3d_kitti_dla34", "dla102_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-102"}}}),
     "DLA-169": ("dd3d_kitti_dla34", "dla169_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-169"}}}),
+    # BottleneckX variants: grouped 3x3 convolutions (cardinality 32, or 64 for DLA-X-102-64)
+    "DLA-X-46-C": ("dd3d_kitti_dla34", "dlax46c_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-46-C"}}}),
+    "DLA-X-60-C": ("dd3d_kitti_dla34", "dlax60c_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-60-C"}}}),
+    "DLA-X-60": ("dd3d_kitti_dla34", "dlax60_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-60"}}}),
+    "DLA-X-102": ("dd3d_kitti_dla34", "dlax102_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-102"}}}),
+    "DLA-X-102-64": ("dd3d_kitti_dla34", "dlax10264_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-102-64"}}}),
     # heads on a subset of the pyramid (core.py:32-34,84)
     "three-levels": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"IN_FEATURES": ["p3", "p4", "p5"]}}),
 }
@@ -305,6 +311,12 @@ def vovnet_specs_golden():
         cfg = get_cfg(exp, _merge(dict(TRAINING_ONLY_KEYS), over))
         ours = META_ARCH_REGISTRY.get("DD3D")(cfg)
         sd = make_state_dict(ours, calib=load_calib(tag))
+        if "dla" in exp:
+            # the reference's dla102x2 builder overwrites the CLASS attribute BottleneckX.cardinality (dla.py:409) and nothing resets it:
+            # give every variant the value its own builder assumes
+            ref_shims.install()
+            import tridet.modeling.feature_extractor.dla as ref_dla
+            ref_dla.BottleneckX.cardinality = 32
         ref = build_reference_model(cfg)
         ref.load_state_dict(sd, strict=True)
         H, W = (64, 128) if "v99" in exp else (128, 256)

@@ -33,6 +33,12 @@ CASES = {
     "dla60_kitti": ("dd3d_kitti_dla34", "dla60_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-60"}}}, "kitti", 1, 128, 256),
     "dla102_kitti": ("dd3d_kitti_dla34", "dla102_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-102"}}}, "kitti", 1, 128, 256),
     "dla169_kitti": ("dd3d_kitti_dla34", "dla169_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-169"}}}, "kitti", 1, 128, 256),
+    # BottleneckX variants: the grouped 3x3 runs as a dense convolution with a block-diagonal filter
+    "dlax46c_kitti": ("dd3d_kitti_dla34", "dlax46c_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-46-C"}}}, "kitti", 1, 128, 256),
+    "dlax60c_kitti": ("dd3d_kitti_dla34", "dlax60c_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-60-C"}}}, "kitti", 1, 128, 256),
+    "dlax60_kitti": ("dd3d_kitti_dla34", "dlax60_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-60"}}}, "kitti", 1, 128, 256),
+    "dlax102_kitti": ("dd3d_kitti_dla34", "dlax102_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-102"}}}, "kitti", 1, 128, 256),
+    "dlax10264_kitti": ("dd3d_kitti_dla34", "dlax10264_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-102-64"}}}, "kitti", 1, 128, 256),
 }
 
 
@@ -94,7 +100,7 @@ def test_unbuilt_vovnet_spec_fails_loudly():
         META_ARCH_REGISTRY.get("DD3D")(cfg)
 
 
-@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE", "fpn-without-norm", "swapped-head-norms", "bn-backbone", "odd-towers", "three-levels", "DLA-46-C", "DLA-60", "DLA-102", "DLA-169"])
+@pytest.mark.parametrize("spec", ["V-19-eSE", "V-39-eSE", "V-57-eSE", "fpn-without-norm", "swapped-head-norms", "bn-backbone", "odd-towers", "three-levels", "DLA-46-C", "DLA-60", "DLA-102", "DLA-169", "DLA-X-46-C", "DLA-X-60-C", "DLA-X-60", "DLA-X-102", "DLA-X-102-64"])
 def test_oracle_vovnet_specs_match_reference_golden(spec):
     """The oracle the emulated plans are compared with is itself pinned for these construction variants: compact goldens from the
     reference's own backbone + FPN + heads (tests/golden/make_golden.py vovnet_specs)."""
