@@ -75,6 +75,24 @@ def dense_filter(conv):
     return dense
 
 
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def scatter_in_channels(weight, segments):
+    """OIHW filter whose input channels are the concatenation of `segments` = [(real, padded), ...] slices -> the filter for the buffer
+    in which every slice is padded to `padded` channels (zero weights on the padding).  The implicit-GEMM kernels walk 32-channel
+    chunks, so a concat buffer holding 80- or 112-channel slices (V-19-slim-eSE) keeps each slice 32-aligned and zero-padded."""
+    O, I, KH, KW = weight.shape
+    assert I == sum(r for r, _ in segments), (I, segments)
+    out = torch.zeros((O, sum(p for _, p in segments), KH, KW), dtype=weight.dtype, device=weight.device)
+    src = dst = 0
+    for r, p in segments:
+        out[:, dst:dst + r] = weight[:, src:src + r]
+        src, dst = src + r, dst + p
+    return out
+
+
 # --------------------------------------------------------------------------------------------- weight packing
 def pack_filter(weights, device):
     """OIHW filters (list => concatenated along O) -> Wp[Npad][Kpad], k = (c/CC)*(T*CC) + tap*CC + c%CC
@@ -373,12 +391,14 @@ class PlanBase:
     def _vec(self, t):
         return t.detach().float().contiguous().to(self.device)
 
-    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name="", in_relu=False):
-        """One Conv2d(+folded norm)(+residual)(+relu) as a single-segment launch."""
+    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name="", in_relu=False, weight=None):
+        """One Conv2d(+folded norm)(+residual)(+relu) as a single-segment launch.  `weight`: an OIHW filter to use instead of the
+        module's (the same filter re-laid for a padded input layout, see `scatter_in_channels`)."""
         scale, shift = fold_norm(conv, norm)
-        weight = dense_filter(conv)
+        explicit = weight is not None
+        weight = dense_filter(conv) if weight is None else weight
         N, Cin, KH, KW = weight.shape
-        if getattr(conv, "groups", 1) > 1:
+        if getattr(conv, "groups", 1) > 1 or explicit:
             w, meta = pack_filter(weight, self.device)
             seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res}
             op = ConvOp(self, meta, conv.stride, conv.padding, [seg], relu, name=name, in_relu=in_relu)
@@ -694,25 +714,38 @@ class ForwardPlan(PlanBase):
         """OSA modules with the torch.cat realised by channel placement: each module owns one NHWC buffer
         [x | layer0 | ... | layer4]; its input slice is written in place by the producer (stem conv, stage max-pool or the
         previous module's eSE + identity kernel)."""
-        from dd3d_amd.modeling.vovnet import seq_conv, seq_norm
+        from dd3d_amd.modeling.vovnet import seq_conv, seq_dw, seq_norm
         B = img.B
+
+        def conv_norm_relu(dw, conv, norm, src, dst, name, stride=1):
+            """conv3x3 / conv1x1 (vovnet.py:124-161), or dw_conv3x3 (:99-121): depthwise 3x3 (no norm, no relu) into a scratch buffer, then
+            the pointwise 1x1 + norm + relu."""
+            if dw is not None:
+                Ho, Wo = (src.H + 2 - 3) // dw.stride + 1, (src.W + 2 - 3) // dw.stride + 1
+                tmp = self.buf(name + ".dw", B, Ho, Wo, pad32(dw.out_channels)).view()
+                self.conv_module(dw, src, tmp, relu=False, name=name + ".dw")
+                src = tmp
+            self.conv_module(conv, src, dst, relu=True, norm=norm, name=name)
+
         x = img
         stages = [getattr(vov, n) for n in vov.stage_names]
         mods0 = list(stages[0].children())
 
-        def cat_width(m):
-            return m.in_ch + len(m.layers) * m.stage_ch
+        def cat_width(m):  # every slice of the concat buffer starts on a 32-channel boundary (no-op for the 32-multiple specs)
+            return pad32(m.in_ch) + len(m.layers) * pad32(m.stage_ch)
 
         cat = None
-        for idx, (cname, nname) in enumerate(vov.stem_seqs):
+        for idx, (cname, nname, dwname) in enumerate(vov.stem_seqs):
             conv, norm = getattr(vov.stem, cname), getattr(vov.stem, nname)
-            Ho, Wo = (x.H + 2 - 3) // conv.stride + 1, (x.W + 2 - 3) // conv.stride + 1
+            dw = getattr(vov.stem, dwname) if dwname else None
+            strided = dw if dw is not None else conv
+            Ho, Wo = (x.H + 2 - 3) // strided.stride + 1, (x.W + 2 - 3) // strided.stride + 1
             if idx == len(vov.stem_seqs) - 1:
                 cat = self.buf("stage2.OSA2_1.cat", B, Ho, Wo, cat_width(mods0[0]))
-                y = cat.view(0, conv.out_channels)
+                y = cat.view(0, pad32(conv.out_channels))
             else:
                 y = self.buf(f"stem.{idx}", B, Ho, Wo, conv.out_channels).view()
-            self.conv_module(conv, x, y, relu=True, norm=norm, name=cname)
+            conv_norm_relu(dw, conv, norm, x, y, cname)
             x = y
         outs, prev = {}, None
         for si, (sname, stage) in enumerate(zip(vov.stage_names, stages)):
@@ -723,7 +756,7 @@ class ForwardPlan(PlanBase):
                 Hp -= (Hp - 1) * 2 >= prev.H
                 Wp -= (Wp - 1) * 2 >= prev.W
                 cat = self.buf(f"{sname}.{mods[0][0]}.cat", B, Hp, Wp, cat_width(mods[0][1]))
-                dstv = cat.view(0, mods[0][1].in_ch)
+                dstv = cat.view(0, pad32(mods[0][1].in_ch))
 
                 def _pool(lib, st, vin=prev, vout=dstv):
                     hip.check(lib.dd3d_maxpool3x3s2_ceil_nhwc(vin.ptr, vout.ptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, st), "pool3")
@@ -731,20 +764,27 @@ class ForwardPlan(PlanBase):
                 self.ops.append(CallOp(_pool, f"{sname}.pool", dict(kind="maxpool3x3s2_ceil", vin=prev, vout=dstv)))
             H, W = cat.H, cat.W
             for k, (mname, m) in enumerate(mods):
-                src = cat.view(0, m.in_ch)
+                pin, pst, pcc = pad32(m.in_ch), pad32(m.stage_ch), pad32(m.concat_ch)
+                src = cat.view(0, pin)
+                if m.conv_reduction is not None:  # depthwise modules: 1x1 to stage_ch first (vovnet.py:201-205,224-225); not part of the concat
+                    red = self.buf(f"{sname}.{mname}.red", B, H, W, pst).view()
+                    self.conv_module(seq_conv(m.conv_reduction), src, red, relu=True, norm=seq_norm(m.conv_reduction), name=f"{mname}.reduction")
+                    src = red
                 for i, layer in enumerate(m.layers):
-                    dst = cat.view(m.in_ch + i * m.stage_ch, m.stage_ch)
-                    self.conv_module(seq_conv(layer), src, dst, relu=True, norm=seq_norm(layer), name=f"{mname}.{i}")
+                    dst = cat.view(pin + i * pst, pst)
+                    conv_norm_relu(seq_dw(layer), seq_conv(layer), seq_norm(layer), src, dst, f"{mname}.{i}")
                     src = dst
-                xt = self.buf(f"{sname}.{mname}.xt", B, H, W, m.concat_ch).view()
-                self.conv_module(seq_conv(m.concat), cat.view(), xt, relu=True, norm=seq_norm(m.concat), name=f"{mname}.concat")
+                xt = self.buf(f"{sname}.{mname}.xt", B, H, W, pcc).view()
+                segments = [(m.in_ch, pin)] + [(m.stage_ch, pst)] * len(m.layers)
+                w_cat = None if all(r == q for r, q in segments) else scatter_in_channels(seq_conv(m.concat).weight.detach(), segments)
+                self.conv_module(seq_conv(m.concat), cat.view(), xt, relu=True, norm=seq_norm(m.concat), name=f"{mname}.concat", weight=w_cat)
                 if k + 1 < len(mods):
                     nxt = self.buf(f"{sname}.{mods[k + 1][0]}.cat", B, H, W, cat_width(mods[k + 1][1]))
-                    dst = nxt.view(0, m.concat_ch)
+                    dst = nxt.view(0, pcc)
                 else:
                     nxt = None
-                    dst = self.buf(f"{sname}.out", B, H, W, m.concat_ch).view()
-                self.ese(xt, cat.view(0, m.in_ch) if m.identity else None, dst, m.ese.fc, name=f"{mname}.ese")
+                    dst = self.buf(f"{sname}.out", B, H, W, pcc).view()
+                self.ese(xt, cat.view(0, pin) if m.identity else None, dst, m.ese.fc, name=f"{mname}.ese")
                 cat = nxt
             outs[sname] = prev = dst
         return {k: outs[k] for k in vov._out_features}
@@ -752,8 +792,12 @@ class ForwardPlan(PlanBase):
     def ese(self, x, identity, out, fc, name="ese"):
         Cc, HW = x.C, x.H * x.W
         rs = max(1, min(64, HW // 256))
-        w = self._vec(fc.weight.reshape(Cc, Cc))
-        b = self._vec(fc.bias)
+        cr = fc.out_channels  # real channels; the buffers may be padded to a 32-multiple (zero channels stay zero: 0 * gate + 0)
+        w = torch.zeros((Cc, Cc), dtype=torch.float32)
+        w[:cr, :cr] = fc.weight.detach().float().reshape(cr, cr).cpu()
+        b = torch.zeros(Cc, dtype=torch.float32)
+        b[:cr] = fc.bias.detach().float().cpu()
+        w, b = self._vec(w), self._vec(b)
         partial = torch.zeros((x.B, rs, Cc), dtype=torch.float32, device=self.device)
         gate = torch.zeros((x.B, Cc), dtype=torch.float32, device=self.device)
 

@@ -279,6 +279,9 @@ STRUCTURAL = {  # name -> (experiment, calibration tag, overrides): construction
     "V-19-eSE": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-eSE"}}}),
     "V-39-eSE": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-39-eSE"}}}),
     "V-57-eSE": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-57-eSE"}}}),
+    "V-19-slim-eSE": ("dd3d_kitti_v99", "v19slim_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-slim-eSE"}}}),
+    "V-19-dw-eSE": ("dd3d_kitti_v99", "v19dw_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-dw-eSE"}}}),
+    "V-19-slim-dw-eSE": ("dd3d_kitti_v99", "v19slimdw_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-slim-dw-eSE"}}}),
     "fpn-without-norm": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"FPN": {"NORM": ""}}}),
     "swapped-head-norms": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"FCOS2D": {"NORM": "FrozenBN"}, "FCOS3D": {"NORM": "BN"}}}),
     "bn-backbone": ("dd3d_kitti_dla34", "dla34_kitti", {"FE": {"BACKBONE": {"NORM": "BN"}}}),
