@@ -9,6 +9,8 @@ CASES = {
     "dla102": ("dd3d_kitti_dla34", "dla102_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-102"}}}, 128, 256),
     "dlax46c": ("dd3d_kitti_dla34", "dlax46c_kitti", {"FE": {"BACKBONE": {"NAME": "DLA-X-46-C"}}}, 128, 256),
     "v19": ("dd3d_kitti_v99", "v99_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-eSE"}}}, 64, 128),
+    "v19slim": ("dd3d_kitti_v99", "v19slim_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-slim-eSE"}}}, 64, 128),  # padded 80- / 112-channel slices
+    "v19slimdw": ("dd3d_kitti_v99", "v19slimdw_kitti", {"FE": {"BACKBONE": {"NAME": "V-19-slim-dw-eSE"}}}, 64, 128),  # + depthwise layers
     "three_levels": ("dd3d_kitti_dla34", "dla34_kitti", {"DD3D": {"IN_FEATURES": ["p3", "p4", "p5"]}}, 128, 256),
 }
 
