@@ -3,7 +3,8 @@ path, each run through the REFERENCE'S OWN DD3D / NuscenesDD3D (CPU, third-party
 same synthetic weights and inputs; every head map and every detection field must agree.  Fixtures are not written: the committed
 goldens cover the named cases, this sweeps the cross product.
 
-    python tests/golden/fuzz_reference.py [n_cases] [seed]
+    python tests/golden/fuzz_reference.py [n_cases] [seed] [backbones]      ("backbones": also draw the other DLA / VoVNet variants)
+    python tests/golden/fuzz_reference.py dense_depth
 """
 import os
 import random
@@ -18,12 +19,27 @@ from tests.golden import ref_shims  # noqa: E402,F401
 from tests.golden.make_golden import TRAINING_ONLY_KEYS, _merge, build_reference_model, case_inputs  # noqa: E402
 
 
-def random_case(rng):
+BACKBONES = {  # NAME -> (family experiment suffix, calibration tag): every builder of dla.py:430-441 and spec of vovnet.py:88-96
+    "DLA-46-C": ("dla34", "dla46c_kitti"), "DLA-60": ("dla34", "dla60_kitti"), "DLA-102": ("dla34", "dla102_kitti"), "DLA-169": ("dla34", "dla169_kitti"),
+    "DLA-X-46-C": ("dla34", "dlax46c_kitti"), "DLA-X-60-C": ("dla34", "dlax60c_kitti"), "DLA-X-60": ("dla34", "dlax60_kitti"),
+    "DLA-X-102": ("dla34", "dlax102_kitti"), "DLA-X-102-64": ("dla34", "dlax10264_kitti"),
+    "V-19-eSE": ("v99", "v99_kitti"), "V-39-eSE": ("v99", "v99_kitti"), "V-57-eSE": ("v99", "v99_kitti"), "V-19-slim-eSE": ("v99", "v19slim_kitti"),
+    "V-19-dw-eSE": ("v99", "v19dw_kitti"), "V-19-slim-dw-eSE": ("v99", "v19slimdw_kitti"),
+}
+
+
+def random_case(rng, backbones=False):
     nusc = rng.random() < 0.3
     v99 = rng.random() < 0.3
     exp = f"dd3d_{'nusc' if nusc else 'kitti'}_{'v99' if v99 else 'dla34'}"
     tag = f"{'v99' if v99 else 'dla34'}_{'nusc' if nusc else 'kitti'}"
     pick = lambda *xs: rng.choice(xs)  # noqa: E731
+    backbone = None
+    if backbones and not nusc and rng.random() < 0.8:
+        backbone = pick(*BACKBONES)
+        fam, tag = BACKBONES[backbone]
+        v99 = fam == "v99"
+        exp = f"dd3d_kitti_{fam}"
     over = {
         "DD3D": {
             "FEATURE_LOCATIONS_OFFSET": pick("none", "half"),
@@ -36,6 +52,8 @@ def random_case(rng):
         },
         "FE": {"FPN": {"NORM": pick("", "FrozenBN")}, "BACKBONE": {"NORM": pick("BN", "FrozenBN")}},
     }
+    if backbone:
+        over["FE"]["BACKBONE"]["NAME"] = backbone
     if not nusc:
         over["DD3D"]["INFERENCE"] = {"DO_POSTPROCESS": pick(True, False), "DO_NMS": pick(True, False)}  # (BEV NMS needs poses: nuScenes cases)
         if not v99:
@@ -77,15 +95,21 @@ def compare_results(cfg, want, got, nusc):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    n = int(nums[0]) if nums else 20
+    rng = random.Random(int(nums[1]) if len(nums) > 1 else 0)
     import dd3d_amd.modeling  # noqa: F401
     from dd3d_amd import META_ARCH_REGISTRY, get_cfg
     from dd3d_amd.synthetic import load_calib, make_state_dict
     from oracle import dd3d_oracle as O
     from oracle import nuscenes_oracle as N
+    backbones = "backbones" in sys.argv[1:]
     for it in range(n):
-        exp, tag, over, nusc, v99 = random_case(rng)
+        exp, tag, over, nusc, v99 = random_case(rng, backbones)
+        if backbones:  # dla102x2's class-attribute side effect (dla.py:409), see make_golden.vovnet_specs_golden
+            ref_shims.install()
+            import tridet.modeling.feature_extractor.dla as ref_dla
+            ref_dla.BottleneckX.cardinality = 32
         cfg = get_cfg(exp, _merge(dict(TRAINING_ONLY_KEYS), over))
         ours = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
         sd = make_state_dict(ours, calib=load_calib(tag))
