@@ -138,7 +138,8 @@ def main():
             ndet = compare_results(cfg2, want2, got2, False)
             note = f"  (compared before the sample aggregation: {e})"
         flat = {f"{k}.{kk}": vv for k, v in over.items() for kk, vv in (v.items() if isinstance(v, dict) else [("", v)])}
-        print(f"[{it:3d}] ok  {exp:18s} detections {ndet:4d}  {flat}{note}", flush=True)
+        bb = over["FE"]["BACKBONE"].get("NAME", "DLA-34" if "dla34" in exp else "V-99-eSE")
+        print(f"[{it:3d}] ok  {exp:18s} {bb:17s} detections {ndet:4d}  {flat}{note}", flush=True)
     print("all", n, "cases agree with the reference")
 
 
