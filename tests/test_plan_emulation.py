@@ -166,7 +166,7 @@ def test_emulated_dense_depth_plan_matches_oracle(hiplib, offset, by_focal, use_
         assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), l
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 1000, 1001, 1002, 1003, 1004, 1005, 1006, 1007])
 def test_emulated_plan_matches_oracle_on_random_switch_combinations(hiplib, seed):
     """Cross product of the construction switches (same generator as tests/golden/fuzz_reference.py, which checks the oracle against the
     reference itself over these combinations): the dry-run plan executed on the CPU must reproduce the oracle's head maps."""
@@ -178,7 +178,7 @@ def test_emulated_plan_matches_oracle_on_random_switch_combinations(hiplib, seed
     from oracle import nuscenes_oracle as N
     from tests.golden.fuzz_reference import random_case
     import dd3d_amd.modeling  # noqa: F401
-    exp, tag, over, nusc, v99 = random_case(random.Random(100 + seed))
+    exp, tag, over, nusc, v99 = random_case(random.Random(100 + seed), backbones=seed >= 1000)  # seeds >= 1000 also draw the backbone variant
     cfg = get_cfg(exp, over)
     model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
     sd = make_state_dict(model, calib=load_calib(tag))
