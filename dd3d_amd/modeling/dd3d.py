@@ -127,6 +127,11 @@ class DD3D(nn.Module):
                 raise ValueError("Intrinsics is Identity.")  # image_list.py:57-62
         if plan is None:
             plan = self.get_plan(B, H, W)
+        elif (B, H, W) != (plan.B, plan.Hp, plan.Wp):
+            # a fixed plan (DistributedForward / PipelinedForward): a short batch would broadcast silently into the size / intrinsics
+            # buffers, a smaller canvas would run on a larger padded canvas than the reference's ImageList (other border features)
+            raise ValueError(f"batch of {B} images on a {H}x{W} canvas does not fit the fixed launch plan (B={plan.B}, {plan.Hp}x{plan.Wp}); "
+                             "pad the batch / canvas or build a plan for this geometry")
         for i, im in enumerate(images):
             assert im.dtype == torch.uint8 and im.shape[0] == 3, "expected uint8 (3,H,W) images (dataset_mapper.py:127)"
             plan.in_u8[i, :, :im.shape[1], :im.shape[2]].copy_(im, non_blocking=True)
@@ -164,7 +169,9 @@ class DD3D(nn.Module):
         for i, (inp, isz) in enumerate(zip(batched_inputs, image_sizes)):
             g = first + i
             n = int(counts[g])
-            d = det[g, :n]
+            # one private copy per image: a (1, k) slice of the detection buffer is "contiguous" whatever its row stride, so
+            # .contiguous() on such a slice would return a VIEW of the plan buffer that the next forward overwrites
+            d = det[g, :n].clone()
             if self.postprocess_in_inference:
                 size = (int(inp.get("height", isz[0])), int(inp.get("width", isz[1])))
             else:

@@ -180,6 +180,12 @@ class PipelinedForward:
 
     def submit(self, batched_inputs):
         slot = self._acquire()
+        # device-resident inputs (DeviceInputMapper / DeviceResizer outputs) were produced on the caller's current stream: the staging
+        # copies on the slot's compute stream must order after them, and the allocator must not recycle them before the copies ran
+        slot.compute_stream.wait_stream(torch.cuda.current_stream())
+        for x in batched_inputs:
+            if x["image"].is_cuda:
+                x["image"].record_stream(slot.compute_stream)
         with torch.cuda.stream(slot.compute_stream):
             _, slot.image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan)
         slot.inputs = batched_inputs

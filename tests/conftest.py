@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are the parity tests proper (they call the HIP library through the C ABI): skipped, not failed, on a box without
+    an MI355X, so a plain `pytest` in the build container runs the CPU suite only."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP GPU on this box (run with -m gpu on the MI355X)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def hiplib():
     """Build (if stale) and load libdd3d_hip.so; hipcc cross-compiles gfx950 without a GPU."""

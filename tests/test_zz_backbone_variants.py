@@ -1,6 +1,6 @@
 """Backbone / pyramid variants outside the reference's experiment configs, on the GPU: forward vs the oracle (which is pinned against the
 reference for each of them, tests/test_plan_emulation.py).  Their host side already equals the oracle in the CPU plan emulation; these run
-the same kernels on the variants' shapes.  Written after the round's GPU minutes were spent, hence non-strict xfail until run once."""
+the same kernels on the variants' shapes."""
 import pytest
 import torch
 
@@ -17,7 +17,6 @@ CASES = {
 
 @pytest.mark.gpu
 @pytest.mark.timeout(240)
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU minutes were spent: these variants have not run on hardware yet")
 @pytest.mark.parametrize("name", list(CASES))
 def test_hip_variant_forward_matches_oracle(hiplib, name):
     from dd3d_amd.synthetic import make_inputs

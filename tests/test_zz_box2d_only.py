@@ -55,7 +55,6 @@ def test_plan_of_the_2d_only_model_builds(hiplib):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(180)
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU minutes were spent: this case has not run on hardware yet")
 def test_hip_box2d_only_matches_reference_golden(hiplib):
     from tests.util import bundle, gpu_model, max_abs
     cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti", BOX2D_ONLY_OVERRIDES)

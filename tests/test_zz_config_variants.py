@@ -44,7 +44,6 @@ def test_oracle_variant_matches_reference_golden(name):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(180)
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU minutes were spent: these switches have not run on hardware yet")
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_hip_variant_matches_reference_golden(hiplib, name):
     from tests.util import bundle, gpu_model, max_abs, oracle_heads_to_plan, quat_err, rel_err

@@ -41,7 +41,6 @@ def test_collect_of_an_empty_detection_buffer(kitti_dla34):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(180)
-@pytest.mark.xfail(strict=False, reason="written after the round's GPU minutes were spent: this case has not run on hardware yet")
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_hip_forward_with_no_candidates(hiplib, use_graph):
     from dd3d_amd.synthetic import make_inputs
@@ -57,3 +56,29 @@ def test_hip_forward_with_no_candidates(hiplib, use_graph):
         i = o["instances"]
         assert len(i) == 0 and tuple(i.image_size) == (99, 201)
         assert i.pred_boxes.tensor.shape == (0, 4) and i.pred_classes.dtype == torch.int64 and i.pred_boxes3d.quat.shape == (0, 4)
+
+
+def test_collect_does_not_alias_the_detection_buffer(kitti_dla34):
+    """An image with exactly ONE detection: a (1, k) slice of the detection buffer counts as contiguous whatever its row stride, so
+    `.contiguous()` alone would hand out views of the plan buffer, and the next forward on the same cached plan (TTA runs several
+    batches through one plan before reading any output) would rewrite results already returned."""
+    from dd3d_amd import hip
+    from dd3d_amd.synthetic import make_inputs
+    _, model, _ = kitti_dla34
+    B, cap = 2, 8
+    det = torch.arange(B * cap * hip.DET_FIELDS, dtype=torch.float32).reshape(B, cap, hip.DET_FIELDS)
+    plan = types.SimpleNamespace(det_count=torch.tensor([1, 3], dtype=torch.int32), det_cap=cap, det=det,
+                                 inv_K=torch.eye(3).reshape(1, 9).repeat(B, 1), has_global_boxes=False)
+    inputs = make_inputs(B, 128, 256)
+    out = model.collect(plan, inputs, [(128, 256)] * B)
+    snap = [(o["instances"].pred_boxes.tensor.clone(), o["instances"].scores.clone(), o["instances"].scores_3d.clone(),
+             o["instances"].locations.clone(), o["instances"].pred_boxes3d.quat.clone(), o["instances"].pred_boxes3d.size.clone()) for o in out]
+    storage = det.untyped_storage().data_ptr()
+    det.add_(1000.0)  # "the next forward" rewrites the plan buffer
+    plan.inv_K.mul_(3.0)
+    for o, s in zip(out, snap):
+        i = o["instances"]
+        for got, want in zip((i.pred_boxes.tensor, i.scores, i.scores_3d, i.locations, i.pred_boxes3d.quat, i.pred_boxes3d.size), s):
+            assert got.untyped_storage().data_ptr() != storage
+            assert torch.equal(got, want)
+        assert torch.equal(i.pred_boxes3d.inv_intrinsics[0], torch.eye(3))

@@ -80,3 +80,36 @@ def candidates_from_plan(plan, b=0):
         proj_ctr=c[14:16].T, depth=c[16:17].T, size=c[17:20].T, counts=counts,
         fpn_levels=torch.cat([torch.full((c_, ), l) for l, c_ in enumerate(counts)]).long()
     )
+
+
+def candidate_margins(plan, st, cfg, b=0):
+    """End-to-end candidate membership of image b: HIP (plan.cand, from its own head maps) vs oracle (st).  Selection is a hard
+    threshold on sigma(cls)*sigma(ctr) (fcos2d.py:280-283) followed by a per-level top-k (fcos2d.py:309-317), so a ~1e-7 relative
+    difference in a logit may flip a candidate that sits ON a cut.  Returns (n_hip, n_ref, margins): `margins` holds, for every
+    candidate only one side selected, the distance of the ORACLE's score from the cut that decided it (PRE_NMS_THRESH, or the
+    k-th largest score of the level when the top-k cut was active).  Parity demands every such distance to be ~0."""
+    inf = cfg.DD3D.FCOS2D.INFERENCE
+    C, topk, thr = int(cfg.DD3D.NUM_CLASSES), int(inf.PRE_NMS_TOPK), float(inf.PRE_NMS_THRESH)
+    c = candidates_from_plan(plan, b)
+    hip_keys = set(zip(c["fpn_levels"].tolist(), c["flat_index"].tolist()))
+    ref_keys, margins = set(), []
+    dense = []
+    for l, info in enumerate(st["level_info"]):
+        fg, cl, tk = info[b]["fg_inds"], info[b]["class_inds"], info[b]["topk_indices"]
+        e = fg * C + cl
+        e = e[tk] if tk is not None else e
+        ref_keys |= {(l, int(v)) for v in e.tolist()}
+        s = st["logits"][l][b].permute(1, 2, 0).reshape(-1, C).sigmoid()
+        ctr = st["centerness"][l][b].permute(1, 2, 0).reshape(-1, 1).sigmoid()
+        s_thr = s * ctr if bool(inf.THRESH_WITH_CTR) else s
+        rank = (s * ctr).reshape(-1)
+        n_pass = int((s_thr > thr).sum())
+        kth = float(rank[(s_thr > thr).reshape(-1)].topk(topk).values.min()) if n_pass > topk else None
+        dense.append((s_thr.reshape(-1), rank, kth))
+    for (l, flat) in hip_keys ^ ref_keys:
+        s_thr, rank, kth = dense[l]
+        d = abs(float(s_thr[flat]) - thr)
+        if kth is not None:
+            d = min(d, abs(float(rank[flat]) - kth))
+        margins.append(d)
+    return len(hip_keys), len(ref_keys), margins
