@@ -1,0 +1,265 @@
+// Device code shared by the implicit-GEMM convolution kernels of libdd3d_hip.so (gfx950): kernel arguments, the XCD-aware block
+// remap, the fused split-K exchange and the epilogue (f32 NHWC store and / or the split-plane store the next convolution streams
+// into LDS by LDS-DMA).
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+namespace dd3d {
+
+constexpr int BK = 32;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct ConvKArgs {
+  const dd3d_conv_seg* segs;
+  const int32_t* tiles;
+  float* ws;
+  int ntiles, nn;  // m-tiles (all segments), n-tiles
+  int KH, KW, stride, pad, Cin, N, Kpad, Npad;
+  int T;         // KH*KW
+  int cc_shift;  // log2(CC) when Cin < 32
+  int kw_magic;  // (65536 / KW) + 1 : tap / KW == (tap * kw_magic) >> 16 for tap < 64
+  int relu, splitk, kt_per_split;
+  const float* zeros;  // >= 128 B of zeros (source of padded taps for the LDS-DMA kernels)
+  int* tile_counters;  // split-K: arrivals per output tile (zero between launches)
+  // Single-segment launches (every backbone / FPN conv) carry their descriptor in the kernel arguments: the block then
+  // starts its first data loads without the tiles[] -> segs[] -> pointer chain of dependent scalar loads.
+  int single;
+  int in_relu;  // bf16x3 kernel with f32 input: rectify the input while it is split (conv(relu(x)) without a rectified copy of x)
+  dd3d_conv_seg seg0;
+};
+
+// Split-operand arithmetic modes (values of dd3d_conv_launch.math_mode) and their plane counts.
+//   X3: x = hi + mid + lo, three bf16 terms by truncation (exact, 24 bits); six cross products  -> f32-equivalent
+//   X2: x ~ hi + lo, two bf16 terms by round-to-nearest (~17 bits); three cross products
+//   X1: x ~ bf16(x) round-to-nearest; one product (plain bf16 inference)
+template <int MODE>
+struct Planes {
+  static constexpr int NP = MODE == DD3D_MATH_BF16X3 ? 3 : (MODE == DD3D_MATH_BF16X2 ? 2 : 1);
+};
+
+// Global-address-space views: the segment descriptor is loaded from memory, so without these casts the compiler
+// must emit FLAT loads, which tick lgkmcnt as well and would make every LDS wait also wait for the HBM prefetch.
+typedef const float __attribute__((address_space(1))) * gcfp;
+typedef float __attribute__((address_space(1))) * gfp;
+typedef const f32x4 __attribute__((address_space(1))) * gcf4p;
+typedef const unsigned char __attribute__((address_space(1))) * gcbp;
+typedef unsigned char __attribute__((address_space(1))) * gbp;
+__device__ __forceinline__ gcfp as_g(const float* p) { return (gcfp)p; }
+__device__ __forceinline__ gfp as_g(float* p) { return (gfp)p; }
+
+// XCD-aware block remap (bijective): blocks dispatched to the same XCD (bid % 8) get a contiguous range of logical
+// tiles, n fastest, so the n-tiles that share an A row band hit the same (private, per-XCD) L2.
+__device__ __forceinline__ int remap_block(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Epilogue shared by the kernels.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+//   out = max(lo, acc*scale + bias (+ residual));  one lane owns one output channel per 32-wide column block.
+// Split-K fix-up, fused into the conv kernel: every K-slice of an output tile stores its raw accumulators to the workspace
+// and counts its arrival; the slice that arrives LAST re-reads all slices in slice order (deterministic, independent of the
+// arrival order) into its accumulators and runs the normal epilogue.  No second launch; the counter resets itself.
+//
+// Coherence across the 8 XCD-private L2s WITHOUT agent-scope fences (on gfx950 a release/acquire fence writes back /
+// invalidates the whole L2: measured +30 us per launch): the partial sums are moved with sc1 (agent-coherent: write-through /
+// L2-bypassing) 16-byte accesses and ordered by s_waitcnt only.  Workspace layout = accumulator layout,
+// ws[slice][tile][quad q of (i,j)][thread][4]: every store / load instruction of a wave covers 1 KiB contiguous.
+__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ f32x4 ld_sc1(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// returns true when this block has to finish the tile (acc then holds the full sum)
+template <int TM, int TN, int NT = 256>
+__device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int tile_id, int tid) {
+  constexpr int Q = TM * TN * 4;  // 16-byte quads per thread
+  constexpr int QS = NT * 4;      // floats between consecutive quads of one thread
+  const long slab = (long)a.ntiles * a.nn * Q * QS;  // floats per slice
+  float* mine = a.ws + (long)blockIdx.y * slab + ((long)tile_id * Q * NT + tid) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        st_sc1(mine + ((i * TN + j) * 4 + q) * QS, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have been acknowledged by the coherence point
+  __shared__ int sh_last;
+  __syncthreads();
+  if (tid == 0) {
+    const int prev = __hip_atomic_fetch_add(a.tile_counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == a.splitk - 1;
+    if (last) __hip_atomic_store(a.tile_counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all slices have arrived
+    sh_last = last;
+  }
+  __syncthreads();
+  if (!sh_last) return false;
+  constexpr int ZC = Q >= 16 ? 1 : (Q >= 8 ? 2 : 4);  // slices in flight: 64 VGPRs of loads
+  const float* base = a.ws + ((long)tile_id * Q * NT + tid) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int z0 = 0; z0 < a.splitk; z0 += ZC) {
+    f32x4 t[ZC][Q];
+#pragma unroll
+    for (int zz = 0; zz < ZC; ++zz) {
+      const int z = min(z0 + zz, a.splitk - 1);  // clamped re-read of the last slice; its value is not added
+#pragma unroll
+      for (int q = 0; q < Q; ++q) t[zz][q] = ld_sc1(base + (long)z * slab + q * QS);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int zz = 0; zz < ZC; ++zz)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(t[zz][q]));  // uses below depend on the wait above
+#pragma unroll
+    for (int zz = 0; zz < ZC; ++zz) {
+      if (z0 + zz >= a.splitk) break;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += t[zz][(i * TN + j) * 4 + q][e];
+    }
+  }
+  return true;
+}
+
+// ---- split of f32 values into the 16-bit planes of an arithmetic mode.  `pack(lo_elem, hi_elem, w)`: w[p] = plane p of the
+// two values as one dword (lo_elem in bits 0-15: the element with the lower channel index).
+template <int MODE>
+__device__ __forceinline__ void split_pack(float x0, float x1, unsigned (&w)[Planes<MODE>::NP]) {
+  if constexpr (MODE == DD3D_MATH_BF16X3) {  // exact, by truncation (the same split the f32-input kernel applies on the fly)
+    const unsigned h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
+    const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
+    const unsigned m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+    const unsigned l0 = __float_as_uint(r0 - __uint_as_float(m0)), l1 = __float_as_uint(r1 - __uint_as_float(m1));
+    w[0] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    w[1] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    w[2] = __builtin_amdgcn_perm(l1, l0, 0x07060302u);
+  } else {  // round-to-nearest-even terms (v_cvt_pk_bf16_f32)
+    const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+    w[0] = __builtin_bit_cast(unsigned, h);
+    if constexpr (MODE == DD3D_MATH_BF16X2) {
+      const f32x2 hf = __builtin_convertvector(h, f32x2);
+      const bf16x2 l = __builtin_convertvector(f32x2{x0 - hf[0], x1 - hf[1]}, bf16x2);
+      w[1] = __builtin_bit_cast(unsigned, l);
+    }
+  }
+}
+
+// MODE == DD3D_MATH_F32: f32 NHWC store only (the kernel's math mode has no planes).
+template <int TM, int TN, int MODE = DD3D_MATH_F32>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                              int wm, int wn, int lane) {
+  const gcfp g_res = as_g(s.res);
+  const gfp g_out = as_g(s.out);
+  const int nlim = s.n_limit > 0 ? s.n_limit : a.N;
+  if constexpr (MODE == DD3D_MATH_F32) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+      if (n >= nlim) continue;
+      const float sc = as_g(s.scale)[n], bi = as_g(s.bias)[n];
+      float lo = s.lo ? as_g(s.lo)[n] : -INFINITY;
+      if (a.relu) lo = fmaxf(lo, 0.f);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+        float rv[16];  // residuals first, all 16 loads in flight together (they must not queue behind the stores)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          rv[r] = (s.res_mode == 1 && m < s.M) ? g_res[(long)m * s.res_pitch + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (m < s.M) g_out[(long)m * s.out_pitch + n] = fmaxf(acc[i][j][r] * sc + bi + rv[r], lo);
+        }
+      }
+    }
+  } else {
+    // Split-plane output [chunk = n / 32][pixel m][plane][32] (16-bit terms): what the NEXT convolution streams into LDS by LDS-DMA
+    // without touching the VALU.  A lane owns ONE channel and 16 pixels of a 32x32 accumulator block; lanes l and l^1 swap one value per
+    // pixel pair (DPP quad_perm) so that every lane stores a (channel n, n+1) dword for one of the two pixels: each store
+    // instruction of the wave then writes 4 pixels x 64 contiguous bytes.  The f32 NHWC copy is written as well when the segment has
+    // one (residual sources, inputs of the pooling / top-down / gating kernels).
+    constexpr int NP = Planes<MODE>::NP;
+    const bool w32 = s.out != nullptr, wpl = s.out_planes != nullptr;
+    const long cstride = (long)s.M * (NP * 64);  // bytes per 32-channel chunk image of the output
+    const int odd = lane & 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wn * TN + j) * 32;  // wave-uniform: first channel of this column block
+      if (nb >= nlim) continue;
+      const int n = nb + (lane & 31);
+      const bool nv = n < nlim;
+      const int nc = nv ? n : nlim - 1;  // clamped index for the per-channel vectors
+      const float sc = as_g(s.scale)[nc], bi = as_g(s.bias)[nc];
+      float lo = s.lo ? as_g(s.lo)[nc] : -INFINITY;
+      if (a.relu) lo = fmaxf(lo, 0.f);
+      const gbp pl_base = (gbp)s.out_planes + (long)(nb >> 5) * cstride + ((lane & 30) << 1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          v[r] = (s.res_mode == 1 && m < s.M && nv) ? g_res[(long)m * s.res_pitch + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = fmaxf(acc[i][j][r] * sc + bi + v[r], lo);
+          v[r] = nv ? v[r] : 0.f;  // channels past N inside the last chunk are zero planes
+        }
+        if (w32 && nv) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m < s.M) g_out[(long)m * s.out_pitch + n] = v[r];
+          }
+        }
+        if (wpl) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int ra = 2 * t, rb = 2 * t + 1;
+            const float send = odd ? v[ra] : v[rb];
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));
+            const float own = odd ? v[rb] : v[ra];
+            const int m = mb + (odd ? (rb & 3) + 8 * (rb >> 2) : (ra & 3) + 8 * (ra >> 2));
+            unsigned w[NP];
+            split_pack<MODE>(odd ? recv : own, odd ? own : recv, w);
+            if (m < s.M) {
+              const gbp dst = pl_base + (long)m * (NP * 64);
+#pragma unroll
+              for (int p = 0; p < NP; ++p) *(unsigned __attribute__((address_space(1)))*)(dst + p * 64) = w[p];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- launchers implemented in the kernel translation units
+int launch_conv_planes(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st);  // conv_planes.hip
+
+}  // namespace dd3d

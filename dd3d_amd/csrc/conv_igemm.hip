@@ -21,160 +21,11 @@
 #include <cstring>
 #include <stdlib.h>
 
-#include <type_traits>
-
-#include "common.h"
+#include "conv_common.h"
 
 namespace dd3d {
 
-constexpr int BK = 32;
 constexpr int LDS_ROW = BK + 4;  // register-staged kernel: 144-B rows keep the 16-B slots of 16 rows distinct mod 256 B
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvKArgs {
-  const dd3d_conv_seg* segs;
-  const int32_t* tiles;
-  float* ws;
-  int ntiles, nn;  // m-tiles (all segments), n-tiles
-  int KH, KW, stride, pad, Cin, N, Kpad, Npad;
-  int T;         // KH*KW
-  int cc_shift;  // log2(CC) when Cin < 32
-  int kw_magic;  // (65536 / KW) + 1 : tap / KW == (tap * kw_magic) >> 16 for tap < 64
-  int relu, splitk, kt_per_split;
-  const float* zeros;  // >= 128 B of zeros (source of padded taps for the LDS-DMA kernel)
-  int* tile_counters;  // split-K: arrivals per output tile (zero between launches)
-  // Single-segment launches (every backbone / FPN conv) carry their descriptor in the kernel arguments: the block then
-  // starts its first data loads without the tiles[] -> segs[] -> pointer chain of dependent scalar loads.
-  int single;
-  int in_relu;  // bf16x3 kernel: rectify the input while it is split (conv(relu(x)) without a rectified copy of x)
-  dd3d_conv_seg seg0;
-};
-
-// Global-address-space views: the segment descriptor is loaded from memory, so without these casts the compiler
-// must emit FLAT loads, which tick lgkmcnt as well and would make every LDS wait also wait for the HBM prefetch.
-typedef const float __attribute__((address_space(1))) * gcfp;
-typedef float __attribute__((address_space(1))) * gfp;
-typedef const f32x4 __attribute__((address_space(1))) * gcf4p;
-__device__ __forceinline__ gcfp as_g(const float* p) { return (gcfp)p; }
-__device__ __forceinline__ gfp as_g(float* p) { return (gfp)p; }
-
-// XCD-aware block remap (bijective): blocks dispatched to the same XCD (bid % 8) get a contiguous range of logical
-// tiles, n fastest, so the n-tiles that share an A row band hit the same (private, per-XCD) L2.
-__device__ __forceinline__ int remap_block(int bid, int nwg) {
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-// Epilogue shared by both kernels.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-//   out = max(lo, acc*scale + bias (+ residual));  one lane owns one output channel per 32-wide column block.
-// Split-K fix-up, fused into the conv kernel: every K-slice of an output tile stores its raw accumulators to the workspace
-// and counts its arrival; the slice that arrives LAST re-reads all slices in slice order (deterministic, independent of the
-// arrival order) into its accumulators and runs the normal epilogue.  No second launch; the counter resets itself.
-//
-// Coherence across the 8 XCD-private L2s WITHOUT agent-scope fences (on gfx950 a release/acquire fence writes back /
-// invalidates the whole L2: measured +30 us per launch): the partial sums are moved with sc1 (agent-coherent: write-through /
-// L2-bypassing) 16-byte accesses and ordered by s_waitcnt only.  Workspace layout = accumulator layout,
-// ws[slice][tile][quad q of (i,j)][thread][4]: every store / load instruction of a wave covers 1 KiB contiguous.
-__device__ __forceinline__ void st_sc1(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ f32x4 ld_sc1(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-// returns true when this block has to finish the tile (acc then holds the full sum)
-template <int TM, int TN, int NT = 256>
-__device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int tile_id, int tid) {
-  constexpr int Q = TM * TN * 4;  // 16-byte quads per thread
-  constexpr int QS = NT * 4;      // floats between consecutive quads of one thread
-  const long slab = (long)a.ntiles * a.nn * Q * QS;  // floats per slice
-  float* mine = a.ws + (long)blockIdx.y * slab + ((long)tile_id * Q * NT + tid) * 4;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        st_sc1(mine + ((i * TN + j) * 4 + q) * QS, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial sums have been acknowledged by the coherence point
-  __shared__ int sh_last;
-  __syncthreads();
-  if (tid == 0) {
-    const int prev = __hip_atomic_fetch_add(a.tile_counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = prev == a.splitk - 1;
-    if (last) __hip_atomic_store(a.tile_counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all slices have arrived
-    sh_last = last;
-  }
-  __syncthreads();
-  if (!sh_last) return false;
-  constexpr int ZC = Q >= 16 ? 1 : (Q >= 8 ? 2 : 4);  // slices in flight: 64 VGPRs of loads
-  const float* base = a.ws + ((long)tile_id * Q * NT + tid) * 4;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  for (int z0 = 0; z0 < a.splitk; z0 += ZC) {
-    f32x4 t[ZC][Q];
-#pragma unroll
-    for (int zz = 0; zz < ZC; ++zz) {
-      const int z = min(z0 + zz, a.splitk - 1);  // clamped re-read of the last slice; its value is not added
-#pragma unroll
-      for (int q = 0; q < Q; ++q) t[zz][q] = ld_sc1(base + (long)z * slab + q * QS);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int zz = 0; zz < ZC; ++zz)
-#pragma unroll
-      for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(t[zz][q]));  // uses below depend on the wait above
-#pragma unroll
-    for (int zz = 0; zz < ZC; ++zz) {
-      if (z0 + zz >= a.splitk) break;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += t[zz][(i * TN + j) * 4 + q][e];
-    }
-  }
-  return true;
-}
-
-template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0,
-                                              int wm, int wn, int lane) {
-  const gcfp g_res = as_g(s.res);
-  const gfp g_out = as_g(s.out);
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-    if (n >= (s.n_limit > 0 ? s.n_limit : a.N)) continue;
-    const float sc = as_g(s.scale)[n], bi = as_g(s.bias)[n];
-    float lo = s.lo ? as_g(s.lo)[n] : -INFINITY;
-    if (a.relu) lo = fmaxf(lo, 0.f);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
-      float rv[16];  // residuals first, all 16 loads in flight together (they must not queue behind the stores)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        rv[r] = (s.res_mode == 1 && m < s.M) ? g_res[(long)m * s.res_pitch + n] : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m < s.M) g_out[(long)m * s.out_pitch + n] = fmaxf(acc[i][j][r] * sc + bi + rv[r], lo);
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Register-staged kernel.  Block = 256 threads = 4 wave64; block tile = (TM*32*WM) x (TN*32*WN); double-buffered LDS.
@@ -609,8 +460,6 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
 // a double-buffered LDS image.  LDS rows are 64 B (32 bf16) per plane; their four 16-byte slots are XOR-swizzled with
 // (row >> 2) & 3, which makes every ds_read_b128 lane group hit 16 distinct 4-bank groups.
 // Block = 512 threads = 8 wave64 (two per SIMD), wave tile (TM*32) x (TN*32), WM x WN waves.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int TM, int TN, int WM, int WN, int NSA, int NSB, int KT, bool SK>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const ConvKArgs a) {
@@ -890,7 +739,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
   if constexpr (SK) {
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
-  conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
+  conv_epilogue<TM, TN, DD3D_MATH_BF16X3>(a, s, acc, m0, n0, wm, wn, lane);  // f32 NHWC and / or split planes for the next conv
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
@@ -989,6 +838,10 @@ static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
 
 }  // namespace dd3d
 
+extern "C" int dd3d_math_planes(int32_t math_mode) {
+  return math_mode == DD3D_MATH_BF16X3 ? 3 : (math_mode == DD3D_MATH_BF16X2 ? 2 : (math_mode == DD3D_MATH_BF16 ? 1 : 0));
+}
+
 extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) {
   static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}, {128, 64}, {64, 128}, {64, 64}};
   DD3D_REQUIRE(tile_cfg >= 0 && tile_cfg < DD3D_TILE_COUNT, "dd3d_conv_tile_shape: unknown tile_cfg %d", tile_cfg);
@@ -1035,6 +888,14 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.kt_per_split = ceil_div(nk, L->splitk);
   const bool smallc = L->Cin < 32;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DD3D_REQUIRE(L->math_mode >= DD3D_MATH_F32 && L->math_mode <= DD3D_MATH_BF16, "dd3d_conv2d_igemm_f32: unknown math mode %d", L->math_mode);
+  if (L->in_planes) {
+    DD3D_REQUIRE(L->math_mode != DD3D_MATH_F32 && !smallc && L->zero_page && !L->in_relu,
+                 "dd3d_conv2d_igemm_f32: split-plane input needs a split-operand math mode, Cin %% 32 == 0, a zero page and no in_relu");
+    return launch_conv_planes(ka, L->math_mode, L->tile_cfg, st);
+  }
+  DD3D_REQUIRE(L->math_mode == DD3D_MATH_F32 || L->math_mode == DD3D_MATH_BF16X3,
+               "dd3d_conv2d_igemm_f32: math mode %d reads split-plane input only (dd3d_split_planes converts f32 tensors)", L->math_mode);
   if (L->math_mode == DD3D_MATH_BF16X3) {
     DD3D_REQUIRE(!smallc && L->zero_page, "dd3d_conv2d_igemm_f32: the split-bf16 kernel needs Cin %% 32 == 0 and a zero page");
     switch (L->tile_cfg) {

@@ -1,0 +1,337 @@
+// Implicit-GEMM convolution for gfx950 whose INPUT is already split into 16-bit planes (the producer's epilogue wrote them,
+// conv_common.h::conv_epilogue): f32-equivalent (three bf16 terms, six cross products) or reduced (two terms / one term) products
+// on the bf16 matrix pipe with NO VALU work in the main loop.
+//
+//   A  activations  [chunk c/32][pixel (b, h, w)][plane][32]   16-bit terms, written by the previous layer
+//   B  filters      [n][k-tile][plane][32]                     split once at plan build
+// Both operands of a K-tile (= 32 channels of one filter tap) stream HBM/L2 -> LDS with global_load_lds_dwordx4 (1 KiB per wave
+// instruction = 16 rows x 64 B of one plane); the im2col gather is the per-lane source address of the A pieces (out-of-image taps
+// and rows >= M read a zero page).  LDS rows are 64 B; their four 16-byte slots are XOR-swizzled with (row >> 2) & 3, applied on
+// the source side of the DMA and again on the ds_read_b128 address, so that every fragment read is conflict-free.
+//
+// Pipeline (NS ring stages, NS - 1 tiles in flight): ONE barrier per K-tile, placed between the MFMA groups of its two 16-k chunks,
+//   read F1 <- chunk 1 (tile kt) | MFMAs chunk 0 | wait tile kt+1 landed | barrier | DMA tile kt+NS -> the stage just freed |
+//   read F0 <- chunk 0 (tile kt+1) | MFMAs chunk 1
+// so the fragment reads of the next tile and the DMA issue sit under MFMAs that do not depend on them, and the two waves of a
+// SIMD leave the barrier with matrix work already in hand.
+#include <cstring>
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace dd3d {
+
+// Scheduling pattern of one phase: NMFMA matrix instructions, NDMA LDS-DMA issues and NDS fragment reads in ONE region.  The DMAs go
+// first (longest latency), one per MFMA; then one ds_read per MFMA; the remaining MFMAs close the phase.  Without it the machine
+// scheduler sinks the reads to just before their first use in the NEXT phase and serialises read -> wait -> MFMA.
+template <int NMFMA, int NDS, int NDMA>
+__device__ __forceinline__ void sched_interleave() {
+  constexpr int NPAIR = NDMA + NDS < NMFMA ? NDMA + NDS : NMFMA;
+#pragma unroll
+  for (int i = 0; i < NPAIR; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+    if (i < NDMA) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // one VMEM (the LDS-DMA)
+    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one DS read
+  }
+  if constexpr (NDMA + NDS > NPAIR) {
+    __builtin_amdgcn_sched_group_barrier(0x010, NDMA > NPAIR ? NDMA - NPAIR : 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NDMA > NPAIR ? NDS : NDMA + NDS - NPAIR, 0);
+  }
+  if constexpr (NMFMA > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NPAIR, 0);
+}
+
+template <int TM, int TN, int WM, int WN, int NS, int MODE, bool SK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const ConvKArgs a) {
+  constexpr int NP = Planes<MODE>::NP;
+  constexpr int BM = TM * 32 * WM;
+  constexpr int BN = TN * 32 * WN;
+  constexpr int NW = WM * WN;
+  constexpr int NTHR = 64 * NW;
+  constexpr int PLA = BM * 64, PLB = BN * 64;      // bytes per plane of a stage
+  constexpr int A_BYTES = NP * PLA, STAGE = NP * (PLA + PLB);
+  constexpr int RA = BM / 16, RB = BN / 16;        // 16-row blocks (one 1-KiB DMA piece per plane)
+  constexpr int QN = (RA + RB + NW - 1) / NW;      // row blocks per wave (the surplus re-fetches the last block)
+  constexpr int P = QN * NP;                       // DMA instructions per wave and K-tile
+  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS ring");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+  typedef unsigned char __attribute__((address_space(3))) * ldsbp;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+
+  const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
+  const int mt = bid / a.nn;
+  const int nt = bid - mt * a.nn;
+  int m0 = mt * BM;
+  dd3d_conv_seg s = a.seg0;
+  if (!a.single) {
+    m0 = a.tiles[2 * mt + 1];
+    s = a.segs[a.tiles[2 * mt]];
+  }
+  const int n0 = nt * BN;
+  const gcbp g_in = (gcbp)s.in_planes;
+  const gcbp g_w = (gcbp)s.w;
+  const gcbp g_zero = (gcbp)a.zeros;
+
+  const int nk = a.Kpad / BK;
+  int kt_begin = 0, kt_end = nk;
+  if (SK) {
+    kt_begin = blockIdx.y * a.kt_per_split;
+    kt_end = min(nk, kt_begin + a.kt_per_split);
+  }
+  const int ntile = kt_end - kt_begin;
+
+  // ---- DMA geometry.  Row block r of the stage: r < RA -> A rows 16 r .., else B rows 16 (r - RA) ..; wave w moves blocks
+  // w, w + NW, ... (all planes of a block).  lane -> (row = lane >> 2, LDS slot = lane & 3 holding k-slot (lane & 3) ^ ((lane >> 4) & 3)).
+  const int slot16 = (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  const long in_cstride = (long)s.B * s.H * s.W * (NP * 64);  // bytes per 32-channel chunk image of the input
+  gcbp q_src[QN];   // A: this lane's pixel for tap (0, 0), chunk 0 / B: this lane's filter row, K-tile 0 (k-slot of the lane included)
+  int a_hi0[QN], a_wi0[QN];
+  int q_dst[QN];    // wave-uniform: LDS byte offset of the block inside a stage (plane 0)
+  int q_pst[QN];    // wave-uniform: LDS bytes between the planes of the block
+  bool q_isA[QN];   // wave-uniform
+  {
+    const int howo = s.Ho * s.Wo;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const int r = min(q * NW + wave, RA + RB - 1);
+      q_isA[q] = r < RA;
+      q_dst[q] = r < RA ? r * 1024 : A_BYTES + (r - RA) * 1024;
+      q_pst[q] = r < RA ? PLA : PLB;
+      // A geometry
+      const int m = m0 + r * 16 + (lane >> 2);
+      const bool live = r < RA && m < s.M;
+      const int b = m / howo;
+      const int rr = m - b * howo;
+      const int ho = rr / s.Wo;
+      const int wo = rr - ho * s.Wo;
+      const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+      const long a_off = (((long)b * s.H + hi0) * s.W + wi0) * (NP * 64) + slot16;
+      // B geometry (rows past Npad feed columns >= N, which are never stored)
+      const int n = min(n0 + (r - RA) * 16 + (lane >> 2), a.Npad - 1);
+      const long b_off = (long)n * nk * (NP * 64) + slot16;
+      a_hi0[q] = r < RA ? (live ? hi0 : -(1 << 28)) : 0;  // dead A rows are never inside [0, H); B rows always are
+      a_wi0[q] = r < RA ? wi0 : 0;
+      q_src[q] = r < RA ? g_in + (live ? a_off : 0) : g_w + b_off;
+    }
+  }
+
+  // The stream walks this block's K-tiles in order; (chunk, tap) are carried instead of divided out of kt.  Tiles past the end
+  // re-fetch the last one (into a stage nobody reads any more): every issue_tile() is exactly P DMA instructions, so the counted
+  // waits stay exact.  Branch-free (wave-uniform selects), so the whole K loop body is one scheduling region.
+  int ld_kt = kt_begin;
+  int ld_chunk = kt_begin / a.T;
+  int ld_tap = kt_begin - ld_chunk * a.T;
+  auto issue_tile = [&](int stage) {
+    const int dh = (ld_tap * a.kw_magic) >> 16;
+    const int dw = ld_tap - dh * a.KW;
+    const long koff_a = (long)ld_chunk * in_cstride + ((long)dh * s.W + dw) * (NP * 64);
+    const long koff_b = (long)ld_kt * (NP * 64);
+    unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      // (bitwise, not short-circuit: no branches in the K loop)
+      const bool ok = (int)!q_isA[q] | ((int)((unsigned)(a_hi0[q] + dh) < (unsigned)s.H) & (int)((unsigned)(a_wi0[q] + dw) < (unsigned)s.W));
+      const gcbp src = ok ? q_src[q] + (q_isA[q] ? koff_a : koff_b) : g_zero + slot16;  // the zero page covers NP planes x 64 B
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + p * 64), (ldsbp)(st + q_dst[q] + p * q_pst[q]), 16, 0, 0);
+    }
+    const int adv = ld_kt + 1 < kt_end;
+    ld_kt += adv;
+    ld_tap += adv;
+    const int wrap = ld_tap == a.T;
+    ld_tap = wrap ? 0 : ld_tap;
+    ld_chunk += wrap;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int lrow = lane & 31;
+  const int kh = lane >> 5;
+  const int swz = (lrow >> 2) & 3;
+  const int frag_off[2] = {lrow * 64 + (((0 + kh) ^ swz) << 4), lrow * 64 + (((2 + kh) ^ swz) << 4)};  // k-chunk 0 / 1
+  const int a_row0 = wm * TM * 32 * 64, b_row0 = A_BYTES + wn * TN * 32 * 64;
+
+  bf16x8 fa[2][TM][NP], fb[2][TN][NP];  // fragment sets of the two 16-k chunks
+  auto read_frags = [&](int stage, auto c_c) {
+    constexpr int c = decltype(c_c)::value;
+    const unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) fa[c][i][p] = *reinterpret_cast<const bf16x8*>(st + a_row0 + p * PLA + i * 32 * 64 + frag_off[c]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) fb[c][j][p] = *reinterpret_cast<const bf16x8*>(st + b_row0 + p * PLB + j * 32 * 64 + frag_off[c]);
+  };
+  // cross products, smallest terms first; (i, j) innermost so consecutive MFMAs hit different accumulators
+  constexpr int NPROD = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
+  constexpr int PA_[6] = {NP == 3 ? 2 : (NP == 2 ? 1 : 0), 0, NP == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int PB_[6] = {0, NP == 3 ? 2 : (NP == 2 ? 1 : 0), NP == 3 ? 1 : 0, 0, 1, 0};
+  auto mfma_chunk = [&](auto c_c) {
+    constexpr int c = decltype(c_c)::value;
+#pragma unroll
+    for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][i][PA_[t]], fb[c][j][PB_[t]], acc[i][j], 0, 0, 0);
+  };
+  constexpr std::integral_constant<int, 0> C0{};
+  constexpr std::integral_constant<int, 1> C1{};
+
+  if (ntile > 0) {
+    // prologue: fill the ring (tiles 0 .. NS-1), wait for tile 0
+#pragma unroll
+    for (int d = 0; d < NS; ++d) issue_tile(d);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * P) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, C0);
+    int stage = 0;
+    for (int kt = 0; kt < ntile; ++kt) {
+      // ---- phase A: chunk-1 fragment reads of tile kt under the chunk-0 MFMAs
+      read_frags(stage, C1);
+      mfma_chunk(C0);
+      sched_interleave<TM * TN * NPROD, (TM + TN) * NP, 0>();
+      __builtin_amdgcn_sched_barrier(0);
+      // my pieces of tile kt+1 have landed once at most NS-2 newer tiles are in flight; my reads of this stage are done
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * P) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone: tile kt+1 landed, stage `stage` (tile kt) no longer read
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B: DMA of tile kt+NS into the stage just freed and chunk-0 fragment reads of tile kt+1 under the chunk-1 MFMAs
+      issue_tile(stage);
+      stage = stage == NS - 1 ? 0 : stage + 1;
+      read_frags(stage, C0);  // (past the end: a stage holding surplus data, never used)
+      mfma_chunk(C1);
+      sched_interleave<TM * TN * NPROD, (TM + TN) * NP, P>();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is released
+  }
+
+  if constexpr (SK) {
+    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
+  }
+  conv_epilogue<TM, TN, MODE>(a, s, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ host
+template <int TM, int TN, int WM, int WN, int MODE>
+static int launch_planes_tile(const ConvKArgs& ka, hipStream_t st) {
+  constexpr int NP = Planes<MODE>::NP;
+  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
+  constexpr int STAGE = NP * (BM + BN) * 64;
+  // 8-wave blocks own the CU (144 KiB ring); 4-wave blocks are sized so that two share a CU (<= 72 KiB each)
+  constexpr int BUDGET = (WM * WN == 8 ? 144 : 72) * 1024;
+  constexpr int NS0 = BUDGET / STAGE;
+  constexpr int NS = NS0 > 4 ? 4 : (NS0 < 2 ? 2 : NS0);
+  const size_t lds = (size_t)NS * STAGE;
+  dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true>), grid, dim3(NTHR), lds, st, ka);
+  else hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false>), grid, dim3(NTHR), lds, st, ka);
+  return check_launch("conv_igemm_planes kernel");
+}
+
+template <int MODE>
+static int launch_planes_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st) {
+  switch (tile_cfg) {
+    case DD3D_TILE_256x128: return launch_planes_tile<2, 2, 4, 2, MODE>(ka, st);
+    case DD3D_TILE_128x128: return launch_planes_tile<2, 1, 2, 4, MODE>(ka, st);
+    case DD3D_TILE_128x64_K2:
+    case DD3D_TILE_128x64: return launch_planes_tile<1, 1, 4, 2, MODE>(ka, st);
+    case DD3D_TILE_64x128_K2:
+    case DD3D_TILE_64x128: return launch_planes_tile<1, 1, 2, 4, MODE>(ka, st);
+    case DD3D_TILE_128x128_W4: return launch_planes_tile<2, 2, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_64x64_W4K2:
+    case DD3D_TILE_64x64_W4: return launch_planes_tile<1, 1, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_128x64_W4: return launch_planes_tile<2, 1, 2, 2, MODE>(ka, st);
+  }
+  DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no split-plane kernel", tile_cfg);
+}
+
+int launch_conv_planes(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st) {
+  switch (math_mode) {
+    case DD3D_MATH_BF16X3: return launch_planes_mode<DD3D_MATH_BF16X3>(ka, tile_cfg, st);
+    case DD3D_MATH_BF16X2: return launch_planes_mode<DD3D_MATH_BF16X2>(ka, tile_cfg, st);
+    case DD3D_MATH_BF16: return launch_planes_mode<DD3D_MATH_BF16>(ka, tile_cfg, st);
+  }
+  DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: math mode %d has no split-plane kernel", math_mode);
+}
+
+}  // namespace dd3d
+
+// ------------------------------------------------------------------------------------------------------------------
+// f32 NHWC -> split planes (for tensors a non-convolution kernel produced).  One thread per (pixel, 8 channels): two 16-byte loads,
+// one 16-byte store per plane; HBM-bound.
+namespace dd3d {
+
+template <int MODE>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, int M, int C8, int in_pitch,
+                                                           int relu) {
+  constexpr int NP = Planes<MODE>::NP;
+  const long total = (long)M * C8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(t / C8);
+    const int c8 = (int)(t - (long)m * C8);
+    const float* src = in + (long)m * in_pitch + c8 * 8;
+    f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x0[e] = fmaxf(x0[e], 0.f), x1[e] = fmaxf(x1[e], 0.f);
+    }
+    unsigned w[4][NP];
+    split_pack<MODE>(x0[0], x0[1], w[0]);
+    split_pack<MODE>(x0[2], x0[3], w[1]);
+    split_pack<MODE>(x1[0], x1[1], w[2]);
+    split_pack<MODE>(x1[2], x1[3], w[3]);
+    unsigned char* dst = out + ((long)(c8 >> 2) * M + m) * (NP * 64) + (c8 & 3) * 16;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<u32x4*>(dst + p * 64) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
+    }
+  }
+}
+
+}  // namespace dd3d
+
+extern "C" int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t C, int32_t in_pitch, int32_t math_mode, int32_t relu, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(in && out && M > 0 && C > 0 && C % 32 == 0 && in_pitch >= C && in_pitch % 4 == 0, "dd3d_split_planes: bad shape (M=%d C=%d pitch=%d)", M,
+               C, in_pitch);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)M * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  unsigned char* o = reinterpret_cast<unsigned char*>(out);
+  switch (math_mode) {
+    case DD3D_MATH_BF16X3: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16X3>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu); break;
+    case DD3D_MATH_BF16X2: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16X2>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu); break;
+    case DD3D_MATH_BF16: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu); break;
+    default: DD3D_REQUIRE(false, "dd3d_split_planes: math mode %d has no planes", math_mode);
+  }
+  return check_launch("split_planes kernel");
+}

@@ -27,33 +27,62 @@ NUM_CU = 256  # MI355X
 
 # --------------------------------------------------------------------------------------------- buffers
 class Buf:
-    """NHWC fp32 activation buffer [B, H, W, pitch] in HBM."""
-    def __init__(self, B, H, W, C, device, name=""):
+    """Activation tensor [B, H, W, pitch channels] in HBM, held in one or both of two storages:
+      f32     `.t`  NHWC fp32 [B, H, W, pitch]                        -- what the pooling / top-down / gating / decode kernels and the
+                                                                         residual adds read
+      planes  `.p`  int16 [pitch/32][B*H*W][NP][32]                   -- the split-plane form one convolution hands to the next
+                                                                         (include/dd3d_hip.h); NP = 16-bit terms of the math mode
+    A dry-run (CPU) plan always carries `.t`: it is the plan emulator's logical tensor, whatever the device storages would be."""
+    def __init__(self, B, H, W, C, device, name="", f32=True, planes=0, dry_run=False):
         self.B, self.H, self.W, self.pitch, self.name = B, H, W, C, name
-        self.t = torch.zeros((B, H, W, C), dtype=torch.float32, device=device)
+        self.has_f32, self.np = bool(f32) or not planes, int(planes)
+        self.t = torch.zeros((B, H, W, C), dtype=torch.float32, device=device) if (self.has_f32 or dry_run) else None
+        self.p = None
+        if planes:
+            assert C % 32 == 0, (name, C)
+            if not dry_run:
+                self.p = torch.zeros((C // 32, B * H * W, planes, 32), dtype=torch.int16, device=device)
 
     def view(self, c0=0, C=None):
         return View(self, c0, self.pitch - c0 if C is None else C)
 
     def nchw(self, c0=0, C=None):
         C = self.pitch - c0 if C is None else C
-        return self.t[..., c0:c0 + C].permute(0, 3, 1, 2)
+        if self.t is not None:
+            return self.t[..., c0:c0 + C].permute(0, 3, 1, 2)
+        # planes only: the value the planes encode (exact for the three-term split), channels c0 .. c0 + C
+        k0, k1 = c0 // 32, (c0 + C + 31) // 32
+        terms = (self.p[k0:k1].to(torch.int32) << 16).view(torch.float32)  # [chunks][BHW][NP][32]
+        x = terms[:, :, 0]
+        for q in range(1, self.np):
+            x = x + terms[:, :, q]
+        x = x.permute(1, 0, 2).reshape(self.B, self.H, self.W, (k1 - k0) * 32)
+        return x[..., c0 - 32 * k0:c0 - 32 * k0 + C].permute(0, 3, 1, 2)
 
 
 class View:
     """Channel slice [c0, c0+C) of a Buf."""
     def __init__(self, buf, c0, C):
         assert c0 % 4 == 0 and 0 <= c0 and c0 + C <= buf.pitch, (c0, C, buf.pitch)
+        assert not buf.np or c0 % 32 == 0, (buf.name, c0)  # a slice of a split-plane buffer is a run of whole 32-channel chunk images
         self.buf, self.c0, self.C = buf, c0, C
 
     @property
     def ptr(self):
-        return self.buf.t.data_ptr() + 4 * self.c0
+        return self.buf.t.data_ptr() + 4 * self.c0 if self.buf.has_f32 and self.buf.t is not None else 0
+
+    @property
+    def pptr(self):
+        """First chunk image of the slice in the split-plane storage (0 when the buffer has none)."""
+        b = self.buf
+        return b.p.data_ptr() + (self.c0 // 32) * (b.B * b.H * b.W) * b.np * 64 if b.p is not None else 0
 
     B = property(lambda s: s.buf.B)
     H = property(lambda s: s.buf.H)
     W = property(lambda s: s.buf.W)
     pitch = property(lambda s: s.buf.pitch)
+    has_f32 = property(lambda s: s.buf.has_f32)
+    np = property(lambda s: s.buf.np)
 
     def nchw(self):
         return self.buf.nchw(self.c0, self.C)
@@ -133,6 +162,21 @@ def split_bf16x3(wp):
     return planes.view(3, Npad, Kpad // 32, 32).permute(1, 2, 0, 3).contiguous()
 
 
+def split_planes_host(wp, math):
+    """Wp[Npad][Kpad] f32 -> [Npad][Kpad/32][NP][32] 16-bit terms of arithmetic mode `math`, split exactly as the kernels split the
+    activations (csrc/conv_common.h::split_pack): three truncated bf16 terms (BF16X3), or round-to-nearest-even hi (+ lo) terms."""
+    if math == hip.MATH_BF16X3:
+        return split_bf16x3(wp)
+    x = wp.detach().float().cpu().contiguous()
+    hi = x.to(torch.bfloat16)
+    terms = [hi]
+    if math == hip.MATH_BF16X2:
+        terms.append((x - hi.float()).to(torch.bfloat16))
+    Npad, Kpad = x.shape
+    planes = torch.stack([t.view(torch.int16) for t in terms], 0)
+    return planes.view(len(terms), Npad, Kpad // 32, 32).permute(1, 2, 0, 3).contiguous()
+
+
 def pack_smallc_bf16x3(weights, cin_p):
     """OIHW filter (Cin <= cin_p in {4, 16}) -> [chunk][plane][Npad16][32] bf16 bit patterns in the k order of
     dd3d_conv2d_smallc_bf16x3 (include/dd3d_hip.h)."""
@@ -180,16 +224,22 @@ MATH_TILES = {  # tile configurations instantiated per arithmetic mode
     hip.MATH_BF16X3: (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4,
                       hip.TILE_128x64_W4, hip.TILE_128x64_K2, hip.TILE_64x128_K2, hip.TILE_64x64_W4K2),
 }
+# the split-plane kernel (csrc/conv_planes.hip): one barrier per K-tile for every tile, so no "two K-tiles per barrier" variants
+PLANE_TILES = (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4, hip.TILE_128x64_W4)
+PLANE_TILE_ALIAS = {hip.TILE_128x64_K2: hip.TILE_128x64, hip.TILE_64x128_K2: hip.TILE_64x128, hip.TILE_64x64_W4K2: hip.TILE_64x64_W4}
+for _m in (hip.MATH_BF16X2, hip.MATH_BF16):
+    MATH_TILES[_m] = PLANE_TILES
 # blocks of a configuration that can share a CU (LDS-limited); the f32 kernels were measured, see profiles/
 BLOCKS_PER_CU = {hip.TILE_128x128_W4: 2, hip.TILE_64x64_W4: 2, hip.TILE_128x64_W4: 2}  # tiles the split-bf16 kernel is instantiated for
 
 
-MATH_NAMES = {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3}
+MATH_NAMES = {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3, "bf16x2": hip.MATH_BF16X2, "bf16": hip.MATH_BF16}
 
 
 def default_math():
     """Arithmetic of the Cin % 32 == 0 convolutions: "bf16x3" (default; f32-equivalent split-operand products on the bf16 matrix
-    pipe, ~1.9x the throughput) or "f32" (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).  Env DD3D_MATH or model.math."""
+    pipe), "f32" (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), or the reduced modes BASELINE.json's bf16 configurations name:
+    "bf16x2" (two bf16 terms, three products) and "bf16" (plain bf16 operands); all accumulate in f32.  Env DD3D_MATH or model.math."""
     import os
     return MATH_NAMES[os.environ.get("DD3D_MATH", "bf16x3")]
 
@@ -207,24 +257,31 @@ def _load_tile_table(math_name):
     return json.load(open(path)) if os.path.exists(path) else {}
 
 
-TILE_TABLE = {hip.MATH_F32: _load_tile_table("f32"), hip.MATH_BF16X3: _load_tile_table("bf16x3")}
+TILE_TABLE = {hip.MATH_F32: _load_tile_table("f32"), hip.MATH_BF16X3: _load_tile_table("bf16x3"), hip.MATH_BF16X2: _load_tile_table("bf16x2"),
+              hip.MATH_BF16: _load_tile_table("bf16")}
+PLANE_TILE_TABLE = {m: _load_tile_table(n + "_planes") for n, m in (("bf16x3", hip.MATH_BF16X3), ("bf16x2", hip.MATH_BF16X2), ("bf16", hip.MATH_BF16))}
 
 
-def choose_tiling(m_list, N, Kpad, stride=1, math=0):
+def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
     """Pick (tile_cfg, splitk): a measured table entry when this exact shape has one, else minimise the modelled makespan
     on 256 CUs: every block costs BM*BN*K MACs on its CU's matrix pipe (partial tiles cost the same as full ones); split-K
-    adds the partial-sum exchange."""
-    allowed = MATH_TILES[math]
-    hit = TILE_TABLE[math].get(tile_key(m_list, N, Kpad, stride))
+    adds the partial-sum exchange.  `planes`: the split-plane-input kernel (its own measured table; the f32-input kernel's
+    entries serve as the fallback for the three-term mode, their two-K-tiles-per-barrier variants mapped to the plain tile)."""
+    allowed = PLANE_TILES if planes else MATH_TILES[math]
+    key = tile_key(m_list, N, Kpad, stride)
+    hit = PLANE_TILE_TABLE[math].get(key) if planes else TILE_TABLE[math].get(key)
+    if hit is None and planes and math == hip.MATH_BF16X3:
+        hit = TILE_TABLE[math].get(key)
     if hit is not None:
-        return next(c for c, nm in hip.TILE_NAMES.items() if nm == hit[0]), int(hit[1])
+        cfg = next(c for c, nm in hip.TILE_NAMES.items() if nm == hit[0])
+        return (PLANE_TILE_ALIAS.get(cfg, cfg) if planes else cfg), int(hit[1])
     nk = Kpad // 32
     best = None
     for cfg in allowed:
         bm, bn = hip.TILE_SHAPES[cfg]
         if bn == 32 and N > 32:
             continue
-        if bn > 32 and N <= 32:
+        if bn > 32 and N <= 32 and not (planes and bn == 64):  # (the split-plane kernel has no 32-wide tile: narrow convs pad to 64)
             continue
         if bn == 128 and N <= 64:
             continue
@@ -242,6 +299,8 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
                 cost /= {hip.TILE_256x128: 2.4, hip.TILE_128x128: 1.8, hip.TILE_128x64: 1.3, hip.TILE_64x128: 1.3,
                          hip.TILE_128x128_W4: 1.0, hip.TILE_64x64_W4: 0.6, hip.TILE_128x64_W4: 0.8,
                          hip.TILE_128x64_K2: 1.0, hip.TILE_64x128_K2: 1.0, hip.TILE_64x64_W4K2: 0.5}[cfg]  # rough; the table decides
+                if math in (hip.MATH_BF16X2, hip.MATH_BF16):  # fewer products per K-tile: the matrix term shrinks, the rest does not
+                    cost *= {hip.MATH_BF16X2: 0.6, hip.MATH_BF16: 0.35}[math]
             if sk > 1:
                 # second launch (~2 us) + partial-sum round trip (sk*M*N*8 B at ~3 TB/s), in per-CU MAC units
                 # (one CU retires 157.3e12 / 2 / 256 = 3.07e11 MAC/s)
@@ -252,19 +311,24 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0):
 
 
 class ConvOp:
-    """One dd3d_conv2d_igemm_f32 launch (possibly many segments)."""
+    """One dd3d_conv2d_igemm_f32 launch (possibly many segments).  Input form: the split planes of the input buffers when they have
+    them (plan.use_planes), else f32 NHWC.  Output form per segment: every storage its output buffer has (f32 NHWC and / or split
+    planes), unless the segment says `write_f32=False` / `write_planes=False`."""
     def __init__(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name="", math=None, in_relu=False):
         dev = plan.device
         self.name = name
         m_list = [s["out"].B * s["out"].H * s["out"].W for s in segs]
         if math is None:
             math = plan.math
-        if meta["Cin"] % 32 or meta["N"] <= 32:  # stem layers (Cin 4 / 16) and the 5-channel predictors stay on the f32 kernel
+        in_planes = math != hip.MATH_F32 and meta["Cin"] % 32 == 0 and all(s["in"].np == hip.MATH_PLANES[math] for s in segs) and not in_relu
+        if meta["Cin"] % 32 or (meta["N"] <= 32 and not in_planes):  # stem layers (Cin 4 / 16) and narrow convs on f32 input: the f32 kernel
             math = hip.MATH_F32
-        self.math = math
-        cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math)
+        if math in (hip.MATH_BF16X2, hip.MATH_BF16) and not in_planes:
+            raise ValueError(f"conv {name}: math mode {math} reads split-plane input only; its input buffer has none")
+        self.math, self.in_planes = math, in_planes
+        cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math, planes=in_planes)
         if tile is not None:
-            if tile not in MATH_TILES[math]:
+            if tile not in (PLANE_TILES if in_planes else MATH_TILES[math]):
                 raise ValueError(f"conv {name}: tile {hip.TILE_NAMES[tile]} is not instantiated for math mode {math}")
             cfg = tile
         if splitk is not None:
@@ -273,6 +337,7 @@ class ConvOp:
         arr = np.zeros(len(segs), dtype=hip.CONV_SEG_DTYPE)
         tiles = []
         self.keep = []
+        self.out_forms = []
         for i, s in enumerate(segs):
             vin, vout = s["in"], s["out"]
             assert vin.C == meta["Cin"], (name, vin.C, meta["Cin"])
@@ -281,8 +346,23 @@ class ConvOp:
             Wo = (vin.W + 2 * pad - meta["KW"]) // stride + 1
             assert (Ho, Wo) == (vout.H, vout.W) and vin.B == vout.B, (name, Ho, Wo, vout.H, vout.W)
             a = arr[i]
-            w = s["w"] if math == hip.MATH_F32 else plan.split_weight(s["w"])
-            a["in_"], a["w"], a["out"] = vin.ptr, w.data_ptr(), vout.ptr
+            w = s["w"] if math == hip.MATH_F32 else plan.split_weight(s["w"], math)
+            a["w"] = w.data_ptr()
+            if in_planes:
+                a["in_planes"] = vin.pptr
+            else:
+                assert vin.has_f32, f"conv {name}: the f32-input kernel reads a buffer that has split planes only"
+                a["in_"] = vin.ptr
+            # output forms
+            wf = vout.has_f32 and s.get("write_f32", True)
+            wp = bool(vout.np) and s.get("write_planes", True) and math != hip.MATH_F32
+            if vout.np and wp:
+                assert vout.np == hip.MATH_PLANES[math], (name, vout.np, math)
+                assert not s.get("n_limit"), f"conv {name}: n_limit segments write f32 maps only"
+            assert wf or wp, f"conv {name}: segment {i} writes nothing"
+            a["out"] = vout.ptr if wf else 0
+            a["out_planes"] = vout.pptr if wp else 0
+            self.out_forms.append((wf, wp))
             a["scale"], a["bias"] = s["scale"].data_ptr(), s["bias"].data_ptr()
             a["lo"] = s["lo"].data_ptr() if s.get("lo") is not None else 0
             a["B"], a["H"], a["W"], a["Ho"], a["Wo"] = vin.B, vin.H, vin.W, Ho, Wo
@@ -291,12 +371,14 @@ class ConvOp:
             res = s.get("res")
             if res is not None:
                 assert (res.B, res.H, res.W) == (vout.B, vout.H, vout.W) and res.C >= meta["N"]
+                assert res.has_f32, f"conv {name}: the residual is read as f32"
                 a["res"], a["res_pitch"], a["res_mode"] = res.ptr, res.pitch, 1
             a["n_limit"] = int(s.get("n_limit", 0))
             assert a["n_limit"] <= meta["N"]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
             self.keep += [w, s["scale"], s["bias"], s.get("lo")]
-        self.desc = dict(kind="conv", segs=segs, meta=meta, stride=stride, pad=pad, relu=bool(relu), in_relu=bool(in_relu))
+        self.desc = dict(kind="conv", segs=segs, meta=meta, stride=stride, pad=pad, relu=bool(relu), in_relu=bool(in_relu),
+                         in_form="planes" if in_planes else "f32", out_forms=self.out_forms)
         self.segs_host = arr  # kept alive: single-segment launches hand the descriptor over by value (seg0_host)
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
@@ -318,11 +400,12 @@ class ConvOp:
         L.seg0_host = self.segs_host.ctypes.data if len(segs) == 1 else None
         assert not in_relu or math == hip.MATH_BF16X3
         L.in_relu = int(in_relu)
+        L.in_planes = int(in_planes)
         self.L = L
         # algorithmic MACs: every segment counts the channels it stores
         self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs)) * meta["KH"] * meta["KW"] * meta["Cin"]
         self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), tile_name=hip.TILE_NAMES[cfg], splitk=sk, math=math,
-                         blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs))
+                         blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs), in_form="planes" if in_planes else "f32")
 
     def __call__(self, lib, stream):
         hip.check(lib.dd3d_conv2d_igemm_f32(C.byref(self.L), stream), "conv " + self.name)
@@ -375,47 +458,78 @@ class PlanBase:
         self.math = default_math()
         self._split = {}
 
-    def split_weight(self, wp):
-        """bf16 hi/mid/lo planes of a packed filter, built once per filter (the towers share theirs over 5 levels)."""
-        key = wp.data_ptr()
+    @property
+    def use_planes(self):
+        """Convolutions hand their outputs to the next convolution as split planes (csrc/conv_planes.hip) -- always in the reduced
+        modes (they have no f32-input kernel); in the three-term mode unless DD3D_PLANES=0 selects the round-1 data flow (f32 NHWC
+        everywhere, operands split on the fly by the consumer) for A/B measurements."""
+        import os
+        if self.math == hip.MATH_F32:
+            return False
+        return self.math != hip.MATH_BF16X3 or os.environ.get("DD3D_PLANES", "1") != "0"
+
+    def split_weight(self, wp, math=hip.MATH_BF16X3):
+        """16-bit term planes of a packed filter, built once per filter and mode (the towers share theirs over 5 levels)."""
+        key = (wp.data_ptr(), math)
         if key not in self._split:
-            self._split[key] = (wp, split_bf16x3(wp).to(self.device))
+            self._split[key] = (wp, split_planes_host(wp, math).to(self.device))
         return self._split[key][1]
 
     # ------------------------------------------------------------------ helpers
-    def buf(self, name, B, H, W, Cc):
-        b = Buf(B, H, W, Cc, self.device, name)
+    def buf(self, name, B, H, W, Cc, kind="f32"):
+        """kind: which storages the tensor needs -- "f32" (read by a non-convolution kernel / as a residual / by the host), "planes"
+        (read by convolutions only), "both".  Without split planes in the plan (f32 math, DD3D_PLANES=0) everything is f32."""
+        assert kind in ("f32", "planes", "both"), kind
+        planes = hip.MATH_PLANES[self.math] if (self.use_planes and kind != "f32" and Cc % 32 == 0) else 0
+        b = Buf(B, H, W, Cc, self.device, name, f32=(kind != "planes" or not planes), planes=planes, dry_run=self.dry_run)
         self.bufs[name] = b
         return b
+
+    def split(self, view, relu=False, dst=None, name=""):
+        """f32 slice -> its split planes (the entry into the plane form for tensors a non-convolution kernel, the stem or an f32-math
+        convolution wrote).  `dst`: another buffer's slice (LastLevelP6P7: the planes of relu(p6))."""
+        dst = view if dst is None else dst
+        assert view.has_f32 and dst.np and view.C % 32 == 0 and dst.C == view.C, (name, view.C, dst.C)
+        M = view.B * view.H * view.W
+        assert (dst.B, dst.H, dst.W) == (view.B, view.H, view.W)
+
+        def _f(lib, st, view=view, dst=dst, M=M):
+            hip.check(lib.dd3d_split_planes(view.ptr, dst.pptr, M, view.C, view.pitch, self.math, int(relu), st), "split_planes " + name)
+
+        self.ops.append(CallOp(_f, name or "split", dict(kind="split_planes", src=view, dst=dst, relu=bool(relu))))
+
+    def f32_written(self, view, name=""):
+        """A kernel that writes f32 only has just filled `view`: bring the buffer's split planes (if it has any) up to date."""
+        if view.np:
+            self.split(view, name=(name or view.buf.name) + ".split")
 
     def _vec(self, t):
         return t.detach().float().contiguous().to(self.device)
 
-    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name="", in_relu=False, weight=None):
+    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name="", in_relu=False, weight=None, write_f32=True, write_planes=True):
         """One Conv2d(+folded norm)(+residual)(+relu) as a single-segment launch.  `weight`: an OIHW filter to use instead of the
-        module's (the same filter re-laid for a padded input layout, see `scatter_in_channels`)."""
+        module's (the same filter re-laid for a padded input layout, see `scatter_in_channels`).  `write_f32` / `write_planes`: drop
+        one of the output buffer's storages for this producer (e.g. an f32 copy nobody reads)."""
         scale, shift = fold_norm(conv, norm)
         explicit = weight is not None
         weight = dense_filter(conv) if weight is None else weight
         N, Cin, KH, KW = weight.shape
-        if getattr(conv, "groups", 1) > 1 or explicit:
-            w, meta = pack_filter(weight, self.device)
-            seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res}
-            op = ConvOp(self, meta, conv.stride, conv.padding, [seg], relu, name=name, in_relu=in_relu)
-            self.ops.append(op)
-            return op
         cin_p = 4 if Cin <= 4 else 16
         # (measured in-graph: the patch kernel takes 30 / 22 us where the im2col f32 kernel took 97 / 67 on base_layer / level0;
         # on the stride-2 Cin-16 level1 the patch is 4.6 inputs per output and the im2col kernel stays 3 us ahead)
-        if (self.math == hip.MATH_BF16X3 and Cin <= 16 and res is None and vin.C == cin_p and not (cin_p == 16 and conv.stride == 2)
-                and self.lib.dd3d_conv2d_smallc_supported(cin_p, KH, KW, conv.stride, conv.padding, N)):
+        if (not (getattr(conv, "groups", 1) > 1 or explicit) and self.math != hip.MATH_F32 and Cin <= 16 and res is None and vin.C == cin_p
+                and not (cin_p == 16 and conv.stride == 2) and self.lib.dd3d_conv2d_smallc_supported(cin_p, KH, KW, conv.stride, conv.padding, N)):
             op = SmallcConvOp(self, conv.weight, cin_p, conv.stride, conv.padding, vin, vout, self._vec(scale), self._vec(shift), relu, name)
             self.ops.append(op)
+            self.f32_written(vout, name)
             return op
-        w, meta = pack_filter(conv.weight, self.device)
-        seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res}
+        w, meta = pack_filter(weight, self.device)
+        seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res,
+               "write_f32": write_f32, "write_planes": write_planes}
         op = ConvOp(self, meta, conv.stride, conv.padding, [seg], relu, name=name, in_relu=in_relu)
         self.ops.append(op)
+        if op.math == hip.MATH_F32 and write_planes:
+            self.f32_written(vout, name)  # an f32-math kernel (stem-sized Cin, narrow N on f32 input) writes f32 only
         return op
 
     def maxpool(self, vin, vout, name="pool"):
@@ -425,6 +539,7 @@ class PlanBase:
             hip.check(lib.dd3d_maxpool2x2_nhwc(vin.ptr, vout.ptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, st), name)
 
         self.ops.append(CallOp(_f, name, dict(kind="maxpool2x2", vin=vin, vout=vout)))
+        self.f32_written(vout, name)
 
     def upsample_add(self, fine, coarse, name="fpn_topdown"):
         assert fine.C == coarse.C and coarse.H * 2 == fine.H and coarse.W * 2 == fine.W
@@ -435,6 +550,7 @@ class PlanBase:
             )
 
         self.ops.append(CallOp(_f, name, dict(kind="upsample2x_add", fine=fine, coarse=coarse)))
+        self.f32_written(fine, name)
 
     # ------------------------------------------------------------------ side branches
     def branch(self, b):
@@ -567,14 +683,14 @@ class ForwardPlan(PlanBase):
         self.strides = [s.stride for s in model.backbone_output_shape]
 
     # ------------------------------------------------------------------ DLA-34 (dla.py:170-355)
-    def _block(self, m, x, residual, out, name, join=None):
+    def _block(self, m, x, residual, out, name, join=None, out_f32=True):
         """BasicBlock (dla.py:50-62): conv1+norm+relu, conv2+norm (+residual) relu.  `join`: side branch that produces the
         residual; it runs beside conv1."""
-        mid = self.buf(name + ".mid", out.B, out.H, out.W, m.conv1.out_channels)
+        mid = self.buf(name + ".mid", out.B, out.H, out.W, m.conv1.out_channels, kind="planes")  # conv1 -> conv2 only
         self.conv_module(m.conv1, x, mid.view(), relu=True, name=name + ".conv1")
         if join is not None:
             self.join(join)
-        self.conv_module(m.conv2, mid.view(), out, relu=True, res=residual, name=name + ".conv2")
+        self.conv_module(m.conv2, mid.view(), out, relu=True, res=residual, name=name + ".conv2", write_f32=out_f32)
 
     def _tree(self, m, x, name, dst=None, cat=None, bottom=None, bottom_branch=None):
         """Tree.forward (dla.py:233-247) with the root's torch.cat realised by channel placement: the root reads
@@ -584,7 +700,7 @@ class ForwardPlan(PlanBase):
         oc, ic = m.out_channels, m.in_channels
         if m.levels == 1:
             if cat is None:
-                cat = self.buf(name + ".cat", B, Ho, Wo, m.root_dim)
+                cat = self.buf(name + ".cat", B, Ho, Wo, m.root_dim, kind="both")  # root input (planes); x1 / bottom also feed residual adds (f32)
                 if m.level_root:
                     bottom = cat.view(2 * oc, ic)
                     if m.stride > 1:
@@ -598,7 +714,7 @@ class ForwardPlan(PlanBase):
             side = bottom_branch
             if bottom is None:
                 if m.stride > 1:
-                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic).view()
+                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic, kind="both").view()
                     with self.branch(1):
                         self.maxpool(x, bottom, name + ".pool")
                     side = 1
@@ -613,13 +729,13 @@ class ForwardPlan(PlanBase):
                 residual = bottom
             x1, x2 = cat.view(oc, oc), cat.view(0, oc)
             self._block(m.tree1, x, residual, x1, name + ".tree1", join=side)
-            self._block(m.tree2, x1, x1, x2, name + ".tree2")
+            self._block(m.tree2, x1, x1, x2, name + ".tree2", out_f32=not x2.np)  # x2 only feeds the root (planes)
             if dst is None:
-                dst = self.buf(name + ".out", B, Ho, Wo, oc).view()
+                dst = self.buf(name + ".out", B, Ho, Wo, oc, kind="both").view()  # next level: conv input + max-pool input
             self.conv_module(m.root.conv, cat.view(), dst, relu=True, name=name + ".root")
             return dst
         assert m.levels == 2, "DLA-34 only nests trees two deep"
-        cat2 = self.buf(name + ".cat", B, Ho, Wo, m.tree2.root_dim)
+        cat2 = self.buf(name + ".cat", B, Ho, Wo, m.tree2.root_dim, kind="both")
         off = 2 * oc
         bottom = None
         bb = None
@@ -639,9 +755,9 @@ class ForwardPlan(PlanBase):
         if not isinstance(m, Bottleneck):
             return self._block(m, x, residual, out, name)
         c = m.conv1.out_channels
-        b1 = self.buf(name + ".b1", x.B, x.H, x.W, c)
+        b1 = self.buf(name + ".b1", x.B, x.H, x.W, c, kind="planes")
         self.conv_module(m.conv1, x, b1.view(), relu=True, name=name + ".conv1")
-        b2 = self.buf(name + ".b2", out.B, out.H, out.W, c)
+        b2 = self.buf(name + ".b2", out.B, out.H, out.W, c, kind="planes")
         self.conv_module(m.conv2, b1.view(), b2.view(), relu=True, name=name + ".conv2")
         self.conv_module(m.conv3, b2.view(), out, relu=True, res=residual, name=name + ".conv3")
 
@@ -656,7 +772,7 @@ class ForwardPlan(PlanBase):
             inner = m
             while inner.levels > 1:
                 inner = inner.tree2
-            cat = self.buf(name + ".cat", B, Ho, Wo, inner.root_dim)
+            cat = self.buf(name + ".cat", B, Ho, Wo, inner.root_dim, kind="both")
             off = 2 * oc
             if m.level_root:
                 if m.stride == 1:
@@ -667,7 +783,7 @@ class ForwardPlan(PlanBase):
         if m.levels == 1:
             if bottom is None:
                 if m.stride > 1:
-                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic).view()
+                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic, kind="both").view()
                     self.maxpool(x, bottom, name + ".pool")
                 else:
                     bottom = x
@@ -679,7 +795,7 @@ class ForwardPlan(PlanBase):
             self._block_any(m.tree1, x, residual, x1, name + ".tree1")
             self._block_any(m.tree2, x1, x1, x2, name + ".tree2")
             if dst is None:
-                dst = self.buf(name + ".out", B, Ho, Wo, oc).view()
+                dst = self.buf(name + ".out", B, Ho, Wo, oc, kind="both").view()
             self.conv_module(m.root.conv, cat.view(), dst, relu=True, res=x2 if m.root.residual else None, name=name + ".root")
             return dst
         t1 = cat.view(off, oc)
@@ -697,7 +813,7 @@ class ForwardPlan(PlanBase):
             self.conv_module(conv, x, y.view(), relu=True, name=f"level0.{i}")
             x = y.view()
         for i, conv in enumerate(dla.level1):
-            y = self.buf(f"level1.{i}", B, x.H // conv.stride, x.W // conv.stride, ch[1])
+            y = self.buf(f"level1.{i}", B, x.H // conv.stride, x.W // conv.stride, ch[1], kind="both")  # level2: conv input + max-pool input
             self.conv_module(conv, x, y.view(), relu=True, name=f"level1.{i}")
             x = y.view()
         outs = {"level0": None, "level1": x}
@@ -717,15 +833,15 @@ class ForwardPlan(PlanBase):
         from dd3d_amd.modeling.vovnet import seq_conv, seq_dw, seq_norm
         B = img.B
 
-        def conv_norm_relu(dw, conv, norm, src, dst, name, stride=1):
+        def conv_norm_relu(dw, conv, norm, src, dst, name, stride=1, write_f32=True):
             """conv3x3 / conv1x1 (vovnet.py:124-161), or dw_conv3x3 (:99-121): depthwise 3x3 (no norm, no relu) into a scratch buffer, then
             the pointwise 1x1 + norm + relu."""
             if dw is not None:
                 Ho, Wo = (src.H + 2 - 3) // dw.stride + 1, (src.W + 2 - 3) // dw.stride + 1
-                tmp = self.buf(name + ".dw", B, Ho, Wo, pad32(dw.out_channels)).view()
+                tmp = self.buf(name + ".dw", B, Ho, Wo, pad32(dw.out_channels), kind="planes").view()
                 self.conv_module(dw, src, tmp, relu=False, name=name + ".dw")
                 src = tmp
-            self.conv_module(conv, src, dst, relu=True, norm=norm, name=name)
+            self.conv_module(conv, src, dst, relu=True, norm=norm, name=name, write_f32=write_f32)
 
         x = img
         stages = [getattr(vov, n) for n in vov.stage_names]
@@ -741,10 +857,10 @@ class ForwardPlan(PlanBase):
             strided = dw if dw is not None else conv
             Ho, Wo = (x.H + 2 - 3) // strided.stride + 1, (x.W + 2 - 3) // strided.stride + 1
             if idx == len(vov.stem_seqs) - 1:
-                cat = self.buf("stage2.OSA2_1.cat", B, Ho, Wo, cat_width(mods0[0]))
+                cat = self.buf("stage2.OSA2_1.cat", B, Ho, Wo, cat_width(mods0[0]), kind="both")
                 y = cat.view(0, pad32(conv.out_channels))
-            else:
-                y = self.buf(f"stem.{idx}", B, Ho, Wo, conv.out_channels).view()
+            else:  # stem_1 comes out of the patch kernel as f32 (split afterwards); stem_2 only feeds stem_3
+                y = self.buf(f"stem.{idx}", B, Ho, Wo, conv.out_channels, kind="both" if idx == 0 else "planes").view()
             conv_norm_relu(dw, conv, norm, x, y, cname)
             x = y
         outs, prev = {}, None
@@ -755,35 +871,36 @@ class ForwardPlan(PlanBase):
                 Wp = -(-(prev.W - 3) // 2) + 1
                 Hp -= (Hp - 1) * 2 >= prev.H
                 Wp -= (Wp - 1) * 2 >= prev.W
-                cat = self.buf(f"{sname}.{mods[0][0]}.cat", B, Hp, Wp, cat_width(mods[0][1]))
+                cat = self.buf(f"{sname}.{mods[0][0]}.cat", B, Hp, Wp, cat_width(mods[0][1]), kind="both")
                 dstv = cat.view(0, pad32(mods[0][1].in_ch))
 
                 def _pool(lib, st, vin=prev, vout=dstv):
                     hip.check(lib.dd3d_maxpool3x3s2_ceil_nhwc(vin.ptr, vout.ptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, st), "pool3")
 
                 self.ops.append(CallOp(_pool, f"{sname}.pool", dict(kind="maxpool3x3s2_ceil", vin=prev, vout=dstv)))
+                self.f32_written(dstv, f"{sname}.pool")
             H, W = cat.H, cat.W
             for k, (mname, m) in enumerate(mods):
                 pin, pst, pcc = pad32(m.in_ch), pad32(m.stage_ch), pad32(m.concat_ch)
                 src = cat.view(0, pin)
                 if m.conv_reduction is not None:  # depthwise modules: 1x1 to stage_ch first (vovnet.py:201-205,224-225); not part of the concat
-                    red = self.buf(f"{sname}.{mname}.red", B, H, W, pst).view()
+                    red = self.buf(f"{sname}.{mname}.red", B, H, W, pst, kind="planes").view()
                     self.conv_module(seq_conv(m.conv_reduction), src, red, relu=True, norm=seq_norm(m.conv_reduction), name=f"{mname}.reduction")
                     src = red
                 for i, layer in enumerate(m.layers):
                     dst = cat.view(pin + i * pst, pst)
-                    conv_norm_relu(seq_dw(layer), seq_conv(layer), seq_norm(layer), src, dst, f"{mname}.{i}")
+                    conv_norm_relu(seq_dw(layer), seq_conv(layer), seq_norm(layer), src, dst, f"{mname}.{i}", write_f32=not dst.np)
                     src = dst
                 xt = self.buf(f"{sname}.{mname}.xt", B, H, W, pcc).view()
                 segments = [(m.in_ch, pin)] + [(m.stage_ch, pst)] * len(m.layers)
                 w_cat = None if all(r == q for r, q in segments) else scatter_in_channels(seq_conv(m.concat).weight.detach(), segments)
                 self.conv_module(seq_conv(m.concat), cat.view(), xt, relu=True, norm=seq_norm(m.concat), name=f"{mname}.concat", weight=w_cat)
                 if k + 1 < len(mods):
-                    nxt = self.buf(f"{sname}.{mods[k + 1][0]}.cat", B, H, W, cat_width(mods[k + 1][1]))
+                    nxt = self.buf(f"{sname}.{mods[k + 1][0]}.cat", B, H, W, cat_width(mods[k + 1][1]), kind="both")
                     dst = nxt.view(0, pcc)
                 else:
                     nxt = None
-                    dst = self.buf(f"{sname}.out", B, H, W, pcc).view()
+                    dst = self.buf(f"{sname}.out", B, H, W, pcc, kind="both").view()  # stage output: FPN lateral + next stage's pool
                 self.ese(xt, cat.view(0, pin) if m.identity else None, dst, m.ese.fc, name=f"{mname}.ese")
                 cat = nxt
             outs[sname] = prev = dst
@@ -809,39 +926,49 @@ class ForwardPlan(PlanBase):
             )
 
         self.ops.append(CallOp(_f, name, dict(kind="ese", x=x, identity=identity, out=out, weight=w, bias=b)))
+        self.f32_written(out, name)
 
     # ------------------------------------------------------------------ FPN ([ext] detectron2 FPN.forward)
     def _fpn(self, fpn, feats):
         names = fpn.in_features
         results = {}
+        # pyramid outputs feed convolutions only (towers, P6); DD3D_KEEP_F32=1 keeps f32 copies too (debugging)
+        import os
+        p_kind = "both" if os.environ.get("DD3D_KEEP_F32", "0") == "1" else "planes"
         # The laterals of the finer levels only need backbone features: side branch 2, beside lateral/output of the coarsest
         # level; P6/P7 only need the coarsest output: side branch 3, beside the rest of the top-down path.
         lats = {}
         for idx in list(range(1, len(names))) + [0]:  # side-branch ops first: a branch forks where its first op sits in the list
             f = feats[names[-idx - 1]]
             st = fpn.stages[-idx - 1]
-            lat = self.buf(f"fpn_lateral{st}", f.B, f.H, f.W, fpn._out_feature_channels[f"p{st}"]).view()
+            # laterals: f32 for the top-down sum, planes for the output conv
+            lat = self.buf(f"fpn_lateral{st}", f.B, f.H, f.W, fpn._out_feature_channels[f"p{st}"], kind="both").view()
             lats[st] = lat
             if idx == 0:
                 self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}")
-                out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C).view()
+                out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C, kind=p_kind).view()
                 self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
                 results[f"p{st}"] = out
             else:
-                with self.branch(2):
-                    self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}")
+                with self.branch(2):  # (its planes are written after the top-down sum)
+                    self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}", write_planes=False)
         assert fpn._fuse_type == "sum", "FUSE_TYPE avg is not used by any reference config"
         if fpn.top_block is not None:
             st = fpn.stages[-1]
             x = results[f"p{st}"]  # in_feature "p5" is an FPN output (dla.py:550-557)
-            p6 = self.buf(f"p{st + 1}", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C).view()
+            p6 = self.buf(f"p{st + 1}", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C, kind="both").view()
             with self.branch(3):
                 self.conv_module(fpn.top_block.p6, x, p6, name="top_block.p6")
             results[f"p{st + 1}"] = p6
             if fpn.top_block.num_levels == 2:
-                p7 = self.buf(f"p{st + 2}", p6.B, (p6.H + 1) // 2, (p6.W + 1) // 2, p6.C).view()
+                p7 = self.buf(f"p{st + 2}", p6.B, (p6.H + 1) // 2, (p6.W + 1) // 2, p6.C, kind=p_kind).view()
                 with self.branch(3):
-                    if self.math == hip.MATH_BF16X3:
+                    if p6.np:
+                        # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the planes of relu(p6), split from its f32 copy
+                        p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C, kind="planes").view()
+                        self.split(p6, relu=True, dst=p6r, name="top_block.p6.relu")
+                        self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
+                    elif self.math == hip.MATH_BF16X3:
                         # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the conv rectifies its input while splitting it
                         self.conv_module(fpn.top_block.p7, p6, p7, name="top_block.p7", in_relu=True)
                     else:  # f32-MFMA mode: a rectified copy of p6 from a second run of its conv
@@ -858,7 +985,7 @@ class ForwardPlan(PlanBase):
                 self.join(2)
             self.upsample_add(lat, prev, f"fpn_topdown{st}")
             prev = lat
-            out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C).view()
+            out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C, kind=p_kind).view()
             self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
             results[f"p{st}"] = out
         self.fpn_tail_join = 3 if fpn.top_block is not None else None
@@ -873,8 +1000,8 @@ class ForwardPlan(PlanBase):
         nt = len(towers)
         Cf = feats[0].C
         depth = max(len(t) for _, t in towers)
-        ping = [self.buf(f"towerA.{l}", f.B, f.H, f.W, nt * Cf) for l, f in enumerate(feats)]
-        pong = [self.buf(f"towerB.{l}", f.B, f.H, f.W, nt * Cf) for l, f in enumerate(feats)]
+        ping = [self.buf(f"towerA.{l}", f.B, f.H, f.W, nt * Cf, kind="planes") for l, f in enumerate(feats)]  # conv -> conv only
+        pong = [self.buf(f"towerB.{l}", f.B, f.H, f.W, nt * Cf, kind="planes") for l, f in enumerate(feats)]
         cur = [[feats[l] for _ in range(nt)] for l in range(L)]  # current input view per (level, tower)
         for i in range(depth):
             dstbufs = ping if i % 2 == 0 else pong
@@ -1139,8 +1266,8 @@ class DenseDepthPlan(ForwardPlan):
         self._trunk(model, B, Hp, Wp)
         dev, feats, head = self.device, self.features, model.fcos3d_head
         L, Cf = len(feats), feats[0].C
-        ping = [self.buf(f"ddA.{l}", f.B, f.H, f.W, Cf) for l, f in enumerate(feats)]
-        pong = [self.buf(f"ddB.{l}", f.B, f.H, f.W, Cf) for l, f in enumerate(feats)]
+        ping = [self.buf(f"ddA.{l}", f.B, f.H, f.W, Cf, kind="planes") for l, f in enumerate(feats)]
+        pong = [self.buf(f"ddB.{l}", f.B, f.H, f.W, Cf, kind="planes") for l, f in enumerate(feats)]
         cur = list(feats)
         for i, conv in enumerate(head.box3d_tower):
             dst = ping if i % 2 == 0 else pong

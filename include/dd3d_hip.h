@@ -13,8 +13,12 @@
  *     persistent device memory and never synchronises the device.
  *   - kernels are enqueued asynchronously on `stream`; calls are safe under hipGraph stream capture.
  *   - return value: 0 = ok, <0 = error (DD3D_E_*); dd3d_last_error() gives a message (thread-local).
- *   - all activations are NHWC fp32 with an explicit per-pixel pitch, so a conv can read / write a
- *     channel slice of a wider buffer (this is how torch.cat in dla.py:161 disappears).
+ *   - activations are NHWC fp32 with an explicit per-pixel pitch, so a conv can read / write a
+ *     channel slice of a wider buffer (this is how torch.cat in dla.py:161 disappears), and / or
+ *     "split planes": [channel chunk c/32][pixel (b,h,w)][plane][32] 16-bit terms of the arithmetic
+ *     mode (DD3D_MATH_*), the form in which one convolution hands its output to the next so that
+ *     the consumer streams it into LDS by LDS-DMA with no conversion work (a channel slice of a
+ *     wider buffer = a run of whole chunk images, so the concat-by-placement carries over).
  */
 #ifndef DD3D_HIP_H
 #define DD3D_HIP_H
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DD3D_ABI_VERSION 1
+#define DD3D_ABI_VERSION 2
 
 #define DD3D_OK 0
 #define DD3D_E_INVALID (-1)  /* bad argument (shape / alignment / enum) */
@@ -72,9 +76,12 @@ typedef struct dd3d_conv_seg {  /* array lives in DEVICE memory */
   int32_t in_pitch, out_pitch, res_pitch; /* floats per pixel of the respective buffers          */
   int32_t M;           /* B*Ho*Wo                                                                */
   int32_t res_mode;    /* 0 none, 1 add res[m, n] (same pixel) before the clamp                  */
-  int32_t reserved0[2];
+  const void* in_planes; /* split-plane input [Cin/32][B*H*W][NP][32], first chunk of the slice; read instead of `in` when
+                            dd3d_conv_launch.in_planes is set                                    */
   int32_t n_limit;     /* > 0: this segment stores only output channels < n_limit (<= launch N); 0: all N  */
-  int32_t reserved[3];
+  int32_t reserved;
+  void* out_planes;    /* split-plane output [ceil(N/32)][M][NP][32] (first chunk of the slice) or NULL; `out` may then be NULL.
+                          Channels N .. 32*ceil(N/32)-1 of the last chunk are written as zeros.  Split-operand modes only. */
 } dd3d_conv_seg;
 
 typedef struct dd3d_conv_launch {  /* host memory */
@@ -96,7 +103,9 @@ typedef struct dd3d_conv_launch {  /* host memory */
   const dd3d_conv_seg* seg0_host; /* HOST copy of segs[0], or NULL.  With nsegs == 1 the descriptor then travels in the kernel
                                      arguments (tiles are taken as m0 = i * BM) and the device copies are not read. */
   int32_t in_relu; /* 1: the input is rectified on the fly, out = epilogue(conv(max(in, 0))) -- LastLevelP6P7: p7 = conv(relu(p6)).
-                      DD3D_MATH_BF16X3 only */
+                      DD3D_MATH_BF16X3 with f32 input only */
+  int32_t in_planes; /* 1: every segment reads its split-plane input (seg.in_planes) instead of the f32 one; Cin % 32 == 0 and a
+                        split-operand math mode */
 } dd3d_conv_launch;
 
 /* Arithmetic of the implicit GEMM (results agree to f32 rounding level; both accumulate in f32):
@@ -106,6 +115,14 @@ typedef struct dd3d_conv_launch {  /* host memory */
  *                     tiles 256x128 / 128x128 / 128x64 / 64x128 */
 #define DD3D_MATH_F32 0
 #define DD3D_MATH_BF16X3 1
+/* Reduced split-operand modes (what BASELINE.json's "bf16 inference" configurations name); split-plane inputs only
+ * (dd3d_split_planes converts an f32 tensor), f32 accumulate, filters split the same way, round-to-nearest-even terms:
+ *   DD3D_MATH_BF16X2  x ~ hi + lo (two bf16 terms, ~17 significand bits), 3 cross products: half the matrix work of BF16X3
+ *   DD3D_MATH_BF16    x ~ bf16(x), one product: plain bf16 operands */
+#define DD3D_MATH_BF16X2 2
+#define DD3D_MATH_BF16 3
+/* planes per value of a math mode (0 for DD3D_MATH_F32) */
+int dd3d_math_planes(int32_t math_mode);
 
 #define DD3D_TILE_128x128 0
 #define DD3D_TILE_128x64 1
@@ -123,6 +140,11 @@ typedef struct dd3d_conv_launch {  /* host memory */
 /* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
 int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
 int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);
+
+/* f32 NHWC -> split planes of `math_mode` (the entry into the plane format for tensors a non-convolution kernel produced: pooled
+ * maps, the FPN top-down sums, eSE outputs, the stem), optionally rectified (LastLevelP6P7: p7 = conv(relu(p6)) [ext]).
+ *   in [M][in_pitch] f32, channels [0, C), C % 32 == 0;  out [C/32][M][NP][32] 16-bit terms */
+int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t C, int32_t in_pitch, int32_t math_mode, int32_t relu, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-channel convolution (the full-resolution stem: dla.py:271-280,327-344 base_layer / level0 / level1,

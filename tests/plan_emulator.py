@@ -54,9 +54,65 @@ def _preprocess(plan, d):
     plan.inv_K.copy_(torch.linalg.inv(plan.in_K.view(-1, 3, 3)).reshape(-1, 9))
 
 
+class Forms:
+    """Which storage (f32 NHWC / split planes) of which channels of every buffer has been written so far.  A dry-run buffer keeps ONE
+    logical tensor for the emulation; on the device the two storages are separate memories, and a convolution reading the planes of a
+    buffer only its f32 side was written to (or the other way round) would read stale zeros.  Every op's reads are checked here."""
+    def __init__(self):
+        self.done = {}
+
+    def wrote(self, view, form, n=None):
+        has = view.buf.np if form == "planes" else view.buf.has_f32
+        assert has, f"{view.buf.name}: op writes the {form} storage, which this buffer does not have"
+        self.done.setdefault((id(view.buf), form), set()).update(range(view.c0, view.c0 + (view.C if n is None else n)))
+
+    def reads(self, view, form, what, n=None):
+        got = self.done.get((id(view.buf), form), set())
+        need = set(range(view.c0, view.c0 + (view.C if n is None else n)))
+        # channels nobody ever writes (32-channel padding of a concat slice) are zeros in both storages from allocation
+        other = self.done.get((id(view.buf), "planes" if form == "f32" else "f32"), set())
+        missing = (need - got) & other
+        assert not missing, f"{what}: reads the {form} storage of {view.buf.name} channels {min(missing)}..{max(missing)}, which only hold the other form"
+
+
+def _track(forms, name, d):
+    k = d["kind"]
+    if k == "conv":
+        for sg, (wf, wp) in zip(d["segs"], d["out_forms"]):
+            forms.reads(sg["in"], d["in_form"], name)
+            if sg.get("res") is not None:
+                forms.reads(sg["res"], "f32", name + " (residual)", d["meta"]["N"])
+            n = int(sg.get("n_limit") or d["meta"]["N"])
+            if wf:
+                forms.wrote(sg["out"], "f32", n)
+            if wp:
+                forms.wrote(sg["out"], "planes", (n + 31) // 32 * 32)
+    elif k == "smallc_conv":
+        forms.reads(d["vin"], "f32", name)
+        forms.wrote(d["vout"], "f32", d["weight"].shape[0])
+    elif k == "preprocess":
+        forms.wrote(d["img"].view(), "f32")
+    elif k == "split_planes":
+        forms.reads(d["src"], "f32", name)
+        forms.wrote(d["dst"], "planes")
+    elif k in ("maxpool2x2", "maxpool3x3s2_ceil"):
+        forms.reads(d["vin"], "f32", name)
+        forms.wrote(d["vout"], "f32")
+    elif k == "upsample2x_add":
+        forms.reads(d["fine"], "f32", name)
+        forms.reads(d["coarse"], "f32", name)
+        forms.wrote(d["fine"], "f32")
+    elif k == "ese":
+        forms.reads(d["x"], "f32", name)
+        if d["identity"] is not None:
+            forms.reads(d["identity"], "f32", name)
+        forms.wrote(d["out"], "f32")
+
+
 def emulate(plan, stop_before=("select_decode", )):
     """Run the plan's ops in order on its CPU buffers; returns the names of the ops executed."""
     done = []
+    forms = Forms()
     for op in plan.ops:
         if op.name in stop_before:
             break
@@ -64,12 +120,19 @@ def emulate(plan, stop_before=("select_decode", )):
         if d is None:
             raise NotImplementedError(f"op {op.name!r} carries no description")
         k = d["kind"]
+        _track(forms, op.name, d)
         if k == "conv":
             _conv(d)
         elif k == "smallc_conv":
             _smallc(d)
         elif k == "preprocess":
             _preprocess(plan, d)
+        elif k == "split_planes":
+            if d["dst"] is not d["src"]:
+                x = d["src"].nchw()
+                _store(d["dst"], F.relu(x) if d["relu"] else x, d["src"].C)
+            else:
+                assert not d["relu"]
         elif k == "maxpool2x2":
             _store(d["vout"], F.max_pool2d(d["vin"].nchw(), 2), d["vin"].C)
         elif k == "maxpool3x3s2_ceil":

@@ -1,0 +1,165 @@
+"""The split-plane data flow (csrc/conv_planes.hip, conv_common.h::conv_epilogue) through the C ABI vs a plain PyTorch fp32 reference:
+f32 -> dd3d_split_planes -> conv reading planes by LDS-DMA -> f32 and / or plane output -> the next conv reading those planes.
+
+Tolerances: the three-term mode (bf16x3) is held to the f32 kernels' tolerance (2e-5 of max |ref|); the reduced modes to what their
+operand width gives (bf16x2: two bf16 terms ~ 2^-17 per operand; bf16: 2^-9), stated per mode below."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dd3d_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+MODES = {"bf16x3": (hip.MATH_BF16X3, 2e-5), "bf16x2": (hip.MATH_BF16X2, 1e-4), "bf16": (hip.MATH_BF16, 3e-2)}
+
+CASES = [
+    # name, B, H, W, Cin, Cout, k, stride, pad, relu, residual, tile, splitk
+    ("tower_256x128", 1, 33, 41, 256, 256, 3, 1, 1, True, True, hip.TILE_256x128, 1),
+    ("tower_256x128_sk3_s2", 1, 30, 44, 128, 192, 3, 2, 1, False, False, hip.TILE_256x128, 3),
+    ("k32_256x128", 1, 24, 40, 32, 128, 1, 1, 0, False, False, hip.TILE_256x128, 1),  # a single K-tile
+    ("tower_128x128", 2, 17, 23, 256, 256, 3, 1, 1, True, True, hip.TILE_128x128, 1),
+    ("sk4_128x128", 1, 12, 20, 256, 256, 3, 1, 1, True, True, hip.TILE_128x128, 4),
+    ("tower_128x64", 1, 24, 40, 256, 256, 3, 1, 1, True, False, hip.TILE_128x64, 1),
+    ("s2_odd_128x64_sk2", 1, 13, 21, 256, 256, 3, 2, 1, False, False, hip.TILE_128x64, 2),
+    ("sk3_64x128", 1, 9, 31, 128, 192, 3, 1, 1, False, True, hip.TILE_64x128, 3),
+    ("w4_128x128", 2, 17, 23, 256, 256, 3, 1, 1, True, True, hip.TILE_128x128_W4, 1),
+    ("w4_64x64", 1, 24, 40, 256, 256, 3, 1, 1, True, False, hip.TILE_64x64_W4, 1),
+    ("w4_64x64_sk2_k64", 1, 24, 40, 64, 64, 1, 1, 0, False, True, hip.TILE_64x64_W4, 2),
+    ("w4_128x64_sk4", 1, 24, 40, 256, 128, 3, 1, 1, True, True, hip.TILE_128x64_W4, 4),
+    ("root1x1_k448", 1, 24, 40, 448, 128, 1, 1, 0, True, False, None, None),
+    ("pred_n55", 1, 24, 40, 256, 55, 3, 1, 1, False, False, None, None),
+    ("pred_n5", 1, 24, 40, 256, 5, 3, 1, 1, False, False, None, None),
+    ("tiny_3x5", 2, 3, 5, 256, 256, 3, 1, 1, True, False, None, None),  # P7-sized: every tap row / column meets the border
+    ("model_choice", 1, 48, 160, 256, 256, 3, 1, 1, True, False, None, None),
+]
+
+
+def _plan(math):
+    from dd3d_amd.engine import PlanBase
+    plan = PlanBase("cuda")
+    plan.math = math
+    return plan
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_planes_conv_matches_torch(hiplib, case, mode):
+    from dd3d_amd.engine import ConvOp, pack_filter
+    name, B, H, W, Cin, Cout, k, stride, pad, relu, use_res, tile, splitk = case
+    math, rtol = MODES[mode]
+    g = torch.Generator().manual_seed(sum(map(ord, name)) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k)**0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    bias = torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+    ref = F.conv2d(x, w, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+
+    plan = _plan(math)
+    wp, meta = pack_filter(w, plan.device)
+    # the input is a 32-aligned channel slice of a wider buffer (concat by placement carries over to the chunk-major plane layout)
+    xin = plan.buf("x", B, H, W, Cin + 64, kind="both")
+    xin.t[..., 32:32 + Cin] = x.permute(0, 2, 3, 1).to(plan.device)
+    plan.split(xin.view(32, Cin), name="x.split")
+    cpad = (Cout + 31) // 32 * 32
+    yout = plan.buf("y", B, Ho, Wo, cpad + 32, kind="both")
+    yout.t.fill_(-777.0)
+    yout.p.fill_(0x1234)
+    seg = {"in": xin.view(32, Cin), "out": yout.view(32, cpad), "w": wp, "scale": scale.to(plan.device), "bias": bias.to(plan.device)}
+    if res is not None:
+        rbuf = plan.buf("r", B, Ho, Wo, Cout)
+        rbuf.t.copy_(res.permute(0, 2, 3, 1))
+        seg["res"] = rbuf.view()
+    op = ConvOp(plan, meta, stride, pad, [seg], relu, tile=tile, splitk=splitk, name=name, math=math)
+    assert op.math == math and op.in_planes
+    plan.ops.append(op)
+    plan.launch()
+    torch.cuda.synchronize()
+    got = yout.t[..., 32:32 + Cout].permute(0, 3, 1, 2).cpu()
+    tol = rtol * max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"{name}/{mode}: max abs err {err:.3e} > {tol:.3e} (info {op.info})"
+    # f32 channels outside [32, 32 + Cout) untouched
+    assert torch.all(yout.t[..., :32] == -777.0) and torch.all(yout.t[..., 32 + Cout:] == -777.0)
+    # plane output: chunk images of the slice hold the split of the f32 output (exactly, for the three-term split; channels past N in
+    # the last chunk are zero); the chunk before the slice is untouched
+    np_ = hip.MATH_PLANES[math]
+    assert torch.all(yout.p[0] == 0x1234)
+    dec = (yout.p[1:].to(torch.int32) << 16).view(torch.float32).sum(2).permute(1, 0, 2).reshape(B, Ho, Wo, cpad).permute(0, 3, 1, 2).cpu()
+    assert torch.all(dec[:, Cout:] == 0)
+    if math == hip.MATH_BF16X3:
+        assert torch.equal(dec[:, :Cout], got)
+    else:
+        step = {2: 2.0**-15, 1: 2.0**-8}[np_]
+        assert float(((dec[:, :Cout] - got).abs() / got.abs().clamp(min=1e-20)).max()) <= step
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_two_convs_chained_through_planes_only(hiplib, mode):
+    """conv -> (planes only, no f32 copy) -> conv, multi-segment like the head towers (per-segment scale / bias), against torch."""
+    from dd3d_amd.engine import ConvOp, pack_filter
+    math, rtol = MODES[mode]
+    plan = _plan(math)
+    g = torch.Generator().manual_seed(11)
+    w1 = torch.randn(256, 256, 3, 3, generator=g) / 48.0
+    w2 = torch.randn(256, 256, 3, 3, generator=g) / 48.0
+    wp1, meta = pack_filter(w1, plan.device)
+    wp2, _ = pack_filter(w2, plan.device)
+    shapes = [(12, 40), (6, 20), (3, 10), (2, 5), (1, 3)]
+    segs1, segs2, refs, outs = [], [], [], []
+    for l, (h, wd) in enumerate(shapes):
+        x = torch.randn(2, 256, h, wd, generator=g)
+        s1, b1 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+        s2, b2 = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+        y1 = F.relu(F.conv2d(x, w1, None, padding=1) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+        refs.append(F.relu(F.conv2d(y1, w2, None, padding=1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1)))
+        xb = plan.buf(f"x{l}", 2, h, wd, 256, kind="both")
+        xb.t.copy_(x.permute(0, 2, 3, 1))
+        plan.split(xb.view(), name=f"x{l}.split")
+        mid = plan.buf(f"m{l}", 2, h, wd, 256, kind="planes")
+        yb = plan.buf(f"y{l}", 2, h, wd, 256, kind="both")
+        dev = plan.device
+        segs1.append({"in": xb.view(), "out": mid.view(), "w": wp1, "scale": s1.to(dev), "bias": b1.to(dev)})
+        segs2.append({"in": mid.view(), "out": yb.view(), "w": wp2, "scale": s2.to(dev), "bias": b2.to(dev)})
+        outs.append(yb)
+    for segs, nm in ((segs1, "l1"), (segs2, "l2")):
+        op = ConvOp(plan, meta, 1, 1, segs, relu=True, name=nm, math=math)
+        assert op.in_planes
+        plan.ops.append(op)
+    plan.launch()
+    torch.cuda.synchronize()
+    for l, ref in enumerate(refs):
+        got = outs[l].t.permute(0, 3, 1, 2).cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= 2 * rtol * max(1.0, ref.abs().max().item()), (l, mode, err)
+
+
+def test_split_planes_relu_and_slices(hiplib):
+    """dd3d_split_planes: exact three-term split, RNE terms of the reduced modes, the rectified variant (LastLevelP6P7) and a channel
+    slice source with a pitch."""
+    for mode, (math, _) in MODES.items():
+        plan = _plan(math)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 5, 7, 96, generator=g) * torch.logspace(-6, 6, 96).view(1, 1, 1, 96)
+        src = plan.buf("s", 2, 5, 7, 160, kind="f32")
+        src.t[..., 32:128] = x.to(plan.device)
+        dst = plan.buf("d", 2, 5, 7, 96, kind="planes")
+        dstr = plan.buf("dr", 2, 5, 7, 96, kind="planes")
+        plan.split(src.view(32, 96), dst=dst.view(), name="s")
+        plan.split(src.view(32, 96), relu=True, dst=dstr.view(), name="sr")
+        plan.launch()
+        torch.cuda.synchronize()
+        got, gotr = dst.nchw().permute(0, 2, 3, 1).cpu(), dstr.nchw().permute(0, 2, 3, 1).cpu()
+        if math == hip.MATH_BF16X3:
+            assert torch.equal(got, x) and torch.equal(gotr, F.relu(x))
+        else:
+            hi = x.to(torch.bfloat16)
+            want = hi.float() + ((x - hi.float()).to(torch.bfloat16).float() if math == hip.MATH_BF16X2 else 0.0)
+            assert torch.equal(got, want), mode
+            assert torch.equal(gotr, torch.where(x > 0, want, torch.zeros_like(want))), mode
