@@ -14,10 +14,11 @@ collective runs under the next steps' trunks; `--pipeline 0` issues one step at 
 `config`); every one of the K timed steps does all of its work and is complete before the closing synchronize.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch,
-conv_igemm_bf16x3_kernel<2,2,4,2,2,2,1,false> in the default split-bf16 arithmetic): algorithmic FLOPs of one launch / its mean
-duration measured here with HIP events on the launch stream, against the MFMA roofline of that arithmetic (2500 TFLOP/s dense
-bf16 / 6 products per f32 product; the f32-input MFMA peak 157.3 TFLOP/s when DD3D_MATH=f32).  ``cpu_baseline`` is the CPU oracle (a restatement
-"port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
+conv_igemm_planes_kernel<2,2,4,2,...> of csrc/conv_planes.hip): algorithmic FLOPs of one launch / its mean duration measured here with
+HIP events on the launch stream, against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
+matrix products spent per f32 product (``--math``: f16x2 3, bf16x3 6, bf16x2 3, bf16 1; the f32-input MFMA peak 157.3 TFLOP/s for f32).
+``blocks`` repeats the timed block a few times so that a reader can tell box / clock variance from a regression.  ``cpu_baseline`` is
+the CPU oracle (a restatement "port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -32,8 +33,17 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_bf16, dense
-# Split-operand arithmetic spends 6 bf16 MFMA products per f32 product, so its roofline in f32-equivalent FLOP/s is
-PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# Split-operand arithmetic spends several 16-bit MFMA products per f32 product; its roofline in f32-equivalent FLOP/s is the
+# dense 16-bit peak divided by that count (the f16 and bf16 pipes run at the same rate)
+PRODUCTS = {"f16x2": 3, "bf16x3": 6, "bf16x2": 3, "bf16": 1}
+DTYPES = {
+    "f16x2": "f32 (f16x2 split-operand MFMA: every f32 operand = two IEEE-half terms, 3 cross products, f32 accumulate; error vs a float64 "
+             "convolution equals the exact-f32 MFMA kernel's, tests/gpu_math_modes.py)",
+    "bf16x3": "f32 (bf16x3 split-operand MFMA: every f32 operand = three bf16 terms, 6 cross products, f32 accumulate)",
+    "bf16x2": "bf16x2 (two bf16 terms per operand, 3 cross products, f32 accumulate; ~1e-5 relative -- a reduced mode)",
+    "bf16": "bf16 (operands rounded to bf16, f32 accumulate -- a reduced mode)",
+    "f32": "f32",
+}
 GFLOP_PER_IMAGE = 220.77  # DD3D-DLA34 KITTI 384x1280, 2 x 110.384 GMAC
 
 
@@ -53,8 +63,10 @@ def parse_args():
                     help="PipelinedForward: streams the slots' trunks are issued on (> 1 lets consecutive steps share the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=200, help="upper bound; the CPU leg stops after ~12 s of work")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_tower_hbm_bytes.json"),
-                    help="optional PMC-derived HBM bytes per launch of the dominant kernel (see profiles/README.md)")
+    ap.add_argument("--math", default=None, help="arithmetic of the convolutions: f16x2 (default) | bf16x3 | f32 | bf16x2 | bf16 (dd3d_amd.engine.default_math)")
+    ap.add_argument("--repeat-blocks", type=int, default=5, help="extra timed blocks of --steps steps each (median / min / max reported in `blocks`)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_tower_hbm_bytes.json"),
+                    help="PMC-derived HBM bytes per launch of the dominant kernel, keyed by kernel signature (see profiles/README.md)")
     return ap.parse_args()
 
 
@@ -96,6 +108,7 @@ def main():
     model = build_model(cfg)
     sd = make_state_dict(model, calib=load_calib("dla34_kitti"))
     model.load_state_dict(sd)
+    model.math = args.math
     B = args.batch
     inputs = make_inputs(B, args.height, args.width, seed=1000 + rank * B)
     pipeline_error = None
@@ -137,6 +150,24 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    # the same timed block repeated (not `value`): spread of box / clock state within one run
+    block_ms = [ms_per_step]
+    for _ in range(max(0, args.repeat_blocks)):
+        barrier()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            runner.step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        eb = time.perf_counter() - tb
+        if world > 1:
+            t = torch.tensor([eb], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            eb = float(t.item())
+        block_ms.append(eb / args.steps * 1e3)
+
     # for transparency: the same forward issued strictly one step at a time on one stream (not part of the timed region)
     serial_ms = None
     if world == 1 and args.pipeline > 0:
@@ -152,22 +183,23 @@ def main():
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - t1) / 50 * 1e3
 
-    x3 = plan.math == hip.MATH_BF16X3
-    # "f32x3bf16": every f32 operand split exactly into 3 bf16 terms, 6 cross products on the bf16 matrix pipe, f32
-    # accumulation -- agrees with the f32-MFMA path to f32 rounding level (tests/test_conv_gpu.py); stem / N<=32 convs are f32 MFMA
-    dtype = "f32 (f32x3bf16 split-operand MFMA, f32 accumulate)" if x3 else "f32"
-    peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    for pl in ([sl.plan for sl in runner.slots] if hasattr(runner, "slots") else [plan]):
+        pl.check_status()  # a half-range overflow of the f16x2 arithmetic would invalidate the run: fail loudly
+    from dd3d_amd.engine import MATH_NAMES, kernel_signature
+    math_name = next(k for k, v in MATH_NAMES.items() if v == plan.math)
+    peak = PEAK_F32_MFMA_TFLOPS if math_name == "f32" else PEAK_BF16_MFMA_TFLOPS / PRODUCTS[math_name]
+    srt = sorted(block_ms)
     out = {
         "metric": "images/sec (384x1280) DD3D-DLA34 fwd", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPES[math_name], "data": "synthetic",
         "config": {
             "workload": f"DD3D-DLA34 KITTI3D {args.height}x{args.width} bs={B}/GPU fp32 inference (BASELINE.json configs[1]); "
                         "uint8 image in HBM -> normalise/pad -> DLA-34 -> FPN P3-P7 -> FCOS2D/3D heads -> select/decode -> NMS",
             "global_batch": world * B, "parallelism": f"dp{world}" + ("+rccl_allgather_candidates" if world > 1 else ""),
             "hip_graph": not args.no_graph, "pipeline_slots": args.pipeline, "compute_streams": args.compute_streams if args.pipeline else 1, "gflop_per_image": GFLOP_PER_IMAGE,
             "achieved_tflops_per_gpu": round(value / world * GFLOP_PER_IMAGE / 1e3, 2),
-            "math": "bf16x3" if x3 else "f32",
+            "math": math_name, "split_planes": bool(plan.use_planes),
             "issue": (f"{args.pipeline} plan slots on {min(args.compute_streams, args.pipeline)} compute streams + 1 exchange/NMS stream "
                       "(dd3d_amd.parallel.PipelinedForward): several single-image steps in flight share the chip; every step does all "
                       "of its work and all K steps are complete at the closing synchronize") if args.pipeline else "one step at a time",
@@ -176,6 +208,10 @@ def main():
             "images_per_s_one_at_a_time": None if serial_ms is None else round(B / serial_ms * 1e3, 2),
             "frac_of_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4),
         },
+        "blocks": {"n": len(block_ms), "steps_each": args.steps, "ms_per_step": [round(x, 4) for x in block_ms],
+                   "median_ms_per_step": round(srt[len(srt) // 2], 4), "min_ms_per_step": round(srt[0], 4), "max_ms_per_step": round(srt[-1], 4),
+                   "median_images_per_s": round(world * B / srt[len(srt) // 2] * 1e3, 2),
+                   "note": "block 0 is the timed region `value` comes from; the others repeat it"},
     }
 
     if rank == 0:
@@ -184,19 +220,28 @@ def main():
         us = sum(kernel_time_us(plan, op) for op in towers) / len(towers)
         flops = 2.0 * towers[0].macs  # algorithmic: 2 * (sum over levels of B*H*W) * 3 towers * 256 * (9*256)
         achieved = flops / (us * 1e-6) / 1e12
-        traffic = None
+        kname = kernel_signature(towers[0])
+        # HBM bytes of one launch from the PMC passes of this kernel (profiles/README.md); only when the record is for THIS instantiation
+        traffic, traffic_src = None, None
         if os.path.exists(args.traffic_json):
             try:
-                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch_" + ("bf16x3" if x3 else "f32"))
+                rec = json.load(open(args.traffic_json)).get(kname)
+                if rec is not None:
+                    traffic, traffic_src = rec["hbm_bytes_per_launch"], f"{os.path.relpath(args.traffic_json, ROOT)} ({rec.get('collected', '')})"
             except Exception:
                 traffic = None
-        kname = ("dd3d::conv_igemm_bf16x3_kernel<2,2,4,2,2,2,1,false>" if x3 else "dd3d::conv_igemm_f32_kernel<2,2,2,2,false,0,false>")
+        np_ = hip.MATH_PLANES[plan.math]
+        m_rows = towers[0].info["M"]
+        alg_bytes = (m_rows * 256 * 2 * np_ * 2 + 3 * 2304 * 256 * 2 * np_) if plan.use_planes else None  # planes in + planes out + split filters
         out["roofline"] = {
             "kernel": kname + " (head towers, 15 segments / launch)", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "peak_basis": ("2500 TFLOP/s dense bf16 MFMA / 6 products per f32 product (f32-equivalent); for reference the f32-input "
-                           "MFMA peak is 157.3") if x3 else "157.3 TFLOP/s dense f32-input MFMA",
-            "traffic": traffic, "flops_per_launch": flops, "avg_launch_us": round(us, 2), "tile": list(towers[0].info["tile"]),
+            "peak_basis": ("157.3 TFLOP/s dense f32-input MFMA" if math_name == "f32" else
+                           f"2500 TFLOP/s dense 16-bit MFMA / {PRODUCTS[math_name]} matrix products per f32 product ({math_name}); f32-equivalent FLOP/s. "
+                           "For reference the f32-input MFMA peak is 157.3"),
+            "executed_16bit_mfma_tflops": None if math_name == "f32" else round(achieved * PRODUCTS[math_name], 1),
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+            "flops_per_launch": flops, "avg_launch_us": round(us, 2), "tile": list(towers[0].info["tile"]),
             "blocks": towers[0].info["blocks"],
         }
         if not args.no_cpu_baseline and world == 1:

@@ -33,6 +33,8 @@ struct ConvKArgs {
   // starts its first data loads without the tiles[] -> segs[] -> pointer chain of dependent scalar loads.
   int single;
   int in_relu;  // bf16x3 kernel with f32 input: rectify the input while it is split (conv(relu(x)) without a rectified copy of x)
+  float out_plane_scale;  // F16X2: split-plane outputs hold value * this (power of two)
+  int* status;            // OR-ed with DD3D_STATUS_* bits, or null
   dd3d_conv_seg seg0;
 };
 
@@ -40,9 +42,13 @@ struct ConvKArgs {
 //   X3: x = hi + mid + lo, three bf16 terms by truncation (exact, 24 bits); six cross products  -> f32-equivalent
 //   X2: x ~ hi + lo, two bf16 terms by round-to-nearest (~17 bits); three cross products
 //   X1: x ~ bf16(x) round-to-nearest; one product (plain bf16 inference)
+//   F16X2: x * S = hi + lo, two IEEE half terms by round-to-nearest (22+ bits: f32-equivalent inside the half range); three products
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int MODE>
 struct Planes {
-  static constexpr int NP = MODE == DD3D_MATH_BF16X3 ? 3 : (MODE == DD3D_MATH_BF16X2 ? 2 : 1);
+  static constexpr int NP = MODE == DD3D_MATH_BF16X3 ? 3 : ((MODE == DD3D_MATH_BF16X2 || MODE == DD3D_MATH_F16X2) ? 2 : 1);
+  static constexpr bool F16 = MODE == DD3D_MATH_F16X2;
 };
 
 // Global-address-space views: the segment descriptor is loaded from memory, so without these casts the compiler
@@ -145,7 +151,13 @@ __device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc
 // two values as one dword (lo_elem in bits 0-15: the element with the lower channel index).
 template <int MODE>
 __device__ __forceinline__ void split_pack(float x0, float x1, unsigned (&w)[Planes<MODE>::NP]) {
-  if constexpr (MODE == DD3D_MATH_BF16X3) {  // exact, by truncation (the same split the f32-input kernel applies on the fly)
+  if constexpr (MODE == DD3D_MATH_F16X2) {  // (the caller has applied the plane scale)
+    const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(f32x2{x0 - hf[0], x1 - hf[1]}, f16x2);
+    w[0] = __builtin_bit_cast(unsigned, h);
+    w[1] = __builtin_bit_cast(unsigned, l);
+  } else if constexpr (MODE == DD3D_MATH_BF16X3) {  // exact, by truncation (the same split the f32-input kernel applies on the fly)
     const unsigned h0 = __float_as_uint(x0) & 0xffff0000u, h1 = __float_as_uint(x1) & 0xffff0000u;
     const float r0 = x0 - __uint_as_float(h0), r1 = x1 - __uint_as_float(h1);
     const unsigned m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
@@ -205,6 +217,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
     const bool w32 = s.out != nullptr, wpl = s.out_planes != nullptr;
     const long cstride = (long)s.M * (NP * 64);  // bytes per 32-channel chunk image of the output
     const int odd = lane & 1;
+    const float pscale = a.out_plane_scale;
+    int ovf = 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nb = n0 + (wn * TN + j) * 32;  // wave-uniform: first channel of this column block
@@ -246,7 +260,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
             const float own = odd ? v[rb] : v[ra];
             const int m = mb + (odd ? (rb & 3) + 8 * (rb >> 2) : (ra & 3) + 8 * (ra >> 2));
             unsigned w[NP];
-            split_pack<MODE>(odd ? recv : own, odd ? own : recv, w);
+            float e0 = odd ? recv : own, e1 = odd ? own : recv;
+            if constexpr (Planes<MODE>::F16) {
+              e0 *= pscale, e1 *= pscale;
+              ovf |= !(fabsf(e0) <= 65504.f) | !(fabsf(e1) <= 65504.f);
+            }
+            split_pack<MODE>(e0, e1, w);
             if (m < s.M) {
               const gbp dst = pl_base + (long)m * (NP * 64);
 #pragma unroll
@@ -255,6 +274,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
           }
         }
       }
+    }
+    if constexpr (Planes<MODE>::F16) {
+      if (ovf && a.status) atomicOr(a.status, DD3D_STATUS_F16_OVERFLOW);  // (NaN / inf inputs trip it as well)
     }
   }
 }

@@ -839,7 +839,7 @@ static int launch_cfg(const ConvKArgs& ka, bool smallc, hipStream_t st) {
 }  // namespace dd3d
 
 extern "C" int dd3d_math_planes(int32_t math_mode) {
-  return math_mode == DD3D_MATH_BF16X3 ? 3 : (math_mode == DD3D_MATH_BF16X2 ? 2 : (math_mode == DD3D_MATH_BF16 ? 1 : 0));
+  return math_mode == DD3D_MATH_BF16X3 ? 3 : ((math_mode == DD3D_MATH_BF16X2 || math_mode == DD3D_MATH_F16X2) ? 2 : (math_mode == DD3D_MATH_BF16 ? 1 : 0));
 }
 
 extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) {
@@ -888,7 +888,9 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.kt_per_split = ceil_div(nk, L->splitk);
   const bool smallc = L->Cin < 32;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  DD3D_REQUIRE(L->math_mode >= DD3D_MATH_F32 && L->math_mode <= DD3D_MATH_BF16, "dd3d_conv2d_igemm_f32: unknown math mode %d", L->math_mode);
+  DD3D_REQUIRE(L->math_mode >= DD3D_MATH_F32 && L->math_mode <= DD3D_MATH_F16X2, "dd3d_conv2d_igemm_f32: unknown math mode %d", L->math_mode);
+  ka.out_plane_scale = L->out_plane_scale > 0.f ? L->out_plane_scale : 1.f;
+  ka.status = L->status;
   if (L->in_planes) {
     DD3D_REQUIRE(L->math_mode != DD3D_MATH_F32 && !smallc && L->zero_page && !L->in_relu,
                  "dd3d_conv2d_igemm_f32: split-plane input needs a split-operand math mode, Cin %% 32 == 0, a zero page and no in_relu");

@@ -188,7 +188,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][i][PA_[t]], fb[c][j][PB_[t]], acc[i][j], 0, 0, 0);
+          if constexpr (Planes<MODE>::F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[c][i][PA_[t]]), __builtin_bit_cast(f16x8, fb[c][j][PB_[t]]),
+                                                               acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][i][PA_[t]], fb[c][j][PB_[t]], acc[i][j], 0, 0, 0);
   };
   constexpr std::integral_constant<int, 0> C0{};
   constexpr std::integral_constant<int, 1> C1{};
@@ -278,6 +282,7 @@ int launch_conv_planes(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStre
     case DD3D_MATH_BF16X3: return launch_planes_mode<DD3D_MATH_BF16X3>(ka, tile_cfg, st);
     case DD3D_MATH_BF16X2: return launch_planes_mode<DD3D_MATH_BF16X2>(ka, tile_cfg, st);
     case DD3D_MATH_BF16: return launch_planes_mode<DD3D_MATH_BF16>(ka, tile_cfg, st);
+    case DD3D_MATH_F16X2: return launch_planes_mode<DD3D_MATH_F16X2>(ka, tile_cfg, st);
   }
   DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: math mode %d has no split-plane kernel", math_mode);
 }
@@ -291,7 +296,7 @@ namespace dd3d {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, int M, int C8, int in_pitch,
-                                                           int relu) {
+                                                           int relu, float pscale, int* status) {
   constexpr int NP = Planes<MODE>::NP;
   const long total = (long)M * C8;
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -302,6 +307,15 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) x0[e] = fmaxf(x0[e], 0.f), x1[e] = fmaxf(x1[e], 0.f);
+    }
+    if constexpr (Planes<MODE>::F16) {
+      int ovf = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x0[e] *= pscale, x1[e] *= pscale;
+        ovf |= !(fabsf(x0[e]) <= 65504.f) | !(fabsf(x1[e]) <= 65504.f);
+      }
+      if (ovf && status) atomicOr(status, DD3D_STATUS_F16_OVERFLOW);
     }
     unsigned w[4][NP];
     split_pack<MODE>(x0[0], x0[1], w[0]);
@@ -319,7 +333,8 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 
 }  // namespace dd3d
 
-extern "C" int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t C, int32_t in_pitch, int32_t math_mode, int32_t relu, void* stream) {
+extern "C" int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t C, int32_t in_pitch, int32_t math_mode, int32_t relu, float plane_scale,
+                                 int32_t* status, void* stream) {
   using namespace dd3d;
   DD3D_REQUIRE(in && out && M > 0 && C > 0 && C % 32 == 0 && in_pitch >= C && in_pitch % 4 == 0, "dd3d_split_planes: bad shape (M=%d C=%d pitch=%d)", M,
                C, in_pitch);
@@ -327,11 +342,129 @@ extern "C" int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t 
   const long total = (long)M * (C / 8);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   unsigned char* o = reinterpret_cast<unsigned char*>(out);
+  const float ps = plane_scale > 0.f ? plane_scale : 1.f;
   switch (math_mode) {
-    case DD3D_MATH_BF16X3: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16X3>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu); break;
-    case DD3D_MATH_BF16X2: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16X2>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu); break;
-    case DD3D_MATH_BF16: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu); break;
+    case DD3D_MATH_BF16X3: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16X3>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu, ps, status); break;
+    case DD3D_MATH_BF16X2: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16X2>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu, ps, status); break;
+    case DD3D_MATH_BF16: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_BF16>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu, ps, status); break;
+    case DD3D_MATH_F16X2: hipLaunchKernelGGL(split_planes_kernel<DD3D_MATH_F16X2>, dim3(blocks), dim3(256), 0, st, in, o, M, C / 8, in_pitch, relu, ps, status); break;
     default: DD3D_REQUIRE(false, "dd3d_split_planes: math mode %d has no planes", math_mode);
   }
   return check_launch("split_planes kernel");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pooling / FPN top-down kernels that also write the split planes of their result (one launch instead of kernel + dd3d_split_planes).
+namespace dd3d {
+
+template <int MODE>
+__device__ __forceinline__ void store_planes8(unsigned char* out_planes, long M, long m, int c8, f32x4 x0, f32x4 x1, float pscale, int* status) {
+  constexpr int NP = Planes<MODE>::NP;
+  if constexpr (Planes<MODE>::F16) {
+    int ovf = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x0[e] *= pscale, x1[e] *= pscale;
+      ovf |= !(fabsf(x0[e]) <= 65504.f) | !(fabsf(x1[e]) <= 65504.f);
+    }
+    if (ovf && status) atomicOr(status, DD3D_STATUS_F16_OVERFLOW);
+  }
+  unsigned w[4][NP];
+  split_pack<MODE>(x0[0], x0[1], w[0]);
+  split_pack<MODE>(x0[2], x0[3], w[1]);
+  split_pack<MODE>(x1[0], x1[1], w[2]);
+  split_pack<MODE>(x1[2], x1[3], w[3]);
+  unsigned char* dst = out_planes + ((long)(c8 >> 2) * M + m) * (NP * 64) + (c8 & 3) * 16;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(dst + p * 64) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void maxpool2x2_planes_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned char* __restrict__ out_planes,
+                                                                int B, int H, int W, int C8, int in_pitch, int out_pitch, float pscale, int* status) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long M = (long)B * Ho * Wo, total = M * C8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long m = t / C8;
+    const int c8 = (int)(t - m * C8);
+    const int wo = (int)(m % Wo);
+    const long r = m / Wo;
+    const int ho = (int)(r % Ho), b = (int)(r / Ho);
+    const float* p = in + (((long)b * H + 2 * ho) * W + 2 * wo) * in_pitch + c8 * 8;
+    f32x4 o[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 v00 = *reinterpret_cast<const f32x4*>(p + 4 * h), v01 = *reinterpret_cast<const f32x4*>(p + in_pitch + 4 * h);
+      const f32x4 v10 = *reinterpret_cast<const f32x4*>(p + (long)W * in_pitch + 4 * h), v11 = *reinterpret_cast<const f32x4*>(p + (long)W * in_pitch + in_pitch + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[h][e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+    }
+    if (out) {
+      float* q = out + m * out_pitch + c8 * 8;
+      *reinterpret_cast<f32x4*>(q) = o[0];
+      *reinterpret_cast<f32x4*>(q + 4) = o[1];
+    }
+    store_planes8<MODE>(out_planes, M, m, c8, o[0], o[1], pscale, status);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void upsample2x_add_planes_kernel(float* __restrict__ fine, const float* __restrict__ coarse, unsigned char* __restrict__ fine_planes,
+                                                                    int B, int H, int W, int C8, int fine_pitch, int coarse_pitch, float pscale, int* status) {
+  const int Hc = H >> 1, Wc = W >> 1;
+  const long M = (long)B * H * W, total = M * C8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const long m = t / C8;
+    const int c8 = (int)(t - m * C8);
+    const int x = (int)(m % W);
+    const long r = m / W;
+    const int y = (int)(r % H), b = (int)(r / H);
+    float* f = fine + m * fine_pitch + c8 * 8;
+    const float* q = coarse + (((long)b * Hc + (y >> 1)) * Wc + (x >> 1)) * coarse_pitch + c8 * 8;
+    const f32x4 o0 = *reinterpret_cast<const f32x4*>(f) + *reinterpret_cast<const f32x4*>(q);
+    const f32x4 o1 = *reinterpret_cast<const f32x4*>(f + 4) + *reinterpret_cast<const f32x4*>(q + 4);
+    *reinterpret_cast<f32x4*>(f) = o0;
+    *reinterpret_cast<f32x4*>(f + 4) = o1;
+    store_planes8<MODE>(fine_planes, M, m, c8, o0, o1, pscale, status);
+  }
+}
+
+}  // namespace dd3d
+
+#define DD3D_PLANE_MODE_SWITCH(KERNEL, ...)                                                                                          \
+  switch (math_mode) {                                                                                                               \
+    case DD3D_MATH_BF16X3: hipLaunchKernelGGL(KERNEL<DD3D_MATH_BF16X3>, dim3(blocks), dim3(256), 0, st, __VA_ARGS__); break;         \
+    case DD3D_MATH_BF16X2: hipLaunchKernelGGL(KERNEL<DD3D_MATH_BF16X2>, dim3(blocks), dim3(256), 0, st, __VA_ARGS__); break;         \
+    case DD3D_MATH_BF16: hipLaunchKernelGGL(KERNEL<DD3D_MATH_BF16>, dim3(blocks), dim3(256), 0, st, __VA_ARGS__); break;             \
+    case DD3D_MATH_F16X2: hipLaunchKernelGGL(KERNEL<DD3D_MATH_F16X2>, dim3(blocks), dim3(256), 0, st, __VA_ARGS__); break;           \
+    default: DD3D_REQUIRE(false, "math mode %d has no planes", math_mode);                                                          \
+  }
+
+extern "C" int dd3d_maxpool2x2_planes(const float* in, float* out, void* out_planes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                                      int32_t out_pitch, int32_t math_mode, float plane_scale, int32_t* status, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(in && out_planes && B > 0 && (H % 2) == 0 && (W % 2) == 0 && C > 0 && (C % 32) == 0 && (in_pitch % 4) == 0 && (out_pitch % 4) == 0,
+               "dd3d_maxpool2x2_planes: bad arguments (H=%d W=%d C=%d)", H, W, C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const float ps = plane_scale > 0.f ? plane_scale : 1.f;
+  unsigned char* o = reinterpret_cast<unsigned char*>(out_planes);
+  DD3D_PLANE_MODE_SWITCH(maxpool2x2_planes_kernel, in, out, o, B, H, W, C / 8, in_pitch, out_pitch, ps, status)
+  return check_launch("maxpool2x2_planes kernel");
+}
+
+extern "C" int dd3d_upsample2x_add_planes(float* fine, const float* coarse, void* fine_planes, int32_t B, int32_t H, int32_t W, int32_t C,
+                                          int32_t fine_pitch, int32_t coarse_pitch, int32_t math_mode, float plane_scale, int32_t* status, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(fine && coarse && fine_planes && B > 0 && (H % 2) == 0 && (W % 2) == 0 && C > 0 && (C % 32) == 0 && (fine_pitch % 4) == 0 &&
+                   (coarse_pitch % 4) == 0, "dd3d_upsample2x_add_planes: bad arguments (H=%d W=%d C=%d)", H, W, C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * H * W * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const float ps = plane_scale > 0.f ? plane_scale : 1.f;
+  unsigned char* o = reinterpret_cast<unsigned char*>(fine_planes);
+  DD3D_PLANE_MODE_SWITCH(upsample2x_add_planes_kernel, fine, coarse, o, B, H, W, C / 8, fine_pitch, coarse_pitch, ps, status)
+  return check_launch("upsample2x_add_planes kernel");
 }

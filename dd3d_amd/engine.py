@@ -13,6 +13,7 @@ Reference behaviour being reproduced: tridet/modeling/dd3d/core.py:64-164 (DD3D.
 """
 import ctypes as C
 import math
+import os
 
 from collections import OrderedDict
 
@@ -33,8 +34,9 @@ class Buf:
       planes  `.p`  int16 [pitch/32][B*H*W][NP][32]                   -- the split-plane form one convolution hands to the next
                                                                          (include/dd3d_hip.h); NP = 16-bit terms of the math mode
     A dry-run (CPU) plan always carries `.t`: it is the plan emulator's logical tensor, whatever the device storages would be."""
-    def __init__(self, B, H, W, C, device, name="", f32=True, planes=0, dry_run=False):
+    def __init__(self, B, H, W, C, device, name="", f32=True, planes=0, dry_run=False, f16=False, plane_scale=1.0):
         self.B, self.H, self.W, self.pitch, self.name = B, H, W, C, name
+        self.f16, self.plane_scale = bool(f16), float(plane_scale)  # terms are IEEE halves of value * plane_scale (DD3D_MATH_F16X2), else bf16
         self.has_f32, self.np = bool(f32) or not planes, int(planes)
         self.t = torch.zeros((B, H, W, C), dtype=torch.float32, device=device) if (self.has_f32 or dry_run) else None
         self.p = None
@@ -52,7 +54,10 @@ class Buf:
             return self.t[..., c0:c0 + C].permute(0, 3, 1, 2)
         # planes only: the value the planes encode (exact for the three-term split), channels c0 .. c0 + C
         k0, k1 = c0 // 32, (c0 + C + 31) // 32
-        terms = (self.p[k0:k1].to(torch.int32) << 16).view(torch.float32)  # [chunks][BHW][NP][32]
+        if self.f16:
+            terms = self.p[k0:k1].view(torch.float16).float() / self.plane_scale
+        else:
+            terms = (self.p[k0:k1].to(torch.int32) << 16).view(torch.float32)  # [chunks][BHW][NP][32]
         x = terms[:, :, 0]
         for q in range(1, self.np):
             x = x + terms[:, :, q]
@@ -168,6 +173,8 @@ def split_planes_host(wp, math):
     if math == hip.MATH_BF16X3:
         return split_bf16x3(wp)
     x = wp.detach().float().cpu().contiguous()
+    if math == hip.MATH_F16X2:
+        raise ValueError("the half-term split carries a per-row scale: use split_f16x2_host")
     hi = x.to(torch.bfloat16)
     terms = [hi]
     if math == hip.MATH_BF16X2:
@@ -175,6 +182,23 @@ def split_planes_host(wp, math):
     Npad, Kpad = x.shape
     planes = torch.stack([t.view(torch.int16) for t in terms], 0)
     return planes.view(len(terms), Npad, Kpad // 32, 32).permute(1, 2, 0, 3).contiguous()
+
+
+def split_f16x2_host(wp):
+    """Wp[Npad][Kpad] f32 -> ([Npad][Kpad/32][2][32] IEEE-half terms of Wp[n] * s[n], s[Npad]): hi = half(x s), lo = half(x s - hi), both
+    round-to-nearest (csrc/conv_common.h::split_pack).  s[n] is the power of two that brings the largest |Wp[n, :]| into [2^13, 2^14):
+    hi then carries 11 bits and lo the next 11 wherever |x s| >= 2^-2, and the absolute floor 2^-25 / s[n] sits ~2^-39 below the row's
+    largest filter tap.  The caller divides s[n] (exactly) out of the epilogue scale."""
+    x = wp.detach().float().cpu().contiguous()
+    amax = x.abs().amax(1)
+    e = torch.floor(torch.log2(amax.clamp(min=1e-30)))
+    s = torch.where(amax > 0, torch.exp2(13.0 - e), torch.ones_like(amax))
+    y = x * s[:, None]
+    hi = y.to(torch.float16)
+    lo = (y - hi.float()).to(torch.float16)
+    Npad, Kpad = x.shape
+    planes = torch.stack([hi.view(torch.int16), lo.view(torch.int16)], 0)
+    return planes.view(2, Npad, Kpad // 32, 32).permute(1, 2, 0, 3).contiguous(), s
 
 
 def pack_smallc_bf16x3(weights, cin_p):
@@ -227,21 +251,41 @@ MATH_TILES = {  # tile configurations instantiated per arithmetic mode
 # the split-plane kernel (csrc/conv_planes.hip): one barrier per K-tile for every tile, so no "two K-tiles per barrier" variants
 PLANE_TILES = (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4, hip.TILE_128x64_W4)
 PLANE_TILE_ALIAS = {hip.TILE_128x64_K2: hip.TILE_128x64, hip.TILE_64x128_K2: hip.TILE_64x128, hip.TILE_64x64_W4K2: hip.TILE_64x64_W4}
-for _m in (hip.MATH_BF16X2, hip.MATH_BF16):
+for _m in (hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2):
     MATH_TILES[_m] = PLANE_TILES
 # blocks of a configuration that can share a CU (LDS-limited); the f32 kernels were measured, see profiles/
 BLOCKS_PER_CU = {hip.TILE_128x128_W4: 2, hip.TILE_64x64_W4: 2, hip.TILE_128x64_W4: 2}  # tiles the split-bf16 kernel is instantiated for
 
 
-MATH_NAMES = {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3, "bf16x2": hip.MATH_BF16X2, "bf16": hip.MATH_BF16}
+MATH_NAMES = {"f32": hip.MATH_F32, "bf16x3": hip.MATH_BF16X3, "bf16x2": hip.MATH_BF16X2, "bf16": hip.MATH_BF16, "f16x2": hip.MATH_F16X2}
 
 
 def default_math():
-    """Arithmetic of the Cin % 32 == 0 convolutions: "bf16x3" (default; f32-equivalent split-operand products on the bf16 matrix
-    pipe), "f32" (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), or the reduced modes BASELINE.json's bf16 configurations name:
-    "bf16x2" (two bf16 terms, three products) and "bf16" (plain bf16 operands); all accumulate in f32.  Env DD3D_MATH or model.math."""
-    import os
-    return MATH_NAMES[os.environ.get("DD3D_MATH", "bf16x3")]
+    """Arithmetic of the Cin % 32 == 0 convolutions (all accumulate in f32).  Env DD3D_MATH or model.math.
+      f32-equivalent (measured against a float64 convolution they sit at the same ~3e-7 as exact f32, tests/test_conv_planes_gpu.py):
+        "f16x2"  (default) two IEEE-half terms per operand, 3 cross products on the f16 matrix pipe; needs |activation| <= 65504 /
+                 plane scale -- a kernel-side status word trips otherwise and the forward raises / falls back to "bf16x3"
+        "bf16x3" three bf16 terms, 6 cross products; the full f32 exponent range
+        "f32"    v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (1/16 of the bf16 rate)
+      reduced (what BASELINE.json's bf16 configurations name):
+        "bf16x2" two bf16 terms, 3 products (~1e-5 relative);  "bf16" plain bf16 operands (~1e-2: misses the 1e-3 parity bar)"""
+    return MATH_NAMES[os.environ.get("DD3D_MATH", "f16x2")]
+
+
+def kernel_signature(op):
+    """Name of the kernel instantiation a ConvOp launches, as rocprofv3 prints it (bench.py / profiles bookkeeping)."""
+    cfg = op.L.tile_cfg
+    tm_tn_wm_wn = {hip.TILE_256x128: (2, 2, 4, 2), hip.TILE_128x128: (2, 1, 2, 4), hip.TILE_128x64: (1, 1, 4, 2), hip.TILE_64x128: (1, 1, 2, 4),
+                   hip.TILE_128x128_W4: (2, 2, 2, 2), hip.TILE_64x64_W4: (1, 1, 2, 2), hip.TILE_128x64_W4: (2, 1, 2, 2)}
+    sk = "true" if op.L.splitk > 1 else "false"
+    if op.in_planes:
+        tm, tn, wm, wn = tm_tn_wm_wn[PLANE_TILE_ALIAS.get(cfg, cfg)]
+        stage = hip.MATH_PLANES[op.math] * (tm * 32 * wm + tn * 32 * wn) * 64
+        ns = max(2, min(4, ((144 if wm * wn == 8 else 72) * 1024) // stage))
+        return f"dd3d::conv_igemm_planes_kernel<{tm}, {tn}, {wm}, {wn}, {ns}, {op.math}, {sk}>"
+    if op.math == hip.MATH_BF16X3:
+        return f"dd3d::conv_igemm_bf16x3_kernel ({hip.TILE_NAMES[cfg]}, split-K {sk})"
+    return f"dd3d::conv_igemm_f32[_dma]_kernel ({hip.TILE_NAMES[cfg]}, split-K {sk})"
 
 
 def tile_key(m_list, N, Kpad, stride):
@@ -258,8 +302,9 @@ def _load_tile_table(math_name):
 
 
 TILE_TABLE = {hip.MATH_F32: _load_tile_table("f32"), hip.MATH_BF16X3: _load_tile_table("bf16x3"), hip.MATH_BF16X2: _load_tile_table("bf16x2"),
-              hip.MATH_BF16: _load_tile_table("bf16")}
-PLANE_TILE_TABLE = {m: _load_tile_table(n + "_planes") for n, m in (("bf16x3", hip.MATH_BF16X3), ("bf16x2", hip.MATH_BF16X2), ("bf16", hip.MATH_BF16))}
+              hip.MATH_BF16: _load_tile_table("bf16"), hip.MATH_F16X2: {}}
+PLANE_TILE_TABLE = {m: _load_tile_table(n + "_planes") for n, m in (("bf16x3", hip.MATH_BF16X3), ("bf16x2", hip.MATH_BF16X2), ("bf16", hip.MATH_BF16),
+                                                                     ("f16x2", hip.MATH_F16X2))}
 
 
 def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
@@ -299,8 +344,8 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
                 cost /= {hip.TILE_256x128: 2.4, hip.TILE_128x128: 1.8, hip.TILE_128x64: 1.3, hip.TILE_64x128: 1.3,
                          hip.TILE_128x128_W4: 1.0, hip.TILE_64x64_W4: 0.6, hip.TILE_128x64_W4: 0.8,
                          hip.TILE_128x64_K2: 1.0, hip.TILE_64x128_K2: 1.0, hip.TILE_64x64_W4K2: 0.5}[cfg]  # rough; the table decides
-                if math in (hip.MATH_BF16X2, hip.MATH_BF16):  # fewer products per K-tile: the matrix term shrinks, the rest does not
-                    cost *= {hip.MATH_BF16X2: 0.6, hip.MATH_BF16: 0.35}[math]
+                if math in (hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2):  # fewer products per K-tile: the matrix term shrinks, the rest does not
+                    cost *= {hip.MATH_BF16X2: 0.6, hip.MATH_F16X2: 0.6, hip.MATH_BF16: 0.35}[math]
             if sk > 1:
                 # second launch (~2 us) + partial-sum round trip (sk*M*N*8 B at ~3 TB/s), in per-CU MAC units
                 # (one CU retires 157.3e12 / 2 / 256 = 3.07e11 MAC/s)
@@ -323,7 +368,7 @@ class ConvOp:
         in_planes = math != hip.MATH_F32 and meta["Cin"] % 32 == 0 and all(s["in"].np == hip.MATH_PLANES[math] for s in segs) and not in_relu
         if meta["Cin"] % 32 or (meta["N"] <= 32 and not in_planes):  # stem layers (Cin 4 / 16) and narrow convs on f32 input: the f32 kernel
             math = hip.MATH_F32
-        if math in (hip.MATH_BF16X2, hip.MATH_BF16) and not in_planes:
+        if math in (hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2) and not in_planes:
             raise ValueError(f"conv {name}: math mode {math} reads split-plane input only; its input buffer has none")
         self.math, self.in_planes = math, in_planes
         cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math, planes=in_planes)
@@ -348,6 +393,10 @@ class ConvOp:
             a = arr[i]
             w = s["w"] if math == hip.MATH_F32 else plan.split_weight(s["w"], math)
             a["w"] = w.data_ptr()
+            scale_vec = s["scale"]
+            if math == hip.MATH_F16X2:  # acc = (S_in x) . (s[n] w): the power-of-two scales leave through the epilogue scale, exactly
+                scale_vec = plan.descaled(s["scale"], s["w"], vin.buf.plane_scale)
+                self.keep.append(scale_vec)
             if in_planes:
                 a["in_planes"] = vin.pptr
             else:
@@ -363,7 +412,7 @@ class ConvOp:
             a["out"] = vout.ptr if wf else 0
             a["out_planes"] = vout.pptr if wp else 0
             self.out_forms.append((wf, wp))
-            a["scale"], a["bias"] = s["scale"].data_ptr(), s["bias"].data_ptr()
+            a["scale"], a["bias"] = scale_vec.data_ptr(), s["bias"].data_ptr()
             a["lo"] = s["lo"].data_ptr() if s.get("lo") is not None else 0
             a["B"], a["H"], a["W"], a["Ho"], a["Wo"] = vin.B, vin.H, vin.W, Ho, Wo
             a["in_pitch"], a["out_pitch"] = vin.pitch, vout.pitch
@@ -401,6 +450,8 @@ class ConvOp:
         assert not in_relu or math == hip.MATH_BF16X3
         L.in_relu = int(in_relu)
         L.in_planes = int(in_planes)
+        L.out_plane_scale = float(plan.act_scale)
+        L.status = plan.status.data_ptr() if plan.status is not None else None
         self.L = L
         # algorithmic MACs: every segment counts the channels it stores
         self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs)) * meta["KH"] * meta["KW"] * meta["Cin"]
@@ -457,6 +508,13 @@ class PlanBase:
         self.zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)  # padded-tap source of the DMA conv
         self.math = default_math()
         self._split = {}
+        self._descaled = {}
+        import math as _math
+        # DD3D_MATH_F16X2: every split-plane activation holds value * act_scale (a power of two; |value| <= 65504 / act_scale or the
+        # status word trips and the forward raises; terms below 2^-24 / act_scale are lost).  DD3D_F16_ACT_SCALE overrides.
+        self.act_scale = float(os.environ.get("DD3D_F16_ACT_SCALE", "16"))
+        assert self.act_scale > 0 and _math.log2(self.act_scale).is_integer(), "DD3D_F16_ACT_SCALE must be a power of two"
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)  # DD3D_STATUS_* bits OR-ed in by the kernels
 
     @property
     def use_planes(self):
@@ -468,12 +526,34 @@ class PlanBase:
             return False
         return self.math != hip.MATH_BF16X3 or os.environ.get("DD3D_PLANES", "1") != "0"
 
+    def check_status(self):
+        """Raise if a kernel flagged a numeric fault (reads one int32 from the device; call after the forward has been waited for)."""
+        st = int(self.status.cpu())
+        if st & hip.STATUS_F16_OVERFLOW:
+            self.status.zero_()
+            raise FloatingPointError(
+                f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}, or a "
+                "NaN / inf): lower DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
+
     def split_weight(self, wp, math=hip.MATH_BF16X3):
         """16-bit term planes of a packed filter, built once per filter and mode (the towers share theirs over 5 levels)."""
         key = (wp.data_ptr(), math)
         if key not in self._split:
-            self._split[key] = (wp, split_planes_host(wp, math).to(self.device))
+            if math == hip.MATH_F16X2:
+                planes, row_scale = split_f16x2_host(wp)
+                self._split[key] = (wp, planes.to(self.device), row_scale)
+            else:
+                self._split[key] = (wp, split_planes_host(wp, math).to(self.device), None)
         return self._split[key][1]
+
+    def descaled(self, scale, wp, in_scale):
+        """Epilogue scale of a DD3D_MATH_F16X2 convolution: scale[n] / (in_scale * row_scale[n]), all powers of two (exact)."""
+        key = (scale.data_ptr(), wp.data_ptr(), float(in_scale))
+        if key not in self._descaled:
+            row_scale = self._split[(wp.data_ptr(), hip.MATH_F16X2)][2]
+            n = scale.numel()
+            self._descaled[key] = (scale, (scale.detach().float().cpu() / (row_scale[:n] * float(in_scale))).to(self.device))
+        return self._descaled[key][1]
 
     # ------------------------------------------------------------------ helpers
     def buf(self, name, B, H, W, Cc, kind="f32"):
@@ -481,7 +561,8 @@ class PlanBase:
         (read by convolutions only), "both".  Without split planes in the plan (f32 math, DD3D_PLANES=0) everything is f32."""
         assert kind in ("f32", "planes", "both"), kind
         planes = hip.MATH_PLANES[self.math] if (self.use_planes and kind != "f32" and Cc % 32 == 0) else 0
-        b = Buf(B, H, W, Cc, self.device, name, f32=(kind != "planes" or not planes), planes=planes, dry_run=self.dry_run)
+        b = Buf(B, H, W, Cc, self.device, name, f32=(kind != "planes" or not planes), planes=planes, dry_run=self.dry_run,
+                f16=self.math == hip.MATH_F16X2, plane_scale=self.act_scale if self.math == hip.MATH_F16X2 else 1.0)
         self.bufs[name] = b
         return b
 
@@ -494,7 +575,8 @@ class PlanBase:
         assert (dst.B, dst.H, dst.W) == (view.B, view.H, view.W)
 
         def _f(lib, st, view=view, dst=dst, M=M):
-            hip.check(lib.dd3d_split_planes(view.ptr, dst.pptr, M, view.C, view.pitch, self.math, int(relu), st), "split_planes " + name)
+            hip.check(lib.dd3d_split_planes(view.ptr, dst.pptr, M, view.C, view.pitch, self.math, int(relu), dst.buf.plane_scale, self.status.data_ptr(),
+                                            st), "split_planes " + name)
 
         self.ops.append(CallOp(_f, name or "split", dict(kind="split_planes", src=view, dst=dst, relu=bool(relu))))
 
@@ -534,6 +616,14 @@ class PlanBase:
 
     def maxpool(self, vin, vout, name="pool"):
         assert vin.C == vout.C and vout.H * 2 == vin.H and vout.W * 2 == vin.W
+        if vout.np and vout.C % 32 == 0:  # pooled map + its split planes in one launch
+
+            def _fp(lib, st, vin=vin, vout=vout):
+                hip.check(lib.dd3d_maxpool2x2_planes(vin.ptr, vout.ptr or None, vout.pptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, self.math,
+                                                     vout.buf.plane_scale, self.status.data_ptr(), st), name)
+
+            self.ops.append(CallOp(_fp, name, dict(kind="maxpool2x2", vin=vin, vout=vout, planes=True)))
+            return
 
         def _f(lib, st, vin=vin, vout=vout):
             hip.check(lib.dd3d_maxpool2x2_nhwc(vin.ptr, vout.ptr, vin.B, vin.H, vin.W, vin.C, vin.pitch, vout.pitch, st), name)
@@ -543,6 +633,14 @@ class PlanBase:
 
     def upsample_add(self, fine, coarse, name="fpn_topdown"):
         assert fine.C == coarse.C and coarse.H * 2 == fine.H and coarse.W * 2 == fine.W
+        if fine.np and fine.C % 32 == 0:  # top-down sum + its split planes in one launch
+
+            def _fp(lib, st, fine=fine, coarse=coarse):
+                hip.check(lib.dd3d_upsample2x_add_planes(fine.ptr, coarse.ptr, fine.pptr, fine.B, fine.H, fine.W, fine.C, fine.pitch, coarse.pitch, self.math,
+                                                         fine.buf.plane_scale, self.status.data_ptr(), st), name)
+
+            self.ops.append(CallOp(_fp, name, dict(kind="upsample2x_add", fine=fine, coarse=coarse, planes=True)))
+            return
 
         def _f(lib, st, fine=fine, coarse=coarse):
             hip.check(

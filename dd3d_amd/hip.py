@@ -14,9 +14,10 @@ _LIB_PATH = os.environ.get("DD3D_HIP_LIB") or os.path.join(os.path.dirname(__fil
 _lib = None
 
 MAX_LEVELS = 8
-MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16 = 0, 1, 2, 3
-MATH_PLANES = {MATH_F32: 0, MATH_BF16X3: 3, MATH_BF16X2: 2, MATH_BF16: 1}  # 16-bit terms per value (dd3d_math_planes)
+MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16, MATH_F16X2 = 0, 1, 2, 3, 4
+MATH_PLANES = {MATH_F32: 0, MATH_BF16X3: 3, MATH_BF16X2: 2, MATH_BF16: 1, MATH_F16X2: 2}  # 16-bit terms per value (dd3d_math_planes)
 ABI_VERSION = 2
+STATUS_F16_OVERFLOW = 1
 CAND_FIELDS = 22
 DET_FIELDS = 32
 
@@ -46,7 +47,7 @@ class ConvLaunch(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("Cin", C.c_int32), ("N", C.c_int32),
         ("Kpad", C.c_int32), ("Npad", C.c_int32), ("relu", C.c_int32), ("splitk", C.c_int32), ("math_mode", C.c_int32),
         ("tile_cfg", C.c_int32), ("zero_page", C.c_void_p), ("tile_counters", C.c_void_p), ("seg0_host", C.c_void_p), ("in_relu", C.c_int32),
-        ("in_planes", C.c_int32)
+        ("in_planes", C.c_int32), ("out_plane_scale", C.c_float), ("status", C.c_void_p)
     ]
 
 
@@ -112,7 +113,7 @@ EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
     "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8",
-    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes"
+    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_upsample2x_add_planes"
 ]
 
 
@@ -161,7 +162,9 @@ def lib():
     L.dd3d_resize_bilinear_u8.argtypes = [C.POINTER(ResizeArgs), C.c_void_p]
     L.dd3d_format_boxes3d.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_void_p]
     L.dd3d_math_planes.argtypes = [C.c_int32]
-    L.dd3d_split_planes.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]
+    L.dd3d_maxpool2x2_planes.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_float, C.c_void_p, C.c_void_p]
+    L.dd3d_upsample2x_add_planes.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_float, C.c_void_p, C.c_void_p]
+    L.dd3d_split_planes.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_float, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the .so is stale
     assert L.dd3d_abi_version() == ABI_VERSION, "libdd3d_hip.so ABI version mismatch; rebuild"

@@ -51,7 +51,9 @@ class DD3D(nn.Module):
         self._plans = {}
         self.max_cached_plans = 8  # launch plans kept per model (one per (batch, padded size, flags)); least recently used goes first
         self.use_graph = True
-        self.math = None  # None: DD3D_MATH / the default ("bf16x3"); or "f32" / "bf16x3" (set before the first forward)
+        # None: DD3D_MATH / the default ("f16x2", falling back to "bf16x3" for good if an activation ever leaves the half range); or one
+        # of "f16x2" / "bf16x3" / "f32" / "bf16x2" / "bf16" (dd3d_amd.engine.default_math), set before the first forward
+        self.math = None
         self.training = False
 
     @property
@@ -160,6 +162,8 @@ class DD3D(nn.Module):
     def collect(self, plan, batched_inputs, image_sizes, first=0):
         """Detection buffer -> List[{"instances": Instances}] with the reference's fields (core.py:153-164)."""
         counts = plan.det_count.cpu()
+        if getattr(plan, "check_status", None) is not None:
+            plan.check_status()  # a numeric fault flagged by a kernel (half-range overflow of the f16x2 mode) fails the forward loudly
         n_max = int(counts.max()) if counts.numel() else 0
         if n_max > plan.det_cap:
             raise RuntimeError(f"{n_max} detections exceed the detection buffer ({plan.det_cap}); raise det_cap")
@@ -199,4 +203,18 @@ class DD3D(nn.Module):
     def forward(self, batched_inputs):
         plan, image_sizes = self.stage_inputs(batched_inputs)
         plan.run()
-        return self.collect(plan, batched_inputs, image_sizes)
+        try:
+            return self.collect(plan, batched_inputs, image_sizes)
+        except FloatingPointError as e:
+            from dd3d_amd import hip
+            if self.math is not None or plan.math != hip.MATH_F16X2:
+                raise  # the mode was asked for explicitly
+            # the default arithmetic met activations outside the half range: this model runs on the three-term bf16 split (same
+            # f32-equivalent products, full f32 exponent range, twice the matrix work) from now on
+            import warnings
+            warnings.warn(f"dd3d_amd: {e}; switching this model to math='bf16x3'")
+            self.math = "bf16x3"
+            self._plans.clear()
+            plan, image_sizes = self.stage_inputs(batched_inputs)
+            plan.run()
+            return self.collect(plan, batched_inputs, image_sizes)

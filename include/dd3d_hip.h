@@ -106,6 +106,8 @@ typedef struct dd3d_conv_launch {  /* host memory */
                       DD3D_MATH_BF16X3 with f32 input only */
   int32_t in_planes; /* 1: every segment reads its split-plane input (seg.in_planes) instead of the f32 one; Cin % 32 == 0 and a
                         split-operand math mode */
+  float out_plane_scale; /* DD3D_MATH_F16X2: the split-plane outputs hold value * out_plane_scale (a power of two; 0 = 1) */
+  int32_t* status;       /* device int32 OR-ed with DD3D_STATUS_* bits by the kernels, or NULL */
 } dd3d_conv_launch;
 
 /* Arithmetic of the implicit GEMM (results agree to f32 rounding level; both accumulate in f32):
@@ -121,6 +123,14 @@ typedef struct dd3d_conv_launch {  /* host memory */
  *   DD3D_MATH_BF16    x ~ bf16(x), one product: plain bf16 operands */
 #define DD3D_MATH_BF16X2 2
 #define DD3D_MATH_BF16 3
+/*   DD3D_MATH_F16X2   x * S = hi + lo, two IEEE half terms by round-to-nearest (2 x 11 significand bits: the pair carries the 24 bits
+ *                     of an f32 wherever lo is a normal half), 3 cross products on v_mfma_f32_32x32x16_f16; the dropped lo*lo term is
+ *                     <= 2^-24 |a*b| like the dropped terms of DD3D_MATH_BF16X3 -> f32-equivalent at HALF its matrix work, inside the
+ *                     half format's exponent range.  S: activations carry the power-of-two `plane_scale` of the launch / of
+ *                     dd3d_split_planes (|x * S| <= 65504 or the status word is set; terms below 2^-24 / S are lost); filters are
+ *                     scaled per output row by the caller, who divides the products of the scales out of `scale[n]`. */
+#define DD3D_MATH_F16X2 4
+#define DD3D_STATUS_F16_OVERFLOW 1 /* bit set in *status when a value left the half range while being split */
 /* planes per value of a math mode (0 for DD3D_MATH_F32) */
 int dd3d_math_planes(int32_t math_mode);
 
@@ -143,8 +153,18 @@ int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);
 
 /* f32 NHWC -> split planes of `math_mode` (the entry into the plane format for tensors a non-convolution kernel produced: pooled
  * maps, the FPN top-down sums, eSE outputs, the stem), optionally rectified (LastLevelP6P7: p7 = conv(relu(p6)) [ext]).
- *   in [M][in_pitch] f32, channels [0, C), C % 32 == 0;  out [C/32][M][NP][32] 16-bit terms */
-int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t C, int32_t in_pitch, int32_t math_mode, int32_t relu, void* stream);
+ *   in [M][in_pitch] f32, channels [0, C), C % 32 == 0;  out [C/32][M][NP][32] 16-bit terms of in * plane_scale (plane_scale: see
+ *   DD3D_MATH_F16X2; ignored by the bf16 modes); status: see dd3d_conv_launch */
+int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t C, int32_t in_pitch, int32_t math_mode, int32_t relu, float plane_scale,
+                      int32_t* status, void* stream);
+
+/* dd3d_maxpool2x2_nhwc / dd3d_upsample2x_add_nhwc that ALSO write the split planes of their result (one launch instead of the kernel
+ * followed by dd3d_split_planes): out_planes / fine_planes = [C/32][pixels][NP][32] terms of `math_mode` (first chunk of the slice),
+ * C % 32 == 0.  dd3d_maxpool2x2_planes: `out` (f32) may be NULL.  plane_scale / status as in dd3d_split_planes. */
+int dd3d_maxpool2x2_planes(const float* in, float* out, void* out_planes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
+                           int32_t out_pitch, int32_t math_mode, float plane_scale, int32_t* status, void* stream);
+int dd3d_upsample2x_add_planes(float* fine, const float* coarse, void* fine_planes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t fine_pitch,
+                               int32_t coarse_pitch, int32_t math_mode, float plane_scale, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small-channel convolution (the full-resolution stem: dla.py:271-280,327-344 base_layer / level0 / level1,

@@ -98,10 +98,14 @@ def _track(forms, name, d):
     elif k in ("maxpool2x2", "maxpool3x3s2_ceil"):
         forms.reads(d["vin"], "f32", name)
         forms.wrote(d["vout"], "f32")
+        if d.get("planes"):
+            forms.wrote(d["vout"], "planes")
     elif k == "upsample2x_add":
         forms.reads(d["fine"], "f32", name)
         forms.reads(d["coarse"], "f32", name)
         forms.wrote(d["fine"], "f32")
+        if d.get("planes"):
+            forms.wrote(d["fine"], "planes")
     elif k == "ese":
         forms.reads(d["x"], "f32", name)
         if d["identity"] is not None:

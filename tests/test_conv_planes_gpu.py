@@ -2,7 +2,8 @@
 f32 -> dd3d_split_planes -> conv reading planes by LDS-DMA -> f32 and / or plane output -> the next conv reading those planes.
 
 Tolerances: the three-term mode (bf16x3) is held to the f32 kernels' tolerance (2e-5 of max |ref|); the reduced modes to what their
-operand width gives (bf16x2: two bf16 terms ~ 2^-17 per operand; bf16: 2^-9), stated per mode below."""
+operand width gives (bf16x2: two bf16 terms ~ 2^-17 per operand; bf16: 2^-9), stated per mode below; the two-half-term mode (f16x2:
+2 x 11 bits inside the half range) is held to the f32 tolerance as well."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -11,7 +12,7 @@ from dd3d_amd import hip
 
 pytestmark = pytest.mark.gpu
 
-MODES = {"bf16x3": (hip.MATH_BF16X3, 2e-5), "bf16x2": (hip.MATH_BF16X2, 1e-4), "bf16": (hip.MATH_BF16, 3e-2)}
+MODES = {"bf16x3": (hip.MATH_BF16X3, 2e-5), "f16x2": (hip.MATH_F16X2, 2e-5), "bf16x2": (hip.MATH_BF16X2, 1e-4), "bf16": (hip.MATH_BF16, 3e-2)}
 
 CASES = [
     # name, B, H, W, Cin, Cout, k, stride, pad, relu, residual, tile, splitk
@@ -91,10 +92,17 @@ def test_planes_conv_matches_torch(hiplib, case, mode):
     # the last chunk are zero); the chunk before the slice is untouched
     np_ = hip.MATH_PLANES[math]
     assert torch.all(yout.p[0] == 0x1234)
-    dec = (yout.p[1:].to(torch.int32) << 16).view(torch.float32).sum(2).permute(1, 0, 2).reshape(B, Ho, Wo, cpad).permute(0, 3, 1, 2).cpu()
+    if math == hip.MATH_F16X2:
+        terms = yout.p[1:].view(torch.float16).float() / yout.plane_scale
+    else:
+        terms = (yout.p[1:].to(torch.int32) << 16).view(torch.float32)
+    dec = terms.sum(2).permute(1, 0, 2).reshape(B, Ho, Wo, cpad).permute(0, 3, 1, 2).cpu()
     assert torch.all(dec[:, Cout:] == 0)
     if math == hip.MATH_BF16X3:
         assert torch.equal(dec[:, :Cout], got)
+    elif math == hip.MATH_F16X2:  # 22 bits, down to the absolute floor 2^-25 / plane scale
+        assert float((dec[:, :Cout] - got).abs().max()) <= 2.0**-21 * float(got.abs().max()) + 2.0**-24 / yout.plane_scale
+        assert int(plan.status.cpu()) == 0
     else:
         step = {2: 2.0**-15, 1: 2.0**-8}[np_]
         assert float(((dec[:, :Cout] - got).abs() / got.abs().clamp(min=1e-20)).max()) <= step
@@ -158,6 +166,13 @@ def test_split_planes_relu_and_slices(hiplib):
         got, gotr = dst.nchw().permute(0, 2, 3, 1).cpu(), dstr.nchw().permute(0, 2, 3, 1).cpu()
         if math == hip.MATH_BF16X3:
             assert torch.equal(got, x) and torch.equal(gotr, F.relu(x))
+        elif math == hip.MATH_F16X2:  # magnitudes 1e-6 .. 1e6 at plane scale 16: the top of the range overflows and is flagged
+            ok = x.abs() * plan.act_scale <= 65504.0
+            err = ((got - x).abs() - 2.0**-24 / plan.act_scale).clamp(min=0) / x.abs()
+            assert float(err[ok].max()) <= 2.0**-22 and int(plan.status.cpu()) == hip.STATUS_F16_OVERFLOW
+            with pytest.raises(FloatingPointError, match="half range"):
+                plan.check_status()
+            assert int(plan.status.cpu()) == 0
         else:
             hi = x.to(torch.bfloat16)
             want = hi.float() + ((x - hi.float()).to(torch.bfloat16).float() if math == hip.MATH_BF16X2 else 0.0)

@@ -53,7 +53,7 @@ def test_eval_forward_raises_like_the_reference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("math", [None, "f32"], ids=["bf16x3", "f32mfma"])
+@pytest.mark.parametrize("math", [None, "bf16x3", "f32"], ids=["f16x2", "bf16x3", "f32mfma"])
 def test_hip_dense_depth_matches_oracle_and_golden(hiplib, math):
     from oracle import dense_depth_oracle as D
     from tests.util import gpu_model, max_abs

@@ -65,8 +65,9 @@ def _check_final(out, ref, exact_ints=True):
     assert float((c_got - c_ref).abs().mean()) <= REL_TOL * max(1.0, float(c_ref.abs().mean()))
 
 
-@pytest.mark.parametrize("H,W,B,math", [(128, 256, 2, None), (128, 256, 2, "f32"), (384, 1280, 1, None), (384, 1280, 1, "f32")],
-                         ids=["small_b2", "small_b2_f32mfma", "kitti_full", "kitti_full_f32mfma"])
+@pytest.mark.parametrize("H,W,B,math", [(128, 256, 2, None), (128, 256, 2, "bf16x3"), (128, 256, 2, "f32"), (384, 1280, 1, None), (384, 1280, 1, "bf16x3"),
+                                        (384, 1280, 1, "f32")],
+                         ids=["small_b2", "small_b2_bf16x3", "small_b2_f32mfma", "kitti_full", "kitti_full_bf16x3", "kitti_full_f32mfma"])
 def test_forward_matches_oracle(hiplib, kitti_dla34, H, W, B, math):
     from dd3d_amd.synthetic import make_inputs
     cfg, _, sd = kitti_dla34

@@ -119,13 +119,13 @@ def test_cabi_exports_match_header(hiplib):
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert getattr(hiplib, name) is not None
-    assert hiplib.dd3d_abi_version() == 1 and hiplib.dd3d_arch() == b"gfx950"
+    assert hiplib.dd3d_abi_version() == hip.ABI_VERSION == 2 and hiplib.dd3d_arch() == b"gfx950"
     import ctypes as C
     bm, bn = C.c_int32(), C.c_int32()
     for cfg_id, shape in hip.TILE_SHAPES.items():
         assert hiplib.dd3d_conv_tile_shape(cfg_id, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == shape
     assert hiplib.dd3d_conv_tile_shape(99, C.byref(bm), C.byref(bn)) < 0 and b"tile_cfg" in hiplib.dd3d_last_error()
-    assert C.sizeof(hip.ConvLaunch) == 112 and hip.CONV_SEG_DTYPE.itemsize == 120
+    assert C.sizeof(hip.ConvLaunch) == 128 and hip.CONV_SEG_DTYPE.itemsize == 120
 
 
 def test_config_surface():

@@ -236,3 +236,31 @@ def test_generic_tree_lowering_reproduces_dla34(hiplib):
     for l in range(5):
         ref = st["features"][l]
         assert float((plan.features[l].nchw() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), l
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "f16x2", "bf16x2", "bf16", "bf16x3-f32in"])
+@pytest.mark.parametrize("name", ["dla34_kitti", "v99_kitti", "dla34_nusc"])
+def test_storage_forms_are_consistent_in_every_math_mode(hiplib, name, math, monkeypatch):
+    """Every arithmetic mode lays its activations out differently (f32 NHWC only; split planes of 3 / 2 / 1 terms next to or instead
+    of f32).  The emulator tracks which storage of which channels each op writes and checks every read against it: a convolution
+    streaming the planes of a tensor only its f32 side was written to would read stale memory on the device."""
+    from dd3d_amd import META_ARCH_REGISTRY
+    from dd3d_amd.engine import ConvOp, ForwardPlan
+    from dd3d_amd.synthetic import make_inputs
+    from tests.util import bundle
+    exp, tag, over, ds, B, H, W = CASES[name]
+    cfg, sd = bundle(exp, tag, over)
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.load_state_dict(sd, strict=True)
+    if math == "bf16x3-f32in":
+        monkeypatch.setenv("DD3D_PLANES", "0")
+        math = "bf16x3"
+    model.math = math
+    div = model.backbone.size_divisibility
+    plan = ForwardPlan(model, B, H + (-H) % div, W + (-W) % div, device="cpu", dry_run=True)
+    model.stage_inputs(make_inputs(B, H, W, dataset=ds), plan=plan)
+    with torch.no_grad():
+        done = emulate(plan)
+    assert "predictors" in done
+    forms = {op.info["in_form"] for op in plan.ops if isinstance(op, ConvOp) and op.L.Cin % 32 == 0}
+    assert forms == ({"planes"} if plan.use_planes else {"f32"}), forms
