@@ -396,7 +396,6 @@ class ConvOp:
             scale_vec = s["scale"]
             if math == hip.MATH_F16X2:  # acc = (S_in x) . (s[n] w): the power-of-two scales leave through the epilogue scale, exactly
                 scale_vec = plan.descaled(s["scale"], s["w"], vin.buf.plane_scale)
-                self.keep.append(scale_vec)
             if in_planes:
                 a["in_planes"] = vin.pptr
             else:
@@ -425,7 +424,7 @@ class ConvOp:
             a["n_limit"] = int(s.get("n_limit", 0))
             assert a["n_limit"] <= meta["N"]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
-            self.keep += [w, s["scale"], s["bias"], s.get("lo")]
+            self.keep += [w, scale_vec, s["bias"], s.get("lo")]  # (what the launch reads; kept alive here)
         self.desc = dict(kind="conv", segs=segs, meta=meta, stride=stride, pad=pad, relu=bool(relu), in_relu=bool(in_relu),
                          in_form="planes" if in_planes else "f32", out_forms=self.out_forms)
         self.segs_host = arr  # kept alive: single-segment launches hand the descriptor over by value (seg0_host)

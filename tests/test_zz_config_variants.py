@@ -104,6 +104,7 @@ def test_predictor_folding_reproduces_the_reference_heads(hiplib, name):
     cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti", VARIANTS.get(name))
     model = META_ARCH_REGISTRY.get("DD3D")(cfg)
     model.load_state_dict(sd, strict=True)
+    model.math = "bf16x3"  # the filter layout decoded below (three bf16 planes); the folding itself does not depend on the arithmetic
     plan = ForwardPlan(model, 1, 128, 256, device="cpu", dry_run=True)
     op = [o for o in plan.ops if isinstance(o, ConvOp) and o.name == "predictors"][0]
     with torch.no_grad():
