@@ -1,4 +1,4 @@
-"""HIP implicit-GEMM conv (through the C ABI) vs a plain PyTorch fp32 reference (F.conv2d on CPU)."""
+"""HIP implicit-GEMM conv, f32 NHWC input kernels (through the C ABI) vs a plain PyTorch fp32 reference (F.conv2d on CPU)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -72,6 +72,7 @@ def test_conv_matches_torch(hiplib, case):
         ref = F.relu(ref)
 
     plan = PlanBase("cuda")
+    plan.math = hip.MATH_BF16X3  # these tests drive the f32-input kernels (f32 MFMA / on-the-fly bf16x3 split); the split-plane path: test_conv_planes_gpu.py
     wp, meta = pack_filter(w, plan.device)
     # input lives in a wider buffer at a channel offset to exercise the pitch addressing
     cin_p = meta["Cin"]
@@ -102,6 +103,7 @@ def test_multi_segment_launch(hiplib):
     """Several levels with their own (scale, bias) in ONE launch == the per-level BatchNorm of the shared towers."""
     from dd3d_amd.engine import ConvOp, PlanBase, pack_filter
     plan = PlanBase("cuda")
+    plan.math = hip.MATH_BF16X3  # these tests drive the f32-input kernels (f32 MFMA / on-the-fly bf16x3 split); the split-plane path: test_conv_planes_gpu.py
     g = torch.Generator().manual_seed(7)
     w = torch.randn(256, 256, 3, 3, generator=g) / 48.0
     wp, meta = pack_filter(w, plan.device)
@@ -126,6 +128,7 @@ def test_aux_kernels(hiplib):
     from dd3d_amd.engine import PlanBase
     import ctypes as C
     plan = PlanBase("cuda")
+    plan.math = hip.MATH_BF16X3  # these tests drive the f32-input kernels (f32 MFMA / on-the-fly bf16x3 split); the split-plane path: test_conv_planes_gpu.py
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 32, 12, 20, generator=g)
     xb, yb = plan.buf("x", 2, 12, 20, 40), plan.buf("y", 2, 6, 10, 36)
@@ -169,6 +172,7 @@ def test_splitk_fixup_sees_fresh_partials(hiplib, math):
     g = torch.Generator().manual_seed(11)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9)**0.5
     plan = PlanBase("cuda")
+    plan.math = hip.MATH_BF16X3  # these tests drive the f32-input kernels (f32 MFMA / on-the-fly bf16x3 split); the split-plane path: test_conv_planes_gpu.py
     wp, meta = pack_filter(w, plan.device)
     xin, yout = plan.buf("x", B, H, W, Cin), plan.buf("y", B, H, W, Cout)
     ones, zeros = torch.ones(Cout, device=plan.device), torch.zeros(Cout, device=plan.device)
@@ -197,6 +201,7 @@ def test_split_bf16_is_f32_accurate(hiplib):
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / 48.0
     ref = F.conv2d(x.double(), w.double(), None, padding=1)
     plan = PlanBase("cuda")
+    plan.math = hip.MATH_BF16X3  # these tests drive the f32-input kernels (f32 MFMA / on-the-fly bf16x3 split); the split-plane path: test_conv_planes_gpu.py
     wp, meta = pack_filter(w, plan.device)
     xin, yout = plan.buf("x", B, H, W, Cin), plan.buf("y", B, H, W, Cout)
     xin.t.copy_(x.permute(0, 2, 3, 1))
@@ -228,6 +233,7 @@ def test_smallc_patch_conv_matches_torch(hiplib, case):
     ref = F.relu(F.conv2d(x, w, None, stride=stride, padding=pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
     Ho, Wo = ref.shape[-2:]
     plan = PlanBase("cuda")
+    plan.math = hip.MATH_BF16X3  # these tests drive the f32-input kernels (f32 MFMA / on-the-fly bf16x3 split); the split-plane path: test_conv_planes_gpu.py
     cin_p = 4 if Cin <= 4 else 16
     assert plan.lib.dd3d_conv2d_smallc_supported(cin_p, k, k, stride, pad, Cout)
     xin = plan.buf("x", B, H, W, cin_p)

@@ -178,3 +178,38 @@ def test_split_planes_relu_and_slices(hiplib):
             want = hi.float() + ((x - hi.float()).to(torch.bfloat16).float() if math == hip.MATH_BF16X2 else 0.0)
             assert torch.equal(got, want), mode
             assert torch.equal(gotr, torch.where(x > 0, want, torch.zeros_like(want))), mode
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2", "bf16x2"])
+def test_pool_and_topdown_write_their_planes(hiplib, mode):
+    """dd3d_maxpool2x2_planes / dd3d_upsample2x_add_planes: the f32 result equals the plain kernels' (bit-exact vs torch), and the
+    planes written in the same launch decode to it (exactly for the three-term split)."""
+    math, _ = MODES[mode]
+    plan = _plan(math)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    xb = plan.buf("x", 2, 12, 20, 96, kind="f32")
+    xb.t[..., 32:96] = x.permute(0, 2, 3, 1).to(plan.device)
+    yb = plan.buf("y", 2, 6, 10, 128, kind="both")  # pooled map placed at channels 32..95 of a wider (concat) buffer
+    plan.maxpool(xb.view(32, 64), yb.view(32, 64))
+    c = torch.randn(2, 64, 3, 5, generator=g)
+    cb = plan.buf("c", 2, 3, 5, 64, kind="f32")
+    cb.t.copy_(c.permute(0, 2, 3, 1))
+    plan.upsample_add(yb.view(32, 64), cb.view())
+    assert len(plan.ops) == 2  # no separate split launches
+    plan.launch()
+    torch.cuda.synchronize()
+    ref = F.max_pool2d(x, 2, 2) + F.interpolate(c, scale_factor=2.0, mode="nearest")
+    got = yb.t[..., 32:96].permute(0, 3, 1, 2).cpu()
+    assert torch.equal(got, ref)
+    if math == hip.MATH_F16X2:
+        terms = yb.p[1:3].view(torch.float16).float() / yb.plane_scale
+    else:
+        terms = (yb.p[1:3].to(torch.int32) << 16).view(torch.float32)
+    dec = terms.sum(2).permute(1, 0, 2).reshape(2, 6, 10, 64).permute(0, 3, 1, 2).cpu()
+    if math == hip.MATH_BF16X3:
+        assert torch.equal(dec, ref)
+    else:
+        tol = {hip.MATH_F16X2: 2.0**-21, hip.MATH_BF16X2: 2.0**-15}[math]
+        assert float((dec - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-8
+    assert torch.all(yb.p[0] == 0) and torch.all(yb.p[3] == 0)  # neighbouring chunk images untouched
