@@ -40,6 +40,39 @@ __device__ __forceinline__ void sched_interleave() {
   if constexpr (NMFMA > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NPAIR, 0);
 }
 
+// The same, with the NDMA + NDS other operations spread EVENLY over the NMFMA matrix instructions (the DMAs evenly among them): all
+// eight waves of a block leave the barrier together, and eight back-to-back bursts of LDS-DMA issues queue up in the CU's one
+// address / texture path while the matrix pipe starves; one issue every few MFMAs keeps that path short.
+template <int NMFMA, int NDS, int NDMA>
+__device__ __forceinline__ void sched_uniform() {
+  constexpr int NX = NDS + NDMA;
+  int placed = 0, dma = 0;
+#pragma unroll
+  for (int i = 0; i < NMFMA; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    const int upto = ((i + 1) * NX) / NMFMA;  // other operations due after MFMA i
+#pragma unroll
+    for (; placed < upto; ++placed) {
+      const bool is_dma = NDMA > 0 && ((placed + 1) * NDMA) / NX > (placed * NDMA) / NX;
+      if (is_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0), ++dma;
+      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  }
+}
+
+#ifndef DD3D_PREFETCH_DISTANCE
+#define DD3D_PREFETCH_DISTANCE 0  // K-tiles between the L2 touch of a tile and its DMA (0: no touch).  Measured: the touches only add VMEM instructions (towers 110 -> 115 us, small convs 22 -> 31 us): the loop is bound by DMA instruction throughput, not by miss latency
+#endif
+#ifndef DD3D_LDS_KIB_8W
+#define DD3D_LDS_KIB_8W 144
+#endif
+#ifndef DD3D_LDS_KIB_4W
+#define DD3D_LDS_KIB_4W 72
+#endif
+#ifndef DD3D_SCHED_VARIANT
+#define DD3D_SCHED_VARIANT 1  // 0: DMA burst right after the barrier; 1: evenly spread over the phase; 2: spread over both phases of a step (NS >= 3)
+#endif
+
 template <int TM, int TN, int WM, int WN, int NS, int MODE, bool SK>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const ConvKArgs a) {
   constexpr int NP = Planes<MODE>::NP;
@@ -126,20 +159,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
   int ld_kt = kt_begin;
   int ld_chunk = kt_begin / a.T;
   int ld_tap = kt_begin - ld_chunk * a.T;
-  auto issue_tile = [&](int stage) {
+  // prepare(): source addresses of the tile the stream stands on (then the stream advances); emit(): its DMA instructions.  Split in
+  // two so that the address arithmetic (scalar tap decode, bounds, 64-bit adds) runs BEFORE the barrier that frees the target stage
+  // and only the DMA instructions themselves follow it.
+  gcbp nxt_src[QN];
+  auto prepare = [&]() {
     const int dh = (ld_tap * a.kw_magic) >> 16;
     const int dw = ld_tap - dh * a.KW;
     const long koff_a = (long)ld_chunk * in_cstride + ((long)dh * s.W + dw) * (NP * 64);
     const long koff_b = (long)ld_kt * (NP * 64);
-    unsigned char* st = lds + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
       // (bitwise, not short-circuit: no branches in the K loop)
       const bool ok = (int)!q_isA[q] | ((int)((unsigned)(a_hi0[q] + dh) < (unsigned)s.H) & (int)((unsigned)(a_wi0[q] + dw) < (unsigned)s.W));
-      const gcbp src = ok ? q_src[q] + (q_isA[q] ? koff_a : koff_b) : g_zero + slot16;  // the zero page covers NP planes x 64 B
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + p * 64), (ldsbp)(st + q_dst[q] + p * q_pst[q]), 16, 0, 0);
+      nxt_src[q] = ok ? q_src[q] + (q_isA[q] ? koff_a : koff_b) : g_zero + slot16;  // the zero page covers NP planes x 64 B
     }
     const int adv = ld_kt + 1 < kt_end;
     ld_kt += adv;
@@ -148,6 +181,60 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
     ld_tap = wrap ? 0 : ld_tap;
     ld_chunk += wrap;
   };
+  auto emit = [&](int stage, auto qb_c, auto qe_c) {  // row blocks [qb, qe) of the prepared tile
+    constexpr int QB = decltype(qb_c)::value, QE = decltype(qe_c)::value;
+#ifdef DD3D_ABLATE_DMA
+    return;
+#endif
+    unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+    for (int q = QB; q < QE; ++q)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(nxt_src[q] + p * 64), (ldsbp)(st + q_dst[q] + p * q_pst[q]), 16, 0, 0);
+  };
+  // L2 prefetch: the tile the DMA stream reaches PFD steps from now is touched with one 4-byte load per lane at the very addresses
+  // its DMA will use.  The first tap of every 32-channel chunk reads activation lines no block has touched yet (the producer wrote
+  // them through ANOTHER XCD's L2), and a counted vmcnt wait is only as fast as the slowest line of the tile: without the touch one
+  // step in nine waits for an HBM round trip.  The loads share vmcnt with the DMAs (in order), hence one per row block and step in
+  // every wave, so the counted waits stay exact; their destination register is never read.
+  constexpr int PFD = DD3D_PREFETCH_DISTANCE;
+  constexpr int PFN = PFD > 0 ? QN : 0;
+  int pf_kt = kt_begin, pf_chunk = kt_begin / a.T, pf_tap = kt_begin - (kt_begin / a.T) * a.T;
+  unsigned pf_sink[QN];
+#pragma unroll
+  for (int q = 0; q < QN; ++q) pf_sink[q] = 0;
+  auto pf_advance = [&]() {
+    const int adv = pf_kt + 1 < kt_end;
+    pf_kt += adv;
+    pf_tap += adv;
+    const int wrap = pf_tap == a.T;
+    pf_tap = wrap ? 0 : pf_tap;
+    pf_chunk += wrap;
+  };
+  auto prefetch = [&]() {
+    if constexpr (PFD > 0) {
+      const int dh = (pf_tap * a.kw_magic) >> 16;
+      const int dw = pf_tap - dh * a.KW;
+      const long koff_a = (long)pf_chunk * in_cstride + ((long)dh * s.W + dw) * (NP * 64);
+      const long koff_b = (long)pf_kt * (NP * 64);
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        const bool ok = (int)!q_isA[q] | ((int)((unsigned)(a_hi0[q] + dh) < (unsigned)s.H) & (int)((unsigned)(a_wi0[q] + dw) < (unsigned)s.W));
+        const gcbp src = ok ? q_src[q] + (q_isA[q] ? koff_a : koff_b) : g_zero + slot16;
+        // "+v": one register chain for the whole loop -- a plain output would be dead right after each definition, and the allocator
+        // could hand the register to something else while the load is still in flight
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink[q]) : "v"(src) : "memory");
+      }
+      pf_advance();
+    }
+  };
+  constexpr std::integral_constant<int, 0> Q0{};
+  constexpr std::integral_constant<int, QN> QALL{};
+  // variant 2: the first QH row blocks of a tile go out after the barrier that frees their stage, the rest before the next one
+  constexpr bool SPLIT = DD3D_SCHED_VARIANT == 2 && NS >= 3 && QN >= 2;
+  constexpr int QH = SPLIT ? (QN + 1) / 2 : QN;
+  constexpr std::integral_constant<int, QH> QMID{};
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -163,10 +250,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
   const int frag_off[2] = {lrow * 64 + (((0 + kh) ^ swz) << 4), lrow * 64 + (((2 + kh) ^ swz) << 4)};  // k-chunk 0 / 1
   const int a_row0 = wm * TM * 32 * 64, b_row0 = A_BYTES + wn * TN * 32 * 64;
 
+#ifdef DD3D_ABLATE_DSREAD
+  bf16x8 fa[2][TM][NP] = {}, fb[2][TN][NP] = {};
+#else
   bf16x8 fa[2][TM][NP], fb[2][TN][NP];  // fragment sets of the two 16-k chunks
+#endif
   auto read_frags = [&](int stage, auto c_c) {
     constexpr int c = decltype(c_c)::value;
     const unsigned char* st = lds + stage * STAGE;
+#ifdef DD3D_ABLATE_DSREAD
+    if (a.relu != 12345) return;
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -182,6 +276,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
   constexpr int PB_[6] = {0, NP == 3 ? 2 : (NP == 2 ? 1 : 0), NP == 3 ? 1 : 0, 0, 1, 0};
   auto mfma_chunk = [&](auto c_c) {
     constexpr int c = decltype(c_c)::value;
+#ifdef DD3D_ABLATE_MFMA
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < NPROD; ++t)
 #pragma unroll
@@ -198,35 +295,58 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
   constexpr std::integral_constant<int, 1> C1{};
 
   if (ntile > 0) {
-    // prologue: fill the ring (tiles 0 .. NS-1), wait for tile 0
+    // prologue: fill the ring (tiles 0 .. NS-1; variant 2 leaves the second part of tile NS-1 to the first step), wait for tile 0
 #pragma unroll
-    for (int d = 0; d < NS; ++d) issue_tile(d);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * P) : "memory");
+    for (int d = 0; d < NS; ++d) {
+      prepare();
+      if (SPLIT && d == NS - 1) emit(d, Q0, QMID);
+      else emit(d, Q0, QALL);
+    }
+    if constexpr (PFD > 0) {  // the touch stream starts NS + PFD tiles in: tiles NS .. NS+PFD-1 go untouched (one start-up latency)
+      for (int d = 0; d < NS + PFD; ++d) pf_advance();
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPLIT ? (NS - 2) * P + QH * NP : (NS - 1) * P) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     read_frags(0, C0);
-    int stage = 0;
+    int stage = 0;        // ring stage of tile kt
+    int fill = NS - 1;    // variant 2: stage whose tile is half issued
+    constexpr int NM = TM * TN * NPROD, NDS = (TM + TN) * NP;
     for (int kt = 0; kt < ntile; ++kt) {
-      // ---- phase A: chunk-1 fragment reads of tile kt under the chunk-0 MFMAs
+      // ---- phase A: chunk-1 fragment reads of tile kt under the chunk-0 MFMAs (variant 2: + the second part of the tile in flight),
+      // and the addresses of the next tile to fetch
+      if constexpr (SPLIT) emit(fill, QMID, QALL);
       read_frags(stage, C1);
       mfma_chunk(C0);
-      sched_interleave<TM * TN * NPROD, (TM + TN) * NP, 0>();
+      prepare();
+      if constexpr (DD3D_SCHED_VARIANT == 0) sched_interleave<NM, NDS, 0>();
+      else sched_uniform<NM, NDS, SPLIT ? (QN - QH) * NP : 0>();
       __builtin_amdgcn_sched_barrier(0);
       // my pieces of tile kt+1 have landed once at most NS-2 newer tiles are in flight; my reads of this stage are done
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * P) : "memory");
+      // (in issue order behind tile kt+1: its step's PFN touches, then NS-2 steps of P DMAs + PFN touches)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (P + PFN) + (SPLIT ? 0 : PFN)) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // everyone: tile kt+1 landed, stage `stage` (tile kt) no longer read
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B: DMA of tile kt+NS into the stage just freed and chunk-0 fragment reads of tile kt+1 under the chunk-1 MFMAs
-      issue_tile(stage);
+      if constexpr (SPLIT) {
+        emit(stage, Q0, QMID);
+        fill = stage;
+      } else {
+        emit(stage, Q0, QALL);
+      }
+      prefetch();
       stage = stage == NS - 1 ? 0 : stage + 1;
       read_frags(stage, C0);  // (past the end: a stage holding surplus data, never used)
       mfma_chunk(C1);
-      sched_interleave<TM * TN * NPROD, (TM + TN) * NP, P>();
+      if constexpr (DD3D_SCHED_VARIANT == 0) sched_interleave<NM, NDS, P>();
+      else sched_uniform<NM, NDS, (SPLIT ? QH * NP : P) + PFN>();
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the LDS is released
+#pragma unroll
+    for (int q = 0; q < QN; ++q) asm volatile("" ::"v"(pf_sink[q]));  // the touch registers stay allocated until here
   }
 
   if constexpr (SK) {
@@ -241,8 +361,8 @@ static int launch_planes_tile(const ConvKArgs& ka, hipStream_t st) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
   constexpr int STAGE = NP * (BM + BN) * 64;
-  // 8-wave blocks own the CU (144 KiB ring); 4-wave blocks are sized so that two share a CU (<= 72 KiB each)
-  constexpr int BUDGET = (WM * WN == 8 ? 144 : 72) * 1024;
+  // LDS ring budgets (KiB): what a block may take decides how many blocks -- of this launch or of another stream's -- share a CU
+  constexpr int BUDGET = (WM * WN == 8 ? DD3D_LDS_KIB_8W : DD3D_LDS_KIB_4W) * 1024;
   constexpr int NS0 = BUDGET / STAGE;
   constexpr int NS = NS0 > 4 ? 4 : (NS0 < 2 ? 2 : NS0);
   const size_t lds = (size_t)NS * STAGE;

@@ -313,6 +313,8 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
     adds the partial-sum exchange.  `planes`: the split-plane-input kernel (its own measured table; the f32-input kernel's
     entries serve as the fallback for the three-term mode, their two-K-tiles-per-barrier variants mapped to the plain tile)."""
     allowed = PLANE_TILES if planes else MATH_TILES[math]
+    # (measured and dropped: forcing the small convolutions onto 4-wave blocks with <= 48 KiB of LDS so that other streams' blocks could
+    # share their CUs -- pipelined throughput 960 -> 921 img/s, profiles/r02_notes.md)
     key = tile_key(m_list, N, Kpad, stride)
     hit = PLANE_TILE_TABLE[math].get(key) if planes else TILE_TABLE[math].get(key)
     if hit is None and planes and math == hip.MATH_BF16X3:

@@ -18,7 +18,7 @@ from tests.golden.make_golden import TRAINING_ONLY_KEYS, _merge  # noqa: E402
 
 TTA_OVERRIDES = {
     "DD3D": {"INFERENCE": {"DO_POSTPROCESS": False, "DO_BEV_NMS": True}, "FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.02}}},
-    "TEST": {"IMS_PER_BATCH": 4, "AUG": {"ENABLED": True, "MIN_SIZES": [96, 128, 160], "MAX_SIZE": 100000, "FLIP": True}},
+    "TEST": {"IMS_PER_BATCH": 2, "AUG": {"ENABLED": True, "MIN_SIZES": [96, 128, 160], "MAX_SIZE": 100000, "FLIP": True}},
     "INPUT": {"FORMAT": "BGR"},
 }
 
@@ -34,7 +34,7 @@ def tta_case():
 NUSC_TTA_OVERRIDES = {
     "DD3D": {"INFERENCE": {"DO_POSTPROCESS": False}, "FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}},
              "NUSC": {"INFERENCE": {"MAX_NUM_DETS_PER_SAMPLE": 120}}},
-    "TEST": {"IMS_PER_BATCH": 4, "AUG": {"ENABLED": True, "MIN_SIZES": [96, 128], "MAX_SIZE": 100000, "FLIP": True}},
+    "TEST": {"IMS_PER_BATCH": 2, "AUG": {"ENABLED": True, "MIN_SIZES": [96, 128], "MAX_SIZE": 100000, "FLIP": True}},
     "INPUT": {"FORMAT": "BGR"},
 }
 

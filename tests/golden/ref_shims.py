@@ -9,7 +9,10 @@ What that pins and what it does not:
   * pinned: every line of the in-repo path (core.py, fcos2d.py, fcos3d.py, dla.py, normalization.py, boxes3d.py,
     image_list.py, geometry.py, tensor2d.py) runs as written by the reference authors;
   * NOT pinned: the third-party pieces below are re-statements of the published behaviour of detectron2 v0.5/0.6,
-    torchvision 0.10 and pytorch3d 0.5/0.6 -- "[ext] parity unpinned".
+    torchvision 0.10 and pytorch3d 0.5/0.6 -- "[ext] parity unpinned".  They are written HERE, independently
+    of the oracle and of the package under test (nothing in this file imports `oracle` or `dd3d_amd`): NMS is a brute-force O(n^2)
+    greedy loop, rotated IoU a float64 polygon clipper, matrix -> quaternion is scipy's, Boxes / Instances are local classes -- so the
+    goldens cross-check the oracle's restatements instead of echoing them.
 
 Test infrastructure only; never imported by dd3d_amd.
 """
@@ -92,13 +95,202 @@ def cat(tensors, dim=0):
 
 
 def _nms(boxes, scores, thr):
-    from oracle.dd3d_oracle import nms
-    return nms(boxes, scores, thr)
+    """[ext] torchvision.ops.nms (0.10), written HERE as a brute-force O(n^2) greedy loop -- deliberately not the
+    oracle's (or the product's) implementation, so that the goldens cross-check those: visit the boxes by descending score, keep a box
+    unless a kept one overlaps it with IoU = inter / (area_a + area_b - inter) > thr (float32, no +1, clamped overlaps); returns the
+    kept indices in visiting order."""
+    b = boxes.detach().to(torch.float32).cpu().numpy()
+    order = torch.sort(scores.detach().float().cpu(), descending=True, stable=True)[1].tolist()
+    import numpy as np
+    area = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])).astype(np.float32)
+    kept = []
+    for i in order:
+        ok = True
+        for j in kept:
+            w = np.float32(max(np.float32(0.0), np.float32(min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0]))))
+            h = np.float32(max(np.float32(0.0), np.float32(min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1]))))
+            inter = np.float32(w * h)
+            if np.float32(inter / np.float32(np.float32(area[i] + area[j]) - inter)) > np.float32(thr):
+                ok = False
+                break
+        if ok:
+            kept.append(i)
+    return torch.tensor(kept, dtype=torch.int64)
 
 
 def batched_nms(boxes, scores, idxs, iou_threshold):
-    from oracle.dd3d_oracle import batched_nms as _b
-    return _b(boxes, scores, idxs, iou_threshold)
+    """[ext] detectron2.layers.batched_nms -> torchvision.ops.batched_nms (0.10): float boxes; more than 4000 coordinates -> one NMS per
+    class, survivors re-sorted by score; else the coordinate trick (every class shifted by max coordinate + 1, one NMS)."""
+    boxes = boxes.float()
+    assert boxes.shape[-1] == 4
+    if boxes.numel() == 0:
+        return torch.empty((0, ), dtype=torch.int64)
+    if boxes.numel() > 4000:
+        keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+        for class_id in torch.unique(idxs):
+            curr = torch.where(idxs == class_id)[0]
+            keep_mask[curr[_nms(boxes[curr], scores[curr], iou_threshold)]] = True
+        keep = torch.where(keep_mask)[0]
+        return keep[scores[keep].sort(descending=True)[1]]
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return _nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+# ---- [ext] detectron2.structures.Boxes / Instances (appendix A7), written here rather than borrowed from the package under test
+class Boxes:
+    def __init__(self, tensor):
+        tensor = torch.as_tensor(tensor, dtype=torch.float32)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((-1, 4)).to(dtype=torch.float32)
+        assert tensor.dim() == 2 and tensor.size(-1) == 4, tensor.size()
+        self.tensor = tensor
+
+    def clone(self):
+        return Boxes(self.tensor.clone())
+
+    def to(self, *args, **kwargs):
+        return Boxes(self.tensor.to(*args, **kwargs))
+
+    def area(self):
+        b = self.tensor
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+    def clip(self, box_size):
+        h, w = box_size
+        self.tensor = torch.stack((self.tensor[:, 0].clamp(min=0, max=w), self.tensor[:, 1].clamp(min=0, max=h),
+                                   self.tensor[:, 2].clamp(min=0, max=w), self.tensor[:, 3].clamp(min=0, max=h)), dim=-1)
+
+    def nonempty(self, threshold=0.0):
+        b = self.tensor
+        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+
+    def scale(self, scale_x, scale_y):
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return Boxes(self.tensor[item].view(1, -1))
+        return Boxes(self.tensor[item])
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    @classmethod
+    def cat(cls, boxes_list):
+        if len(boxes_list) == 0:
+            return cls(torch.empty(0))
+        return cls(torch.cat([b.tensor for b in boxes_list], dim=0))
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+
+class Instances:
+    def __init__(self, image_size, **kwargs):
+        self._image_size = image_size
+        self._fields = {}
+        for k, v in kwargs.items():
+            self.set(k, v)
+
+    image_size = property(lambda s: s._image_size)
+
+    def __setattr__(self, name, val):
+        if name.startswith("_"):
+            super().__setattr__(name, val)
+        else:
+            self.set(name, val)
+
+    def __getattr__(self, name):
+        if name == "_fields" or name not in self._fields:
+            raise AttributeError(f"Cannot find field '{name}' in the given Instances!")
+        return self._fields[name]
+
+    def set(self, name, value):
+        if len(self._fields):
+            assert len(self) == len(value), f"Adding a field of length {len(value)} to a Instances of length {len(self)}"
+        self._fields[name] = value
+
+    def has(self, name):
+        return name in self._fields
+
+    def remove(self, name):
+        del self._fields[name]
+
+    def get(self, name):
+        return self._fields[name]
+
+    def get_fields(self):
+        return self._fields
+
+    def to(self, *args, **kwargs):
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            ret.set(k, v.to(*args, **kwargs) if hasattr(v, "to") else v)
+        return ret
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            if item >= len(self) or item < -len(self):
+                raise IndexError("Instances index out of range!")
+            item = slice(item, None, len(self))
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            ret.set(k, v[item])
+        return ret
+
+    def __len__(self):
+        for v in self._fields.values():
+            return v.__len__()
+        raise NotImplementedError("Empty Instances does not support __len__!")
+
+    @staticmethod
+    def cat(instance_lists):
+        assert all(isinstance(i, Instances) for i in instance_lists) and len(instance_lists) > 0
+        if len(instance_lists) == 1:
+            return instance_lists[0]
+        image_size = instance_lists[0].image_size
+        for i in instance_lists[1:]:
+            assert i.image_size == image_size
+        ret = Instances(image_size)
+        for k in instance_lists[0]._fields.keys():
+            values = [i.get(k) for i in instance_lists]
+            v0 = values[0]
+            if isinstance(v0, torch.Tensor):
+                values = torch.cat(values, dim=0)
+            elif isinstance(v0, list):
+                values = [x for v in values for x in v]
+            elif hasattr(type(v0), "cat"):
+                values = type(v0).cat(values)
+            else:
+                raise ValueError(f"Unsupported type {type(v0)} for concatenation")
+            ret.set(k, values)
+        return ret
+
+
+def quaternion_to_matrix(quaternions):
+    """[ext] pytorch3d.transforms.quaternion_to_matrix (appendix A8), real part first."""
+    r, i, j, k = torch.unbind(quaternions, -1)
+    two_s = 2.0 / (quaternions * quaternions).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r), two_s * (i * j + k * r), 1 - two_s * (i * i + k * k),
+                     two_s * (j * k - i * r), two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
+def matrix_to_quaternion(matrix):
+    """[ext] pytorch3d.transforms.matrix_to_quaternion: NOT the oracle's restatement of pytorch3d's branches but scipy's independent
+    conversion (float64, Shepperd's method), returned real part first in float32.  The overall sign differs between pytorch3d releases
+    (appendix A8) -- every consumer compares quaternions up to sign or through the rotation / the box corners."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation
+    m = matrix.detach().cpu().double().numpy().reshape(-1, 3, 3)
+    if m.shape[0] == 0:
+        return matrix.new_zeros(matrix.shape[:-2] + (4, ))
+    q = Rotation.from_matrix(m).as_quat()  # (x, y, z, w)
+    q = np.concatenate([q[:, 3:4], q[:, 0:3]], axis=1)
+    return torch.from_numpy(q).to(matrix.dtype).reshape(matrix.shape[:-2] + (4, )).to(matrix.device)
 
 
 # --------------------------------------------------------------------------------------------- registries / config
@@ -252,7 +444,6 @@ class FPN(Backbone):
 
 
 def detector_postprocess(results, output_height, output_width, mask_threshold=0.5):
-    from dd3d_amd.structures import Instances
     scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
     results = Instances((output_height, output_width), **results.get_fields())
     boxes = results.pred_boxes
@@ -642,8 +833,6 @@ def install():
     """Install every shim module and make ``tridet`` importable without running its package __init__ chains."""
     if "detectron2" in sys.modules and getattr(sys.modules["detectron2"], "_dd3d_shim", False):
         return
-    from dd3d_amd.structures import Boxes, Instances
-    from oracle import dd3d_oracle as O
     d2 = _mod("detectron2", _dd3d_shim=True)
     _mod("detectron2.config", configurable=configurable)
     _mod("detectron2.layers", Conv2d=Conv2d, get_norm=get_norm, FrozenBatchNorm2d=FrozenBatchNorm2d, ShapeSpec=ShapeSpec, cat=cat,
@@ -674,8 +863,7 @@ def install():
     _mod("fvcore.nn.weight_init", c2_msra_fill=c2_msra_fill, c2_xavier_fill=_xavier)
     _mod("pytorch3d")
     _mod("pytorch3d.transforms")
-    _mod("pytorch3d.transforms.rotation_conversions", quaternion_to_matrix=O.quaternion_to_matrix,
-         matrix_to_quaternion=O.matrix_to_quaternion)
+    _mod("pytorch3d.transforms.rotation_conversions", quaternion_to_matrix=quaternion_to_matrix, matrix_to_quaternion=matrix_to_quaternion)
     t3d = _mod("pytorch3d.transforms.transform3d", Translate=Translate, Rotate=Rotate, Transform3d=Transform3d)
     sys.modules["pytorch3d.transforms"].transform3d = t3d
     _mod("fvcore.nn.smooth_l1_loss", smooth_l1_loss=lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("training only")))

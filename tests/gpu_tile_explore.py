@@ -59,7 +59,8 @@ def main():
     torch.cuda.synchronize()
     seen = {}
     table = {}
-    engine.TILE_TABLE = {hip.MATH_F32: {}, hip.MATH_BF16X3: {}}  # measure against the analytic model
+    engine.TILE_TABLE = {m: {} for m in engine.TILE_TABLE}  # measure against the analytic model
+    engine.PLANE_TILE_TABLE = {m: {} for m in engine.PLANE_TILE_TABLE}
     for name, pl, meta, stride, pad, segs, relu, kw in RECORD:
         m_list = tuple(s["out"].B * s["out"].H * s["out"].W for s in segs)
         key = (m_list, meta["N"], meta["Kpad"], meta["Cin"], stride)
@@ -67,12 +68,13 @@ def main():
             continue
         seen[key] = name
         nk = meta["Kpad"] // 32
-        math = pl.math if (meta["Cin"] % 32 == 0 and meta["N"] > 32) else hip.MATH_F32
-        cur_cfg, cur_sk = engine.choose_tiling(list(m_list), meta["N"], meta["Kpad"], stride, math)
+        planes = pl.use_planes and meta["Cin"] % 32 == 0 and all(sg["in"].np for sg in segs)
+        math = pl.math if (meta["Cin"] % 32 == 0 and (meta["N"] > 32 or planes)) else hip.MATH_F32
+        cur_cfg, cur_sk = engine.choose_tiling(list(m_list), meta["N"], meta["Kpad"], stride, math, planes=planes)
         res = []
-        for cfg_id in engine.MATH_TILES[math]:
+        for cfg_id in (engine.PLANE_TILES if planes else engine.MATH_TILES[math]):
             bm, bn = hip.TILE_SHAPES[cfg_id]
-            if (bn == 32) != (meta["N"] <= 32):
+            if (bn == 32) != (meta["N"] <= 32) and not (planes and bn == 64 and meta["N"] <= 32):
                 continue
             if bn == 128 and meta["N"] <= 64:
                 continue
@@ -100,7 +102,8 @@ def main():
 
 
     import json
-    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}_{'bf16x3' if plan.math == hip.MATH_BF16X3 else 'f32'}.json")
+    mname = next(k for k, v in engine.MATH_NAMES.items() if v == plan.math)
+    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}_{mname}{'_planes' if plan.use_planes else ''}.json")
     os.makedirs("gpurun_out", exist_ok=True)
     with open(out, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)

@@ -49,8 +49,8 @@ def main():
             b.t.zero_()
         if b.p is not None:
             b.p.zero_()
-    for _, w in plan._split.values():
-        w.zero_()
+    for entry in plan._split.values():
+        entry[1].zero_()
     zero = {op.name: time_op(plan, op) for op in ops}
     for op in ops:
         fl = 2.0 * op.macs

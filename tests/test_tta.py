@@ -16,7 +16,7 @@ def _bundle():
 
 
 def _check(boxes, scores_3d, classes, vec, proj_ctr, tol):
-    assert len(boxes) == len(G["boxes"]) == 186
+    assert len(boxes) == len(G["boxes"]) == 192
     assert np.array_equal(np.asarray(classes), G["classes"])
     assert np.allclose(boxes, G["boxes"], rtol=tol, atol=tol * 300) and np.allclose(scores_3d, G["scores_3d"], rtol=tol, atol=1e-6)
     assert np.allclose(vec[:, 4:], G["vectorize"][:, 4:], rtol=tol, atol=tol * 80) and np.allclose(proj_ctr, G["proj_ctr"], rtol=tol, atol=tol * 300)
