@@ -17,6 +17,16 @@ namespace dd3d {
 
 constexpr int PT = 1024;        // threads per block for the per-image / per-level kernels
 constexpr int TOPK_MAX = 1024;  // PRE_NMS_TOPK capacity of the LDS candidate list
+// slot_off[l] = first candidate slot of level l inside an image's row, slot_off[L] = slots per image (engine: level l holds
+// min(topk, H*W*C) slots -- the RCCL payload carries no slot a level can never fill); all zero = the dense layout l * topk
+__device__ __host__ inline int slot_base(const int32_t* slot_off, int L, int topk, int l) { return slot_off[L] > 0 ? slot_off[l] : l * topk; }
+__device__ __host__ inline int level_of_slot(const int32_t* slot_off, int L, int topk, int slot) {
+  if (slot_off[L] <= 0) return slot / topk;
+  int l = 0;
+  while (l + 1 < L && slot >= slot_off[l + 1]) ++l;
+  return l;
+}
+
 constexpr int NCAP_MAX = 8192;  // max candidates per image (levels * topk) the LDS sorter handles
 constexpr float QEPS = 1e-7f;   // tridet/modeling/dd3d/fcos3d.py:13
 
@@ -255,8 +265,8 @@ __global__ __launch_bounds__(PT) void fcos_select_decode_kernel(const SelectK P)
   __syncthreads();
 
   // ---- phase 3: decode  (fcos2d.py:319-336, fcos3d.py:343-399, fcos3d.py:16-52, geometry.py:15-55)
-  const int NS = a.num_levels * a.topk;
-  float* cand = a.cand + (long)b * DD3D_CAND_FIELDS * NS + l * a.topk;
+  const int NS = slot_base(a.slot_off, a.num_levels, a.topk, a.num_levels);
+  float* cand = a.cand + (long)b * DD3D_CAND_FIELDS * NS + slot_base(a.slot_off, a.num_levels, a.topk, l);
   float q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 1.f;
   int bad = 0;
   const bool active = tid < k;
@@ -415,7 +425,7 @@ enum { NMS_TRICK = 0, NMS_PER_CLASS = 1, NMS_NONE = 2 };
 __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
   const int g = blockIdx.x, tid = threadIdx.x;
-  const int L = a.num_levels, NS = L * a.topk;
+  const int L = a.num_levels, NS = slot_base(a.slot_off, L, a.topk, L);
   const float* cand = a.cand + (long)g * DD3D_CAND_FIELDS * NS;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // keys[ncap2] | vals[ncap2]
   float* keys = reinterpret_cast<float*>(dyn_lds);
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
     if (i < n) {
       int l = 0;
       while (l + 1 < L && i >= pref[l + 1]) ++l;
-      const int slot = l * a.topk + (i - pref[l]);
+      const int slot = slot_base(a.slot_off, L, a.topk, l) + (i - pref[l]);
       key = key_src[slot];
       val = slot;  // slots grow with the concatenated (level-major) index => ties keep the Instances.cat order
       mx = fmaxf(mx, fmaxf(fmaxf(cand[0 * NS + slot], cand[1 * NS + slot]), fmaxf(cand[2 * NS + slot], cand[3 * NS + slot])));
@@ -595,7 +605,7 @@ __device__ __forceinline__ void greedy_reduce(const unsigned long long* mask, in
 __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
   const int g = blockIdx.x, tid = threadIdx.x;
-  const int L = a.num_levels, NS = L * a.topk;
+  const int L = a.num_levels, NS = slot_base(a.slot_off, L, a.topk, L);
   const float* cand = a.cand + (long)g * DD3D_CAND_FIELDS * NS;
   const int n = a.nvalid[2 * g], mode = a.nvalid[2 * g + 1];
   const int* sort_idx = a.sort_idx + (long)g * P.ncap;
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
       d[4] = cand[4 * NS + slot];
       d[5] = cand[5 * NS + slot];
       d[6] = (float)__float_as_int(cand[6 * NS + slot]);
-      d[7] = (float)(slot / a.topk);
+      d[7] = (float)level_of_slot(a.slot_off, L, a.topk, slot);
 #pragma unroll
       for (int f = 8; f < 20; ++f) d[f] = cand[f * NS + slot];
       d[20] = (float)__float_as_int(cand[20 * NS + slot]);
@@ -1073,8 +1083,8 @@ extern "C" int dd3d_fcos_select_decode(const dd3d_select_args* args, void* strea
 extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
   using namespace dd3d;
   DD3D_REQUIRE(args, "dd3d_nms_finalize: null args");
-  const int ns = args->num_levels * args->topk;
-  DD3D_REQUIRE(args->G > 0 && ns > 0 && ns <= NCAP_MAX, "dd3d_nms_finalize: levels*topk=%d exceeds %d", ns, NCAP_MAX);
+  const int ns = slot_base(args->slot_off, args->num_levels, args->topk, args->num_levels);
+  DD3D_REQUIRE(args->G > 0 && ns > 0 && ns <= NCAP_MAX, "dd3d_nms_finalize: %d candidate slots per image exceed %d", ns, NCAP_MAX);
   DD3D_REQUIRE(args->cand && args->counts && args->out_size && args->sort_idx && args->sbox && args->scls && args->mask && args->nvalid &&
                    args->det && args->det_count,
                "dd3d_nms_finalize: null buffer");

@@ -1224,8 +1224,12 @@ class ForwardPlan(PlanBase):
         inf2 = cfg.DD3D.FCOS2D.INFERENCE
         topk = int(inf2.PRE_NMS_TOPK)
         C_ = model.num_classes
-        NS = L * topk
-        self.topk, self.num_levels = topk, L
+        # candidate slots per image: level l can never hold more than H*W*C candidates, so it gets min(topk, H*W*C) slots -- the
+        # buffer the ranks exchange carries no slot that cannot be filled (KITTI 384x1280: 3750 instead of 5000 slots)
+        caps = [min(topk, f.H * f.W * C_) for f in self.features]
+        self.slot_off = [sum(caps[:l]) for l in range(L + 1)]
+        NS = self.slot_off[L]
+        self.topk, self.num_levels, self.slots_per_image = topk, L, NS
         a = hip.SelectArgs()
         sizes = []
         for l, f in enumerate(self.features):
@@ -1259,10 +1263,24 @@ class ForwardPlan(PlanBase):
             a.scratch_off[l] = off
             off += sizes[l]
         a.scratch_img_stride = off
+        for l in range(L + 1):
+            a.slot_off[l] = self.slot_off[l]
         self.scratch_idx = torch.empty(B * off, dtype=torch.int32, device=dev)
         self.scratch_score = torch.empty(B * off, dtype=torch.float32, device=dev)
-        self.cand = torch.zeros((B, hip.CAND_FIELDS, NS), dtype=torch.float32, device=dev)
-        self.counts = torch.zeros((B, L), dtype=torch.int32, device=dev)
+        # What a rank hands to the others is ONE contiguous record: [candidates B x F x NS | counts B x L | resize targets B x 4];
+        # the post-select stages read the record out of the gathered buffer, so they are ordered behind the collective.
+        pad4 = lambda n: (n + 3) // 4 * 4
+        n_c, n_k, n_o = pad4(B * hip.CAND_FIELDS * NS), pad4(B * L), pad4(B * 4)
+        self.record_len = n_c + n_k + n_o
+
+        def views(rec):
+            return (rec[:B * hip.CAND_FIELDS * NS].view(B, hip.CAND_FIELDS, NS), rec[n_c:n_c + B * L].view(torch.int32).view(B, L),
+                    rec[n_c + n_k:n_c + n_k + B * 4].view(B, 4))
+
+        self.record = torch.zeros(self.record_len, dtype=torch.float32, device=dev)
+        self.cand, self.counts, outsize = views(self.record)
+        outsize.copy_(self.in_outsize)
+        self.in_outsize = outsize  # stage_inputs writes the resize targets straight into the record
         self.npass = torch.zeros((B, L), dtype=torch.int32, device=dev)
         a.scratch_idx, a.scratch_score = self.scratch_idx.data_ptr(), self.scratch_score.data_ptr()
         a.cand, a.counts, a.npass = self.cand.data_ptr(), self.counts.data_ptr(), self.npass.data_ptr()
@@ -1270,14 +1288,17 @@ class ForwardPlan(PlanBase):
         self.ops.append(CallOp(lambda lib, st: hip.check(lib.dd3d_fcos_select_decode(C.byref(a), st), "select_decode"), "select_decode"))
         self.num_pre_nms_ops = len(self.ops)
 
-        # NMS over G images (G = B locally; B * world_size after the RCCL gather, see dd3d_amd.parallel)
-        self.G = G = B * world_size
-        self.world_size = world_size
+        # The exchange (dd3d_amd.parallel): every rank's record is all-gathered into `gathered` [W x record]; each rank then finalises
+        # the images it OWNS -- its own B (class-aware NMS is per image; the cameras of a nuScenes sample are kept rank-local, as the
+        # reference's InferenceGroupSampler does, tridet/data/samplers/group_sampler.py:30-35) -- out of ITS segment of the gathered
+        # buffer: no rank repeats another rank's NMS.
+        self.G = G = B
+        self.world_size, self.rank = world_size, rank
         if self.exchange:
-            self.cand_all = torch.zeros((G, hip.CAND_FIELDS, NS), dtype=torch.float32, device=dev)
-            self.counts_all = torch.zeros((G, L), dtype=torch.int32, device=dev)
-            self.outsize_all = torch.zeros((G, 4), dtype=torch.float32, device=dev)
+            self.gathered = torch.zeros(world_size * self.record_len, dtype=torch.float32, device=dev)
+            self.cand_all, self.counts_all, self.outsize_all = views(self.gathered[rank * self.record_len:(rank + 1) * self.record_len])
         else:
+            self.gathered = None
             self.cand_all, self.counts_all, self.outsize_all = self.cand, self.counts, self.in_outsize
         ncap = (NS + 63) // 64 * 64
         n = hip.NmsArgs()
@@ -1292,6 +1313,8 @@ class ForwardPlan(PlanBase):
         self.det_count = torch.zeros((G, ), dtype=torch.int32, device=dev)
         n.cand, n.counts = self.cand_all.data_ptr(), self.counts_all.data_ptr()
         n.G, n.num_levels, n.topk = G, L, topk
+        for l in range(L + 1):
+            n.slot_off[l] = self.slot_off[l]
         n.do_nms, n.use_score3d = int(bool(inf.DO_NMS)), int(self.b3d_maps is not None)
         n.nms_thresh, n.post_topk = float(inf2.NMS_THRESH), int(inf2.POST_NMS_TOPK)
         # BEV stages (core.py:135-150, nuscenes_dd3d.py:423-465) run after the 2D NMS; the resize / clip / non-empty filter
@@ -1311,7 +1334,7 @@ class ForwardPlan(PlanBase):
             # The images that meet in a BEV stage (one image, or the 6 cameras of a sample) are always on the rank that
             # decoded them (InferenceGroupSampler hands out whole samples, tridet/data/samplers.py), so with W ranks the
             # stages run over this rank's slice [rank*B, (rank+1)*B) of the gathered detection buffers.
-            first = rank * B
+            first = 0  # (the detection buffers hold this rank's images only)
             self.has_bev_inputs = True
             self.in_pose = torch.zeros((B, 7), dtype=torch.float32, device=dev)
             self.in_pose[:, 0] = 1.0
@@ -1352,8 +1375,16 @@ class ForwardPlan(PlanBase):
                 self.has_global_boxes = True
 
     def gather_pairs(self):
-        """(local, global) tensors the multi-GPU step all-gathers between select/decode and the NMS stages."""
-        return [(self.cand, self.cand_all), (self.counts, self.counts_all), (self.in_outsize, self.outsize_all)]
+        """(local record, gathered buffer [W x record]): the ONE tensor pair the multi-GPU step all-gathers between select/decode and
+        the NMS stages."""
+        return [(self.record, self.gathered)]
+
+    def gathered_counts(self):
+        """Candidate counts [W*B, L] of every rank's images as delivered by the exchange (diagnostics / tests)."""
+        B, L, NS = self.B, self.num_levels, self.slots_per_image
+        n_c = (B * hip.CAND_FIELDS * NS + 3) // 4 * 4
+        g = self.gathered.view(self.world_size, self.record_len)
+        return g[:, n_c:n_c + B * L].view(torch.int32).reshape(self.world_size * B, L)
 
 
 class DenseDepthPlan(ForwardPlan):

@@ -83,7 +83,7 @@ class SelectArgs(C.Structure):
         ("max_depth", C.c_float), ("focal_factor", C.c_float), ("scale_depth_by_focal", C.c_int32), ("allocentric", C.c_int32),
         ("depth_is_distance", C.c_int32), ("inv_K", C.c_void_p), ("canon_sizes", C.c_void_p), ("scratch_idx", C.c_void_p),
         ("scratch_score", C.c_void_p), ("scratch_off", C.c_int64 * MAX_LEVELS), ("scratch_img_stride", C.c_int64),
-        ("cand", C.c_void_p), ("counts", C.c_void_p), ("npass", C.c_void_p)
+        ("cand", C.c_void_p), ("counts", C.c_void_p), ("npass", C.c_void_p), ("slot_off", C.c_int32 * (MAX_LEVELS + 1))
     ]
 
 
@@ -94,7 +94,7 @@ class NmsArgs(C.Structure):
         ("do_nms", C.c_int32), ("use_score3d", C.c_int32), ("nms_thresh", C.c_float), ("post_topk", C.c_int32),
         ("do_postprocess", C.c_int32), ("out_size", C.c_void_p), ("sort_idx", C.c_void_p), ("sbox", C.c_void_p),
         ("scls", C.c_void_p), ("mask", C.c_void_p), ("nvalid", C.c_void_p), ("det", C.c_void_p), ("det_count", C.c_void_p),
-        ("det_cap", C.c_int32)
+        ("det_cap", C.c_int32), ("slot_off", C.c_int32 * (MAX_LEVELS + 1))
     ]
 
 

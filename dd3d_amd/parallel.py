@@ -2,13 +2,13 @@
 
 The reference's inference uses no device collective (each rank evaluates its shard, pickled results are gathered
 over gloo at evaluation time: tridet/data/build.py:75-93, kitti_3d_evaluator.py:154-161).  The north star adds one:
-every rank decodes the candidates of its own images, then a single RCCL ``all_gather`` (xGMI) of the
-fixed-capacity candidate buffer + its count header precedes the batched NMS, so that images that must meet
-before suppression (the 6 cameras of a nuScenes sample, nuscenes_dd3d.py:448-465) are co-located no matter
-which GPU produced them.  The payload is small (<= 400 KB per image) and latency-bound, hence one fused
-``all_gather_into_tensor`` per tensor instead of bucketed rings.
+every rank decodes the candidates of its own images, then ONE RCCL ``all_gather_into_tensor`` (xGMI) of each rank's
+record -- [candidates | per-level counts | resize targets], fixed capacity, <= 330 KB per KITTI image -- precedes the
+batched NMS, which every rank then runs for the images it owns, out of its segment of the gathered buffer (no rank
+repeats another rank's NMS).  The payload is latency-bound: one call, no bucketing.
 
-Rank r owns the global images ``[r*B, (r+1)*B)`` (rank-major order == gather order).
+Rank r owns the global images ``[r*B, (r+1)*B)`` (rank-major order == gather order); the cameras of a nuScenes
+sample stay on one rank, as the reference's InferenceGroupSampler keeps them (group_sampler.py:30-35).
 """
 import os
 
@@ -45,8 +45,8 @@ def owner_of_image(g, B):
 
 
 def gather_candidates(pairs, group=None):
-    """The step's only exchange: all_gather the local candidate buffer [B,F,NS], its per-level counts [B,L], the resize
-    targets [B,4] into the rank-major global buffers [W*B, ...].  `pairs` = ForwardPlan.gather_pairs()."""
+    """The step's only exchange: all_gather every rank's record (ForwardPlan.gather_pairs(): one (record, [W x record]) pair) into
+    the rank-major gathered buffer."""
     staged = dist.get_backend(group) == "gloo" and pairs[0][0].is_cuda
     for local, glob in pairs:
         if staged:
@@ -61,7 +61,7 @@ def gather_candidates(pairs, group=None):
 
 class DistributedForward:
     """Drives a ``ForwardPlan(world_size=W)``: [hipGraph: preprocess .. select/decode] -> RCCL all_gather ->
-    [batched NMS over all W*B images].  Every rank ends up with every image's detections and returns its own."""
+    [batched NMS of the rank's own images, read out of the gathered buffer]."""
     def __init__(self, model, B, Hp, Wp, use_graph=True, force_exchange=False):
         self.model = model
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -100,7 +100,7 @@ class DistributedForward:
     def forward(self, batched_inputs):
         plan, image_sizes = self.model.stage_inputs(batched_inputs, plan=self.plan)
         self.step()
-        return self.model.collect(plan, batched_inputs, image_sizes, first=self.rank * self.B)
+        return self.model.collect(plan, batched_inputs, image_sizes)
 
 
 class PipelinedForward:
@@ -194,7 +194,7 @@ class PipelinedForward:
 
     def result(self, slot):
         slot.post_done.synchronize()
-        out = self.model.collect(slot.plan, slot.inputs, slot.image_sizes, first=self.rank * self.B)
+        out = self.model.collect(slot.plan, slot.inputs, slot.image_sizes)
         slot.released.record()  # the copies out of the detection buffer are enqueued: later steps of this slot order after them
         return out
 

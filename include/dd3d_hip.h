@@ -241,7 +241,7 @@ int dd3d_upsample2x_add_nhwc(float* fine, const float* coarse, int32_t B, int32_
  *   cls  [B*HW][cls_pitch]  : logits 0..C-1
  *   box2d[B*HW][b2d_pitch]  : relu(scale*reg) 0..3, centerness logit 4
  *   box3d[B*HW][b3d_pitch]  : quat 4*C3 (comp*C3+cls), ctr 2*C3, depth C3, size 3*C3, conf C3
- * Output (per image b): cand[b][f][level*topk + j], f < DD3D_CAND_FIELDS:
+ * Output (per image b): cand[b][f][slot_off[level] + j], f < DD3D_CAND_FIELDS:
  *   0-3 box x1,y1,x2,y2 | 4 score=sqrt(cls*ctr) | 5 score_3d | 6 class (int bits) | 7 loc*C+class (int bits)
  *   8-9 location x,y | 10-13 quat wxyz (egocentric) | 14-15 proj_ctr | 16 depth | 17-19 size WLH
  *   20 argmax attribute (int bits) | 21 speed      (nuScenes; NuscenesInference, nuscenes_dd3d.py:268-296)
@@ -270,9 +270,12 @@ typedef struct dd3d_select_args {  /* host memory */
   float* scratch_score;
   int64_t scratch_off[DD3D_MAX_LEVELS]; /* element offset of level l's region for image 0 */
   int64_t scratch_img_stride;           /* elements per image */
-  float* cand;                   /* [B][DD3D_CAND_FIELDS][num_levels*topk] */
+  float* cand;                   /* [B][DD3D_CAND_FIELDS][slots per image] */
   int32_t* counts;               /* [B][num_levels] */
   int32_t* npass;                /* [B][num_levels] */
+  int32_t slot_off[DD3D_MAX_LEVELS + 1]; /* first slot of level l in an image's candidate row; slot_off[num_levels] = slots per image.
+                                    Level l needs min(topk, H*W*C) slots, so the exchanged buffer carries no slot a level can never
+                                    fill.  All zero: the dense layout l * topk (num_levels * topk slots per image). */
 } dd3d_select_args;
 int dd3d_fcos_select_decode(const dd3d_select_args* args, void* stream);
 
@@ -312,6 +315,7 @@ typedef struct dd3d_nms_args {  /* host memory */
   float* det;
   int32_t* det_count;
   int32_t det_cap;
+  int32_t slot_off[DD3D_MAX_LEVELS + 1]; /* same table as the producer of `cand` used (the select args) */
 } dd3d_nms_args;
 int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream);
 

@@ -43,8 +43,12 @@ def _worker(rank, world, port, ret):
             ok &= len(a) == len(b) and len(a) > 0 and tuple(a.image_size) == tuple(b.image_size)
             ok &= torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores_3d, b.scores_3d)
             ok &= torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.pred_boxes3d.quat, b.pred_boxes3d.quat)
-        counts = runner.plan.det_count.cpu().tolist()
-        ok &= len(counts) == world * B and all(c > 0 for c in counts)
+        counts = runner.plan.det_count.cpu().tolist()  # a rank finalises its OWN images only
+        ok &= len(counts) == B and all(c > 0 for c in counts)
+        # ... but the exchange delivered every rank's candidates: the gathered count table holds all W * B images
+        gc = runner.plan.gathered_counts().cpu()
+        ok &= gc.shape[0] == world * B and bool((gc.sum(1) > 0).all())
+        ok &= bool(torch.equal(gc[rank * B:(rank + 1) * B], runner.plan.counts.cpu()))
         dist.barrier()
     # throughput mode: two plan slots, exchange + NMS of one step under the trunk of the next, several steps in flight
     from dd3d_amd.parallel import PipelinedForward

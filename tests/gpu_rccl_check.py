@@ -51,7 +51,7 @@ def main():
             ok &= len(a) == len(b) and len(a) > 0
             ok &= torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores_3d, b.scores_3d)
             ok &= torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.pred_boxes3d.quat, b.pred_boxes3d.quat)
-    # timing of the exchange itself (three all_gather_into_tensor calls on device buffers)
+    # timing of the exchange itself (ONE all_gather_into_tensor of the rank's record)
     pairs = runner.plan.gather_pairs()
     for _ in range(5):
         gather_candidates(pairs)

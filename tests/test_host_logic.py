@@ -267,9 +267,11 @@ def test_integration_doc_stub_matches_the_abi():
     from dd3d_amd import hip
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     block = doc[doc.index("class NmsArgs(C.Structure)"):doc.index("def nms_and_top_k_hip")]
-    fields = re.findall(r'\("([A-Za-z_0-9]+)", C\.(c_[a-z0-9_]+)\)', block)
+    fields = re.findall(r'\("([A-Za-z_0-9]+)", C\.(c_[a-z0-9_]+)(?: \* (\d+))?\)', block)
     import ctypes as C
-    assert [(n, getattr(C, t)) for n, t in fields] == list(hip.NmsArgs._fields_)
+    got = [(n, getattr(C, t) * int(k) if k else getattr(C, t)) for n, t, k in fields]
+    want = list(hip.NmsArgs._fields_)
+    assert [n for n, _ in got] == [n for n, _ in want] and all(C.sizeof(a) == C.sizeof(b) for (_, a), (_, b) in zip(got, want))
     for name in re.findall(r"`(dd3d_[a-z0-9_]+)`", doc):
         assert name in hip.EXPORTS or name in ("dd3d_hip", "dd3d_nms_args", "dd3d_amd"), name
 
@@ -338,7 +340,7 @@ def test_cabi_argument_validation_without_a_gpu(hiplib):
     assert L.dd3d_fcos_select_decode(C.byref(a), None) != 0 and "topk=100000 exceeds" in err()
     n = hip.NmsArgs()
     n.G, n.num_levels, n.topk = 1, 5, 5000
-    assert L.dd3d_nms_finalize(C.byref(n), None) != 0 and "levels*topk=25000 exceeds" in err()
+    assert L.dd3d_nms_finalize(C.byref(n), None) != 0 and "25000 candidate slots per image exceed" in err()
     assert L.dd3d_format_boxes3d(None, None, None, None, 5, None) != 0 and "null pointer" in err()
     assert L.dd3d_format_boxes3d(None, None, None, None, 0, None) == 0  # nothing to do
     assert L.dd3d_rotate_iou_eval(None, None, None, 3, 3, -1, None) != 0 and "null pointer" in err()

@@ -1,5 +1,6 @@
-"""The N>1 path's only collective, exercised with world_size 2 on CPU (gloo): rank-major all_gather of the fixed-capacity
-candidate buffers + count headers (dd3d_amd/parallel.py)."""
+"""The N>1 path's only collective, exercised with world_size 2 on CPU (gloo) on real (dry-run) launch plans: every rank's record
+[candidates | counts | resize targets] travels in ONE all_gather_into_tensor; afterwards a rank's post-select stages read its own
+segment of the gathered buffer, and every rank can see every rank's counts (dd3d_amd/parallel.py, dd3d_amd/engine.py)."""
 import os
 import socket
 
@@ -16,24 +17,46 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, B, F, NS, L, ret):
+def _fill(plan, rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    plan.cand.copy_(torch.randn(plan.cand.shape, generator=g))
+    plan.counts.copy_(torch.randint(0, 50, plan.counts.shape, generator=g, dtype=torch.int32))
+    plan.in_outsize.fill_(float(rank) + 0.5)
+
+
+def _worker(rank, world, port, B, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.engine import ForwardPlan
     from dd3d_amd.parallel import gather_candidates, init_distributed, owner_of_image
     r, _, w = init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
-    g = torch.Generator().manual_seed(100 + rank)
-    cand = torch.randn(B, F, NS, generator=g)
-    counts = torch.randint(0, 50, (B, L), generator=g, dtype=torch.int32)
-    outsz = torch.full((B, 4), float(rank))
-    cand_all, counts_all, outsz_all = torch.zeros(world * B, F, NS), torch.zeros(world * B, L, dtype=torch.int32), torch.zeros(world * B, 4)
-    gather_candidates([(cand, cand_all), (counts, counts_all), (outsz, outsz_all)])
-    ok = True
-    for src in range(world):  # every rank can regenerate every other rank's payload
+    cfg = get_cfg("dd3d_kitti_dla34")
+    model = META_ARCH_REGISTRY.get("DD3D")(cfg)
+    plan = ForwardPlan(model, B, 128, 256, device="cpu", dry_run=True, world_size=world, rank=rank)
+    ok = plan.exchange and plan.G == B and plan.det.shape[0] == B  # a rank finalises its OWN images only
+    # trimmed capacity: level l holds min(topk, H*W*C) slots (128x256: 16x32, 8x16, 4x8, 2x4, 1x2 locations x 5 classes)
+    ok &= plan.slot_off == [0, 1000, 1640, 1800, 1840, 1850] and plan.cand.shape == (B, 22, 1850)
+    _fill(plan, rank)
+    calls = []
+    orig = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    gather_candidates(plan.gather_pairs())
+    dist.all_gather_into_tensor = orig
+    ok &= len(calls) == 1  # ONE collective per step
+    # what the NMS stages read (this rank's segment of the gathered buffer) is this rank's record
+    ok &= torch.equal(plan.cand_all, plan.cand) and torch.equal(plan.counts_all, plan.counts) and torch.equal(plan.outsize_all, plan.in_outsize)
+    ok &= plan.cand_all.data_ptr() != plan.cand.data_ptr()
+    # ... and every other rank's record arrived, rank-major
+    g = plan.gathered.view(world, plan.record_len)
+    for src in range(world):
+        other = ForwardPlan.__new__(ForwardPlan)  # regenerate src's payload
         g2 = torch.Generator().manual_seed(100 + src)
-        c2 = torch.randn(B, F, NS, generator=g2)
-        n2 = torch.randint(0, 50, (B, L), generator=g2, dtype=torch.int32)
-        ok &= torch.equal(cand_all[src * B:(src + 1) * B], c2) and torch.equal(counts_all[src * B:(src + 1) * B], n2)
-        ok &= bool((outsz_all[src * B:(src + 1) * B] == src).all())
+        c2 = torch.randn(plan.cand.shape, generator=g2)
+        n2 = torch.randint(0, 50, plan.counts.shape, generator=g2, dtype=torch.int32)
+        ok &= torch.equal(g[src, :c2.numel()].view(c2.shape), c2)
+        ok &= torch.equal(plan.gathered_counts()[src * B:(src + 1) * B], n2)
         ok &= all(owner_of_image(gi, B) == src for gi in range(src * B, (src + 1) * B))
     ret[rank] = bool(ok)
     dist.barrier()
@@ -41,8 +64,8 @@ def _worker(rank, world, port, B, F, NS, L, ret):
 
 
 def test_gather_candidates_gloo_world2():
-    world, B, F, NS, L = 2, 3, 22, 40, 5
+    world, B = 2, 3
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, F, NS, L, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), B, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}

@@ -72,7 +72,7 @@ def candidates_from_plan(plan, b=0):
     import numpy as np
     cand = plan.cand[b].cpu()
     counts = plan.counts[b].cpu().tolist()
-    slots = torch.cat([torch.arange(c) + l * plan.topk for l, c in enumerate(counts)]).long()
+    slots = torch.cat([torch.arange(c) + plan.slot_off[l] for l, c in enumerate(counts)]).long()
     c = cand[:, slots]
     ints = lambda row: torch.from_numpy(c[row].numpy().view(np.int32).copy()).long()
     return dict(
