@@ -7,9 +7,9 @@
 A step = one forward pass of the hot path (uint8 image already resident in HBM -> final detections in HBM) over one
 batch of synthetic 384x1280 KITTI-shaped frames, ``--batch`` images per GPU (default 1 = BASELINE.json configs[1]
 "DD3D-DLA34 KITTI3D 384x1280 bs=1 fp32 inference"; one image per GPU per step as the north star shards them).
-For N > 1 every rank forwards its own images and the step includes the RCCL all_gather of the decoded candidates and
-the batched NMS over all N*batch images (dd3d_amd/parallel.py).  Steps are issued through PipelinedForward (default: four plan
-slots on four compute streams + one exchange/NMS stream, so several single-image steps are in flight and share the chip, and the
+For N > 1 every rank forwards its own images and the step includes ONE RCCL all_gather of every rank's decoded-candidate record, after
+which each rank runs the batched NMS of the images it owns (dd3d_amd/parallel.py).  Steps are issued through PipelinedForward (default:
+sixteen plan slots on sixteen compute streams + one exchange/NMS stream, so several single-image steps are in flight and share the chip, and the
 collective runs under the next steps' trunks; `--pipeline 0` issues one step at a time and that figure is also reported in
 `config`); every one of the K timed steps does all of its work and is complete before the closing synchronize.
 
@@ -56,10 +56,10 @@ def parse_args():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DD3D_BENCH_PIPELINE", "4")),
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DD3D_BENCH_PIPELINE", "16")),
                     help="plan slots of dd3d_amd.parallel.PipelinedForward (exchange + NMS of step i overlap the trunk of step i+1); "
                          "0 = one step at a time")
-    ap.add_argument("--compute-streams", type=int, default=int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "4")),
+    ap.add_argument("--compute-streams", type=int, default=int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "16")),
                     help="PipelinedForward: streams the slots' trunks are issued on (> 1 lets consecutive steps share the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=200, help="upper bound; the CPU leg stops after ~12 s of work")

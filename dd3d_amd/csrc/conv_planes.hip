@@ -63,6 +63,9 @@ __device__ __forceinline__ void sched_uniform() {
 #ifndef DD3D_PREFETCH_DISTANCE
 #define DD3D_PREFETCH_DISTANCE 0  // K-tiles between the L2 touch of a tile and its DMA (0: no touch).  Measured: the touches only add VMEM instructions (towers 110 -> 115 us, small convs 22 -> 31 us): the loop is bound by DMA instruction throughput, not by miss latency
 #endif
+#ifndef DD3D_PRODUCER_WAVES
+#define DD3D_PRODUCER_WAVES 0  // loader waves of the warp-specialised form (0: every wave loads and computes)
+#endif
 #ifndef DD3D_LDS_KIB_8W
 #define DD3D_LDS_KIB_8W 144
 #endif
@@ -73,17 +76,22 @@ __device__ __forceinline__ void sched_uniform() {
 #define DD3D_SCHED_VARIANT 1  // 0: DMA burst right after the barrier; 1: evenly spread over the phase; 2: spread over both phases of a step (NS >= 3)
 #endif
 
-template <int TM, int TN, int WM, int WN, int NS, int MODE, bool SK>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const ConvKArgs a) {
+// PW > 0: warp-specialised form -- PW extra LOADER waves (one per SIMD) issue every LDS-DMA of the block and the WM x WN compute waves
+// only read fragments and issue MFMAs.  An LDS-DMA instruction holds its wave's issue slot for ~60-180 cycles (address path), and in
+// the unspecialised loop all waves pay that at the same moment (right after the barrier): measured on the head towers, DMA-only loop
+// 55 us, MFMA-only loop 65 us, both in every wave 82 us (zero operands).  Loaders and compute waves meet at the same one barrier per K-tile.
+template <int TM, int TN, int WM, int WN, int NS, int MODE, bool SK, int PW = 0>
+__global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(const ConvKArgs a) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BM = TM * 32 * WM;
   constexpr int BN = TN * 32 * WN;
   constexpr int NW = WM * WN;
-  constexpr int NTHR = 64 * NW;
+  constexpr int NTHR = 64 * NW;      // compute threads (the accumulator / split-K layouts are theirs)
+  constexpr int NL = PW > 0 ? PW : NW;  // waves that issue DMA
   constexpr int PLA = BM * 64, PLB = BN * 64;      // bytes per plane of a stage
   constexpr int A_BYTES = NP * PLA, STAGE = NP * (PLA + PLB);
   constexpr int RA = BM / 16, RB = BN / 16;        // 16-row blocks (one 1-KiB DMA piece per plane)
-  constexpr int QN = (RA + RB + NW - 1) / NW;      // row blocks per wave (the surplus re-fetches the last block)
+  constexpr int QN = (RA + RB + NL - 1) / NL;      // row blocks per loading wave (the surplus re-fetches the last block)
   constexpr int P = QN * NP;                       // DMA instructions per wave and K-tile
   static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS ring");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -93,8 +101,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN;
-  const int wn = wave - wm * WN;
+  const bool loader = PW > 0 && wave >= NW;          // wave-uniform role
+  const int lw = PW > 0 ? (wave >= NW ? wave - NW : 0) : wave;  // index among the loading waves
+  const int wm = (wave < NW ? wave : 0) / WN;
+  const int wn = (wave < NW ? wave : 0) - wm * WN;
 
   const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
   const int mt = bid / a.nn;
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
     const int howo = s.Ho * s.Wo;
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
-      const int r = min(q * NW + wave, RA + RB - 1);
+      const int r = min(q * NL + lw, RA + RB - 1);
       q_isA[q] = r < RA;
       q_dst[q] = r < RA ? r * 1024 : A_BYTES + (r - RA) * 1024;
       q_pst[q] = r < RA ? PLA : PLB;
@@ -294,6 +304,54 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
   constexpr std::integral_constant<int, 0> C0{};
   constexpr std::integral_constant<int, 1> C1{};
 
+  if constexpr (PW > 0) {
+    if (ntile > 0) {
+      if (loader) {
+        // ---- loader waves: ring fill, then per K-tile: addresses -> [tile kt+1 landed] -> barrier -> DMA of tile kt+NS
+#pragma unroll
+        for (int d = 0; d < NS; ++d) {
+          prepare();
+          emit(d, Q0, QALL);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * P) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int stage = 0;
+        for (int kt = 0; kt < ntile; ++kt) {
+          prepare();
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * P) : "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          emit(stage, Q0, QALL);
+          stage = stage == NS - 1 ? 0 : stage + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus fetches land before the block may release its LDS
+        return;
+      }
+      // ---- compute waves: fragments + MFMAs only
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_frags(0, C0);
+      int stage = 0;
+      constexpr int NM = TM * TN * NPROD, NDS = (TM + TN) * NP;
+      for (int kt = 0; kt < ntile; ++kt) {
+        read_frags(stage, C1);
+        mfma_chunk(C0);
+        sched_uniform<NM, NDS, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        stage = stage == NS - 1 ? 0 : stage + 1;
+        read_frags(stage, C0);
+        mfma_chunk(C1);
+        sched_uniform<NM, NDS, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if (loader) {
+      return;
+    }
+  } else
   if (ntile > 0) {
     // prologue: fill the ring (tiles 0 .. NS-1; variant 2 leaves the second part of tile NS-1 to the first step), wait for tile 0
 #pragma unroll
@@ -359,7 +417,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_kernel(const C
 template <int TM, int TN, int WM, int WN, int MODE>
 static int launch_planes_tile(const ConvKArgs& ka, hipStream_t st) {
   constexpr int NP = Planes<MODE>::NP;
-  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
+  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
+  // loader waves (warp-specialised form) for the big 8-wave tiles, whose blocks own a CU for hundreds of K-tiles
+  constexpr int PW = (WM * WN == 8 && TM * TN >= 2) ? DD3D_PRODUCER_WAVES : 0;
+  constexpr int NTHR = 64 * (WM * WN + PW);
   constexpr int STAGE = NP * (BM + BN) * 64;
   // LDS ring budgets (KiB): what a block may take decides how many blocks -- of this launch or of another stream's -- share a CU
   constexpr int BUDGET = (WM * WN == 8 ? DD3D_LDS_KIB_8W : DD3D_LDS_KIB_4W) * 1024;
@@ -369,14 +430,14 @@ static int launch_planes_tile(const ConvKArgs& ka, hipStream_t st) {
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false, PW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true, PW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true>), grid, dim3(NTHR), lds, st, ka);
-  else hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false>), grid, dim3(NTHR), lds, st, ka);
+  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true, PW>), grid, dim3(NTHR), lds, st, ka);
+  else hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false, PW>), grid, dim3(NTHR), lds, st, ka);
   return check_launch("conv_igemm_planes kernel");
 }
 

@@ -17,6 +17,8 @@ from dd3d_amd import build_model, get_cfg  # noqa: E402
 from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict  # noqa: E402
 
 CASES = [("dd3d_kitti_v99", "v99_kitti", "kitti", 1, 384, 1280), ("dd3d_kitti_v99", "v99_kitti", "kitti", 4, 384, 1280),
+         # BASELINE.json configs[2]: DD3D-V2-99 KITTI3D 384x1280 bs=16
+         ("dd3d_kitti_v99", "v99_kitti", "kitti", 16, 384, 1280),
          ("dd3d_nusc_dla34", "dla34_nusc", "nusc", 6, 896, 1600), ("dd3d_kitti_dla34", "dla34_kitti", "kitti", 8, 384, 1280),
          # BASELINE.json configs[3] per GPU: V2-99 on one 6-camera nuScenes sample (900 x 1600 -> 896 x 1593, padded to /64)
          ("dd3d_nusc_v99", "v99_nusc", "nusc", 6, 896, 1600)]
@@ -46,7 +48,7 @@ def main():
         e1.synchronize()
         ms = e0.elapsed_time(e1) / n
         gmac = plan.conv_macs / 1e9
-        print(f"{exp:18s} B={B} {H}x{W}: {ms:8.3f} ms/forward = {B / ms * 1e3:7.1f} img/s, {2 * gmac / ms:7.1f} TFLOP/s, dets {[len(o['instances']) for o in out]}, "
+        print(f"{exp:18s} math={os.environ.get('DD3D_MATH', 'f16x2'):7s} B={B} {H}x{W}: {ms:8.3f} ms/forward = {B / ms * 1e3:7.1f} img/s, {2 * gmac / ms:7.1f} TFLOP/s, dets {[len(o['instances']) for o in out]}, "
               f"plan build {t_build:.1f} s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB, ops {len(plan.ops)}", flush=True)
         del model, plan, out
         torch.cuda.empty_cache()

@@ -213,3 +213,59 @@ def test_pool_and_topdown_write_their_planes(hiplib, mode):
         tol = {hip.MATH_F16X2: 2.0**-21, hip.MATH_BF16X2: 2.0**-15}[math]
         assert float((dec - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-8
     assert torch.all(yb.p[0] == 0) and torch.all(yb.p[3] == 0)  # neighbouring chunk images untouched
+
+
+def test_split_modes_against_float64(hiplib):
+    """Error of every arithmetic mode against a float64 convolution of the same f32 data.  The two f32-equivalent split modes -- bf16x3
+    (three bf16 terms, 6 products) and f16x2 (two IEEE-half terms, 3 products) -- must sit at f32 rounding level like the exact-f32 MFMA
+    kernel (measured on MI355X: f32 4.1e-7, bf16x3 3.7e-7, f16x2 3.4e-7 of max |ref|; bf16x2 4.7e-6; bf16 2.2e-3)."""
+    from dd3d_amd.engine import ConvOp, pack_filter
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 1, 24, 40, 256, 256
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 48.0
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    err = {}
+    for name, math in [("f32", hip.MATH_F32)] + [(k, v[0]) for k, v in MODES.items()]:
+        plan = _plan(math)
+        wp, meta = pack_filter(w, plan.device)
+        xin, yout = plan.buf("x", B, H, W, Cin, kind="both"), plan.buf("y", B, H, W, Cout)
+        xin.t.copy_(x.permute(0, 2, 3, 1))
+        if plan.use_planes:
+            plan.split(xin.view(), name="x.split")
+        ones, zeros = torch.ones(Cout, device=plan.device), torch.zeros(Cout, device=plan.device)
+        plan.ops.append(ConvOp(plan, meta, 1, 1, [{"in": xin.view(), "out": yout.view(), "w": wp, "scale": ones, "bias": zeros}], False, name="acc"))
+        plan.launch()
+        torch.cuda.synchronize()
+        err[name] = float((yout.nchw().cpu().double() - ref).abs().max() / ref.abs().max())
+    print("max |err| / max |ref| vs float64: " + "  ".join(f"{k} {v:.2e}" for k, v in err.items()))
+    assert err["f32"] < 2e-6
+    for mode in ("bf16x3", "f16x2"):
+        assert err[mode] < 2e-6 and err[mode] < 3 * err["f32"] + 2e-7, (mode, err)
+    assert err["bf16x2"] < 5e-5 and 1e-4 < err["bf16"] < 2e-2
+
+
+def test_f16x2_keeps_small_and_large_magnitudes(hiplib):
+    """The half-term split inside its range: activations spanning 1e-4 .. 3.5e3 (plane scale 16: the half format holds 65504 / 16) and
+    filters spanning six decades per row stay at f32-level accuracy relative to the result, because the per-row filter scale and the
+    plane scale are powers of two that leave through the epilogue exactly."""
+    from dd3d_amd.engine import ConvOp, pack_filter
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Cin, Cout = 1, 12, 20, 128, 64
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.logspace(-4, 2.9, Cin).view(1, Cin, 1, 1)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * torch.logspace(-6, 0, Cout).view(Cout, 1, 1, 1)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    plan = _plan(hip.MATH_F16X2)
+    wp, meta = pack_filter(w, plan.device)
+    xin, yout = plan.buf("x", B, H, W, Cin, kind="both"), plan.buf("y", B, H, W, Cout)
+    xin.t.copy_(x.permute(0, 2, 3, 1))
+    plan.split(xin.view(), name="x.split")
+    ones, zeros = torch.ones(Cout, device=plan.device), torch.zeros(Cout, device=plan.device)
+    plan.ops.append(ConvOp(plan, meta, 1, 1, [{"in": xin.view(), "out": yout.view(), "w": wp, "scale": ones, "bias": zeros}], False, name="range"))
+    plan.launch()
+    torch.cuda.synchronize()
+    assert int(plan.status.cpu()) == 0
+    got = yout.nchw().cpu().double()
+    # per output channel (rows differ by six decades): error relative to that channel's largest output
+    rel = ((got - ref).abs().amax((0, 2, 3)) / ref.abs().amax((0, 2, 3)))
+    assert float(rel.max()) < 3e-6, rel
