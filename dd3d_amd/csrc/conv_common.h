@@ -281,7 +281,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
   }
 }
 
+// ---- instruction-scheduling pattern of one phase of a K step (sched_group_barrier: 0x008 MFMA, 0x010 VMEM, 0x100 DS read)
+// NMFMA matrix instructions with NDMA LDS-DMA issues and NDS fragment reads spread EVENLY among them (the DMAs evenly among those): all
+// eight waves of a block leave the barrier together, and eight back-to-back bursts of LDS-DMA issues queue up in the CU's one
+// address / texture path while the matrix pipe starves; one issue every few MFMAs keeps that path short.
+template <int NMFMA, int NDS, int NDMA>
+__device__ __forceinline__ void sched_uniform() {
+  constexpr int NX = NDS + NDMA;
+  int placed = 0, dma = 0;
+#pragma unroll
+  for (int i = 0; i < NMFMA; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    const int upto = ((i + 1) * NX) / NMFMA;  // other operations due after MFMA i
+#pragma unroll
+    for (; placed < upto; ++placed) {
+      const bool is_dma = NDMA > 0 && ((placed + 1) * NDMA) / NX > (placed * NDMA) / NX;
+      if (is_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0), ++dma;
+      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  }
+}
+
+template <int NMFMA, int NDS, int NDMA>
+__device__ __forceinline__ void sched_barrier_phase() {
+  sched_uniform<NMFMA, NDS, NDMA>();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- launchers implemented in the kernel translation units
 int launch_conv_planes(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st);  // conv_planes.hip
+bool conv_planes_row_applicable(const ConvKArgs& ka);                                          // conv_planes_row.hip
+int launch_conv_planes_row(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st);
 
 }  // namespace dd3d

@@ -894,6 +894,9 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   if (L->in_planes) {
     DD3D_REQUIRE(L->math_mode != DD3D_MATH_F32 && !smallc && L->zero_page && !L->in_relu,
                  "dd3d_conv2d_igemm_f32: split-plane input needs a split-operand math mode, Cin %% 32 == 0, a zero page and no in_relu");
+    // 3x3 / stride 1: the three taps of a filter row share one A stage (conv_planes_row.hip); DD3D_CONV_ROW=0 keeps the per-tap gather
+    const int use_row = env_int("DD3D_CONV_ROW", 1);  // (read per call: the tests drive both kernels in one process)
+    if (use_row && conv_planes_row_applicable(ka)) return launch_conv_planes_row(ka, L->math_mode, L->tile_cfg, st);
     return launch_conv_planes(ka, L->math_mode, L->tile_cfg, st);
   }
   DD3D_REQUIRE(L->math_mode == DD3D_MATH_F32 || L->math_mode == DD3D_MATH_BF16X3,

@@ -40,26 +40,6 @@ __device__ __forceinline__ void sched_interleave() {
   if constexpr (NMFMA > NPAIR) __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NPAIR, 0);
 }
 
-// The same, with the NDMA + NDS other operations spread EVENLY over the NMFMA matrix instructions (the DMAs evenly among them): all
-// eight waves of a block leave the barrier together, and eight back-to-back bursts of LDS-DMA issues queue up in the CU's one
-// address / texture path while the matrix pipe starves; one issue every few MFMAs keeps that path short.
-template <int NMFMA, int NDS, int NDMA>
-__device__ __forceinline__ void sched_uniform() {
-  constexpr int NX = NDS + NDMA;
-  int placed = 0, dma = 0;
-#pragma unroll
-  for (int i = 0; i < NMFMA; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    const int upto = ((i + 1) * NX) / NMFMA;  // other operations due after MFMA i
-#pragma unroll
-    for (; placed < upto; ++placed) {
-      const bool is_dma = NDMA > 0 && ((placed + 1) * NDMA) / NX > (placed * NDMA) / NX;
-      if (is_dma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0), ++dma;
-      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-  }
-}
-
 #ifndef DD3D_PREFETCH_DISTANCE
 #define DD3D_PREFETCH_DISTANCE 0  // K-tiles between the L2 touch of a tile and its DMA (0: no touch).  Measured: the touches only add VMEM instructions (towers 110 -> 115 us, small convs 22 -> 31 us): the loop is bound by DMA instruction throughput, not by miss latency
 #endif

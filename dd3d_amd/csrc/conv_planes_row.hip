@@ -1,0 +1,330 @@
+// 3x3 / stride 1 / pad 1 implicit-GEMM convolution on split-plane operands in which THE THREE TAPS OF A FILTER ROW SHARE ONE A STAGE.
+//
+// conv_planes.hip streams, for every K-tile (32 channels of ONE tap), the A rows of the block's output pixels shifted by that tap:
+// nine fetches of (nearly) the same pixels per channel chunk.  Its loop is bound by the LDS-DMA instructions a CU can issue (measured:
+// step time ~ 57 cycles x DMA instructions per CU, profiles/r02_conv_ablation.txt), not by the matrix pipe.  Here the K order is
+// (chunk, dh, dw) with dw innermost, and an A stage holds the BM + 2 consecutive input pixels
+//     q = m0 - 1 + j + (dh - 1) W ,   j = 0 .. BM + 1      (flattened (b, h, w) index, stride 1: input and output share it)
+// of one (chunk, dh); tap dw of output row r reads LDS row r + dw.  One A fetch serves three K-tiles: 17 row blocks per three steps
+// instead of 48 (256-row tile) -- 39 % fewer DMA instructions per MFMA for the two-term modes.
+//
+// What the per-tap gather gave for free is now explicit: a flattened neighbour is a real neighbour only inside the image, so every lane
+// carries a 9-bit validity mask of its output pixels (0 <= ho + dh - 1 < H, 0 <= wo + dw - 1 < W, m < M) and points the fragment read of
+// an invalid (pixel, tap) at 16 zero bytes in LDS (one address select per read) -- the same zeros the zero page supplied.
+//
+// Rings: two A stages (an A stage lives for three steps, so its successor has three steps to land) and NSB B stages (one per K-tile,
+// as in conv_planes.hip).  One barrier per K-tile between the MFMA groups of its two 16-k chunks, DMA addresses computed before it.
+#include <cstring>
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace dd3d {
+
+template <int TM, int TN, int WM, int WN, int NSB, int MODE, bool SK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(const ConvKArgs a) {
+  constexpr int NP = Planes<MODE>::NP;
+  constexpr int BM = TM * 32 * WM;
+  constexpr int BN = TN * 32 * WN;
+  constexpr int NW = WM * WN;
+  constexpr int NTHR = 64 * NW;
+  constexpr int AROWS = BM + 16;                   // BM + 2 used; whole 16-row DMA blocks
+  constexpr int PLA = AROWS * 64, PLB = BN * 64;   // bytes per plane of an A / B stage
+  constexpr int A_STAGE = NP * PLA, B_STAGE = NP * PLB;
+  constexpr int B_BASE = 2 * A_STAGE;
+  constexpr int NPA = (AROWS / 16) * NP, NPB = (BN / 16) * NP;  // 1-KiB pieces of an A stage / a B stage
+  constexpr int PA = (NPA + NW - 1) / NW, PB = (NPB + NW - 1) / NW;  // per wave (the surplus re-fetches the last piece)
+  static_assert(NSB >= 2 && NSB <= 3 && B_BASE + NSB * B_STAGE + 64 <= 160 * 1024, "LDS rings");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
+  typedef unsigned char __attribute__((address_space(3))) * ldsbp;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+
+  const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
+  const int mt = bid / a.nn;
+  const int nt = bid - mt * a.nn;
+  int m0 = mt * BM;
+  dd3d_conv_seg s = a.seg0;
+  if (!a.single) {
+    m0 = a.tiles[2 * mt + 1];
+    s = a.segs[a.tiles[2 * mt]];
+  }
+  const int n0 = nt * BN;
+  const gcbp g_in = (gcbp)s.in_planes;
+  const gcbp g_w = (gcbp)s.w;
+  const gcbp g_zero = (gcbp)a.zeros;
+
+  const int nk = a.Kpad / BK;  // 9 * chunks
+  int kt_begin = 0, kt_end = nk;
+  if (SK) {  // (the host only picks this kernel when kt_per_split is a multiple of 3: slices start on a filter row)
+    kt_begin = blockIdx.y * a.kt_per_split;
+    kt_end = min(nk, kt_begin + a.kt_per_split);
+  }
+  const int ngroup = (kt_end - kt_begin) / 3;
+  const int g_begin = kt_begin / 3;  // group index = chunk * 3 + dh
+
+  // ---- DMA geometry.  lane -> (row = lane >> 2 of a 16-row piece, LDS slot = lane & 3 holding k-slot (lane & 3) ^ ((lane >> 4) & 3))
+  const int slot16 = (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  const long npix = (long)s.B * s.H * s.W;
+  const long in_cstride = npix * (NP * 64);
+  // A pieces of this wave: piece = q * NW + wave -> (row block, plane); the lane's LDS row j holds input pixel m0 - 1 + j (+ (dh-1) W)
+  int a_pix[PA];   // m0 - 1 + j of this lane
+  int a_dst[PA];   // wave-uniform LDS byte offset inside an A stage
+  int a_pl[PA];    // wave-uniform plane
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int piece = min(q * NW + wave, NPA - 1);
+    const int rb = piece / NP, pl = piece - rb * NP;
+    a_pl[q] = pl;
+    a_dst[q] = pl * PLA + rb * 1024;
+    a_pix[q] = m0 - 1 + rb * 16 + (lane >> 2);
+  }
+  gcbp b_src[PB];  // this lane's filter row, K-tile 0, plane and k-slot included
+  int b_dst[PB];
+#pragma unroll
+  for (int q = 0; q < PB; ++q) {
+    const int piece = min(q * NW + wave, NPB - 1);
+    const int rb = piece / NP, pl = piece - rb * NP;
+    const int n = min(n0 + rb * 16 + (lane >> 2), a.Npad - 1);  // rows past Npad feed columns >= N, which are never stored
+    b_dst[q] = B_BASE + pl * PLB + rb * 1024;
+    b_src[q] = g_w + (long)n * nk * (NP * 64) + pl * 64 + slot16;
+  }
+
+  // ---- streams: A walks the groups (chunk, dh), B walks the K-tiles; past the end both re-fetch their last element (exact DMA counts)
+  int ld_g = g_begin, ld_kt = kt_begin;
+  gcbp nxt_a[PA];
+  auto prepare_a = [&]() {  // addresses of group ld_g, then advance
+    const int chunk = ld_g / 3, dh = ld_g - chunk * 3;
+    const long base = (long)chunk * in_cstride + slot16;
+    const int shift = (dh - 1) * s.W;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const long p = (long)a_pix[q] + shift;
+      const bool ok = (unsigned long)p < (unsigned long)npix;
+      nxt_a[q] = ok ? g_in + base + p * (NP * 64) + a_pl[q] * 64 : g_zero + slot16;
+    }
+    ld_g += (ld_g + 1 < g_begin + ngroup);
+  };
+  auto emit_a = [&](int stage) {
+#pragma unroll
+    for (int q = 0; q < PA; ++q)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)nxt_a[q], (ldsbp)(lds + stage * A_STAGE + a_dst[q]), 16, 0, 0);
+  };
+  auto emit_b = [&](int stage) {  // K-tile ld_kt, then advance
+    const long koff = (long)ld_kt * (NP * 64);
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(b_src[q] + koff), (ldsbp)(lds + stage * B_STAGE + b_dst[q]), 16, 0, 0);
+    ld_kt += (ld_kt + 1 < kt_end);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment addressing.  A: LDS row (wave rows + lrow + dw); B: as conv_planes.hip
+  const int lrow = lane & 31;
+  const int kh = lane >> 5;
+  int fa_off[3][2];  // [dw][chunk]
+#pragma unroll
+  for (int dw = 0; dw < 3; ++dw) {
+    const int row = wm * TM * 32 + lrow + dw;
+    const int swz = (row >> 2) & 3;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) fa_off[dw][c] = row * 64 + (((2 * c + kh) ^ swz) << 4);
+  }
+  const int swzb = (lrow >> 2) & 3;
+  const int fb_off[2] = {(wn * TN * 32 + lrow) * 64 + (((0 + kh) ^ swzb) << 4), (wn * TN * 32 + lrow) * 64 + (((2 + kh) ^ swzb) << 4)};
+
+  // ---- validity of (output pixel, tap): bit dh * 3 + dw
+  unsigned vmask[TM];
+  {
+    const int howo = s.Ho * s.Wo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + (wm * TM + i) * 32 + lrow;
+      unsigned mk = 0;
+      if (m < s.M) {
+        const int b = m / howo;
+        const int rr = m - b * howo;
+        const int ho = rr / s.Wo;
+        const int wo = rr - ho * s.Wo;
+        const unsigned vrow[3] = {(unsigned)(ho > 0), 1u, (unsigned)(ho + 1 < s.H)};
+        const unsigned hcol = (unsigned)(wo > 0) | 2u | ((unsigned)(wo + 1 < s.W) << 2);
+        mk = (vrow[0] * hcol) | ((vrow[1] * hcol) << 3) | ((vrow[2] * hcol) << 6);
+      }
+      vmask[i] = mk;
+    }
+  }
+
+  bf16x8 fa[2][TM][NP], fb[2][TN][NP];
+  // An invalid (pixel, tap) reads 16 zero bytes kept behind the rings instead of its LDS row: one address select per fragment read,
+  // computed before the read is issued (masking the loaded registers would make every MFMA phase wait for its own prefetch).
+  constexpr int ZERO_OFF = B_BASE + NSB * B_STAGE;
+  auto read_frags = [&](int sa, int sb, int dw, int tap, auto c_c) {
+    constexpr int c = decltype(c_c)::value;
+    const int abase = sa * A_STAGE + fa_off[dw][c];
+    const unsigned char* Bs = lds + B_BASE + sb * B_STAGE + fb_off[c];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const bool ok = (vmask[i] >> tap) & 1u;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int off = ok ? abase + p * PLA + i * 32 * 64 : ZERO_OFF;
+        fa[c][i][p] = *reinterpret_cast<const bf16x8*>(lds + off);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) fb[c][j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PLB + j * 32 * 64);
+  };
+  constexpr int NPROD = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
+  constexpr int PA_[6] = {NP == 3 ? 2 : (NP == 2 ? 1 : 0), 0, NP == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int PB_[6] = {0, NP == 3 ? 2 : (NP == 2 ? 1 : 0), NP == 3 ? 1 : 0, 0, 1, 0};
+  auto mfma_chunk = [&](auto c_c) {
+    constexpr int c = decltype(c_c)::value;
+#pragma unroll
+    for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if constexpr (Planes<MODE>::F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[c][i][PA_[t]]), __builtin_bit_cast(f16x8, fb[c][j][PB_[t]]),
+                                                               acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][i][PA_[t]], fb[c][j][PB_[t]], acc[i][j], 0, 0, 0);
+  };
+  constexpr std::integral_constant<int, 0> C0{};
+  constexpr std::integral_constant<int, 1> C1{};
+
+  if (tid < 4) reinterpret_cast<int*>(lds + ZERO_OFF)[tid] = 0;  // (visible to every wave after the prologue's barrier)
+  if (ngroup > 0) {
+    // prologue, in issue order: A(group 0) -> A stage 0 | B(tiles 0 .. NSB-1) | A(group 1) -> A stage 1.  Wait for A(0) and B(0).
+    prepare_a();
+    emit_a(0);
+#pragma unroll
+    for (int d = 0; d < NSB; ++d) emit_b(d);
+    prepare_a();
+    emit_a(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 1) * PB + PA) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, 0, (g_begin % 3) * 3, C0);
+    int sb = 0;
+    // One step = one K-tile (filter row dh, column dw).  DMA issue order after the prologue: step s issues B(s + NSB) and, when dw == 2
+    // (the group's A stage has just been read for the last time), A(group + 2) behind it.  "B(s+1) has landed" at step s therefore
+    // means: at most the B tiles s+2 .. s+NSB-1 and the A groups issued in steps s+1-NSB .. s-1 are still in flight.
+    auto step = [&](int sa, int dh, auto dw_c) {
+      constexpr int dw = decltype(dw_c)::value;
+      const int tap = dh * 3 + dw;
+      // ---- phase A: chunk-1 fragments under the chunk-0 MFMAs; addresses of the next A group (used after the barrier when dw == 2)
+      read_frags(sa, sb, dw, tap, C1);
+      mfma_chunk(C0);
+      if constexpr (dw == 2) prepare_a();
+      sched_barrier_phase<TM * TN * NPROD, (TM + TN) * NP, 0>();
+      // A issues among steps s+1-NSB .. s-1: with NSB = 3 those are two steps (one has dw == 2 unless this step has); with NSB = 2 one step
+      constexpr int a_in_flight = NSB == 3 ? (dw != 2 ? 1 : 0) : (dw == 0 ? 1 : 0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 2) * PB + a_in_flight * PA) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone: K-tile s+1 (and, after dw == 2, the next A group) landed; B stage sb / A stage sa free
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B: refill the freed stages; chunk-0 fragments of the next K-tile under the chunk-1 MFMAs
+      emit_b(sb);
+      if constexpr (dw == 2) emit_a(sa);
+      sb = sb == NSB - 1 ? 0 : sb + 1;
+      constexpr int ndw = dw == 2 ? 0 : dw + 1;
+      const int nsa = dw == 2 ? sa ^ 1 : sa;
+      const int ndh = dw == 2 ? (dh == 2 ? 0 : dh + 1) : dh;
+      read_frags(nsa, sb, ndw, ndh * 3 + ndw, C0);  // (past the end: surplus data, never used)
+      mfma_chunk(C1);
+      sched_barrier_phase<TM * TN * NPROD, (TM + TN) * NP, PB + (dw == 2 ? PA : 0)>();
+    };
+    constexpr std::integral_constant<int, 0> D0{};
+    constexpr std::integral_constant<int, 1> D1{};
+    constexpr std::integral_constant<int, 2> D2{};
+    int dh = g_begin % 3;
+    for (int g = 0; g < ngroup; ++g) {
+      const int sa = g & 1;
+      step(sa, dh, D0);
+      step(sa, dh, D1);
+      step(sa, dh, D2);
+      dh = dh == 2 ? 0 : dh + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus fetches land before the LDS is released
+  }
+
+  if constexpr (SK) {
+    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
+  }
+  conv_epilogue<TM, TN, MODE>(a, s, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ host
+template <int TM, int TN, int WM, int WN, int MODE>
+static int launch_row_tile(const ConvKArgs& ka, hipStream_t st) {
+  constexpr int NP = Planes<MODE>::NP;
+  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
+  constexpr int A2 = 2 * NP * (BM + 16) * 64, BST = NP * BN * 64;
+  constexpr int BUDGET = (WM * WN == 8 ? 152 : 76) * 1024;
+  constexpr int NSB = (A2 + 3 * BST <= BUDGET) ? 3 : 2;
+  static_assert(A2 + NSB * BST + 64 <= 160 * 1024, "tile does not fit the LDS");
+  const size_t lds = (size_t)A2 + (size_t)NSB * BST + 64;  // + the zero bytes invalid taps read
+  dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>), grid, dim3(NTHR), lds, st, ka);
+  else hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>), grid, dim3(NTHR), lds, st, ka);
+  return check_launch("conv_igemm_planes_row kernel");
+}
+
+template <int MODE>
+static int launch_row_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st) {
+  switch (tile_cfg) {
+    case DD3D_TILE_256x128: return launch_row_tile<2, 2, 4, 2, MODE>(ka, st);
+    case DD3D_TILE_128x128: return launch_row_tile<2, 1, 2, 4, MODE>(ka, st);
+    case DD3D_TILE_128x64_K2:
+    case DD3D_TILE_128x64: return launch_row_tile<1, 1, 4, 2, MODE>(ka, st);
+    case DD3D_TILE_64x128_K2:
+    case DD3D_TILE_64x128: return launch_row_tile<1, 1, 2, 4, MODE>(ka, st);
+    case DD3D_TILE_128x128_W4: return launch_row_tile<2, 2, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_64x64_W4K2:
+    case DD3D_TILE_64x64_W4: return launch_row_tile<1, 1, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_128x64_W4: return launch_row_tile<2, 1, 2, 2, MODE>(ka, st);
+  }
+  DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no row-shared split-plane kernel", tile_cfg);
+}
+
+// The row-shared form applies to 3x3 / stride 1 / pad 1 convolutions whose K slices start on a filter row.
+bool conv_planes_row_applicable(const ConvKArgs& ka) {
+  return ka.KH == 3 && ka.KW == 3 && ka.stride == 1 && ka.pad == 1 && (ka.Cin % 32) == 0 && (ka.splitk == 1 || ka.kt_per_split % 3 == 0);
+}
+
+int launch_conv_planes_row(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st) {
+  switch (math_mode) {
+    case DD3D_MATH_BF16X3: return launch_row_mode<DD3D_MATH_BF16X3>(ka, tile_cfg, st);
+    case DD3D_MATH_BF16X2: return launch_row_mode<DD3D_MATH_BF16X2>(ka, tile_cfg, st);
+    case DD3D_MATH_BF16: return launch_row_mode<DD3D_MATH_BF16>(ka, tile_cfg, st);
+    case DD3D_MATH_F16X2: return launch_row_mode<DD3D_MATH_F16X2>(ka, tile_cfg, st);
+  }
+  DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: math mode %d has no split-plane kernel", math_mode);
+}
+
+}  // namespace dd3d

@@ -280,9 +280,19 @@ def kernel_signature(op):
     sk = "true" if op.L.splitk > 1 else "false"
     if op.in_planes:
         tm, tn, wm, wn = tm_tn_wm_wn[PLANE_TILE_ALIAS.get(cfg, cfg)]
-        stage = hip.MATH_PLANES[op.math] * (tm * 32 * wm + tn * 32 * wn) * 64
+        np_ = hip.MATH_PLANES[op.math]
+        bm, bn = tm * 32 * wm, tn * 32 * wn
+        L = op.L
+        nk = L.Kpad // 32
+        row = (L.KH == 3 and L.KW == 3 and L.stride == 1 and L.pad == 1 and (L.splitk == 1 or -(-nk // L.splitk) % 3 == 0)
+               and os.environ.get("DD3D_CONV_ROW", "1") != "0")
+        if row:  # csrc/conv_planes_row.hip: the three taps of a filter row share one A stage
+            a2, bst = 2 * np_ * (bm + 16) * 64, np_ * bn * 64
+            nsb = 3 if a2 + 3 * bst <= (152 if wm * wn == 8 else 76) * 1024 else 2
+            return f"dd3d::conv_igemm_planes_row_kernel<{tm}, {tn}, {wm}, {wn}, {nsb}, {op.math}, {sk}>"
+        stage = np_ * (bm + bn) * 64
         ns = max(2, min(4, ((144 if wm * wn == 8 else 72) * 1024) // stage))
-        return f"dd3d::conv_igemm_planes_kernel<{tm}, {tn}, {wm}, {wn}, {ns}, {op.math}, {sk}>"
+        return f"dd3d::conv_igemm_planes_kernel<{tm}, {tn}, {wm}, {wn}, {ns}, {op.math}, {sk}, 0>"
     if op.math == hip.MATH_BF16X3:
         return f"dd3d::conv_igemm_bf16x3_kernel ({hip.TILE_NAMES[cfg]}, split-K {sk})"
     return f"dd3d::conv_igemm_f32[_dma]_kernel ({hip.TILE_NAMES[cfg]}, split-K {sk})"

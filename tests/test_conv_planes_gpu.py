@@ -43,11 +43,25 @@ def _plan(math):
     return plan
 
 
+ROW_CASES = [  # 3x3 / stride 1: the row-shared kernel (csrc/conv_planes_row.hip); the same shapes also run on the per-tap kernel below
+    ("row_256x128_wraps", 2, 33, 41, 64, 128, 3, 1, 1, True, True, hip.TILE_256x128, 1),      # 41-wide rows: every wave crosses image rows
+    ("row_256x128_sk3", 1, 30, 44, 96, 192, 3, 1, 1, False, False, hip.TILE_256x128, 3),       # 27 K-tiles / 3 = 9: slices start on a filter row
+    ("row_sk2_not_on_a_row", 1, 12, 20, 64, 64, 3, 1, 1, False, False, hip.TILE_64x64_W4, 4),  # 18 K-tiles / 4: falls back to the per-tap kernel
+    ("row_64x64w4_b3", 3, 7, 9, 256, 256, 3, 1, 1, True, False, hip.TILE_64x64_W4, 1),         # three tiny images: batch boundaries inside a tile
+    ("row_128x64w4_sk3", 1, 24, 40, 128, 128, 3, 1, 1, True, True, hip.TILE_128x64_W4, 3),
+    ("row_64x128_1x3", 1, 1, 3, 32, 128, 3, 1, 1, False, False, hip.TILE_64x128, 1),           # a 1 x 3 image: every neighbour but two is padding
+]
+
+
+@pytest.mark.parametrize("row_kernel", [1, 0], ids=["rowshared", "pertap"])
 @pytest.mark.parametrize("mode", list(MODES))
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_planes_conv_matches_torch(hiplib, case, mode):
+@pytest.mark.parametrize("case", CASES + ROW_CASES, ids=[c[0] for c in CASES + ROW_CASES])
+def test_planes_conv_matches_torch(hiplib, case, mode, row_kernel, monkeypatch):
     from dd3d_amd.engine import ConvOp, pack_filter
     name, B, H, W, Cin, Cout, k, stride, pad, relu, use_res, tile, splitk = case
+    if not row_kernel and not (k == 3 and stride == 1):
+        pytest.skip("only 3x3 / stride 1 has two kernels")
+    monkeypatch.setenv("DD3D_CONV_ROW", str(row_kernel))
     math, rtol = MODES[mode]
     g = torch.Generator().manual_seed(sum(map(ord, name)) % 1000)
     x = torch.randn(B, Cin, H, W, generator=g)
