@@ -31,7 +31,7 @@ for m in ("f16x2", "bf16x3"):
     for f in glob.glob("$O/pmc_*_%s/**/*counter_collection.csv" % m, recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "conv_igemm_planes_kernel<2, 2, 4, 2" in k:
+            if "conv_igemm_planes_row_kernel<2, 2, 4, 2" in k or "conv_igemm_planes_kernel<2, 2, 4, 2" in k:
                 agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
                 names.add(k.split("(")[0])
     out[m] = {"kernel_names": sorted(names), "counters_avg_per_launch": {k: sum(v) / len(v) for k, v in agg.items()}, "launches": {k: len(v) for k, v in agg.items()}}
@@ -39,4 +39,4 @@ json.dump(out, open("$O/${TAG}_tower_pmc_raw.json", "w"), indent=1)
 print(json.dumps(out)[:1500])
 PY
 cd $R
-for m in f16x2 bf16x2 bf16; do DD3D_MATH=$m timeout 900 python tests/gpu_configs_check.py 2>&1 | grep -v amdgpu | tee -a $O/${TAG}_configs.txt; done
+for m in f16x2 bf16; do DD3D_MATH=$m timeout 900 python tests/gpu_configs_check.py 2>&1 | grep -v amdgpu | tee -a $O/${TAG}_configs.txt; done
