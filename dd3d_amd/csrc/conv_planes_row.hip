@@ -19,6 +19,13 @@
 
 #include "conv_common.h"
 
+#ifndef DD3D_ROW_LDS_KIB_8W
+#define DD3D_ROW_LDS_KIB_8W 152  // LDS a block of the 8-wave tiles may take (decides NSB = 3 or 2)
+#endif
+#ifndef DD3D_ROW_LDS_KIB_4W
+#define DD3D_ROW_LDS_KIB_4W 76
+#endif
+
 namespace dd3d {
 
 template <int TM, int TN, int WM, int WN, int NSB, int MODE, bool SK>
@@ -277,7 +284,7 @@ static int launch_row_tile(const ConvKArgs& ka, hipStream_t st) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
   constexpr int A2 = 2 * NP * (BM + 16) * 64, BST = NP * BN * 64;
-  constexpr int BUDGET = (WM * WN == 8 ? 152 : 76) * 1024;
+  constexpr int BUDGET = (WM * WN == 8 ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
   constexpr int NSB = (A2 + 3 * BST <= BUDGET) ? 3 : 2;
   static_assert(A2 + NSB * BST + 64 <= 160 * 1024, "tile does not fit the LDS");
   const size_t lds = (size_t)A2 + (size_t)NSB * BST + 64;  // + the zero bytes invalid taps read

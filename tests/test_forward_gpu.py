@@ -213,9 +213,12 @@ def test_hip_matches_reference_golden(hiplib, name):
             na = st["attr"][l].shape[1]
             assert max_abs(plan.cls_maps[l].nchw(C, na), st["attr"][l]) < 1e-4 * max(1.0, float(st["attr"][l].abs().max()))
             assert max_abs(plan.cls_maps[l].nchw(C + na, 1), st["speed"][l]) < 1e-4 * max(1.0, float(st["speed"][l].abs().max()))
-        assert max_abs(plan.cls_maps[l].nchw(0, C), st["logits"][l]) < 1e-4 * max(1.0, float(st["logits"][l].abs().max()))
-        assert max_abs(plan.b2d_maps[l].nchw(0, 4), st["box2d_reg"][l]) < 1e-4 * max(1.0, float(st["box2d_reg"][l].abs().max()))
-        assert max_abs(plan.b3d_maps[l].nchw(6 * C, C), st["depth"][l]) < 1e-4 * max(1.0, float(st["depth"][l].abs().max()))
+        # every head map of the HIP forward against the reference's own (golden) map, end to end
+        C3 = st["quat"][l].shape[1] // 4  # C, or 1 for a class-agnostic 3D head
+        for key, got in [("logits", plan.cls_maps[l].nchw(0, C)), ("box2d_reg", plan.b2d_maps[l].nchw(0, 4)), ("centerness", plan.b2d_maps[l].nchw(4, 1)),
+                         ("quat", plan.b3d_maps[l].nchw(0, 4 * C3)), ("ctr", plan.b3d_maps[l].nchw(4 * C3, 2 * C3)), ("depth", plan.b3d_maps[l].nchw(6 * C3, C3)),
+                         ("size", plan.b3d_maps[l].nchw(7 * C3, 3 * C3)), ("conf", plan.b3d_maps[l].nchw(10 * C3, C3))]:
+            assert max_abs(got, st[key][l]) < 1e-4 * max(1.0, float(st[key][l].abs().max())), (name, key, l)
     oracle_heads_to_plan(plan, st, C)
     plan.launch(first=plan.num_pre_nms_ops - 1)
     torch.cuda.synchronize()
