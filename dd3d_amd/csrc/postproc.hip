@@ -11,6 +11,8 @@
 // These are latency/HBM-bound integer+scalar-float kernels (<= ~150 flop per candidate): no MFMA.
 // Floating-point contraction is off so IoU / score comparisons round like the reference's separate mul/add ops.
 #pragma clang fp contract(off)
+#include <algorithm>
+
 #include "common.h"
 
 namespace dd3d {
@@ -403,13 +405,13 @@ struct NmsK {
   int ncap2;  // next power of two >= levels*topk (size of the LDS sort arrays)
 };
 
-// Rank of (ki, position pos) among keys[0, n) in descending order, ties by position: the initial order of both sorters is
-// by increasing value index, so "val_j < val_i" is "j < pos" and the index array need not be read.  One broadcast
-// ds_read_b128 feeds four comparisons; keys[n, round_up(n, 4)) must hold -inf.
-__device__ __forceinline__ int rank_of(const float* keys, int n, float ki, int pos) {
+// Number of keys[lo, hi) that sort before (ki, position pos) in descending order, ties by position: the initial order of the
+// sorters is by increasing value index, so "val_j < val_i" is "j < pos" and the index array need not be read.  One broadcast
+// ds_read_b128 feeds four comparisons; lo and hi are multiples of 4 and keys past the last candidate hold -inf.
+__device__ __forceinline__ int rank_of(const float* keys, int lo, int hi, float ki, int pos) {
   int rank = 0;
 #pragma unroll 4
-  for (int j0 = 0; j0 < n; j0 += 4) {
+  for (int j0 = lo; j0 < hi; j0 += 4) {
     const float4 k4 = *reinterpret_cast<const float4*>(keys + j0);
     rank += (k4.x > ki) || (k4.x == ki && j0 + 0 < pos);
     rank += (k4.y > ki) || (k4.y == ki && j0 + 1 < pos);
@@ -422,9 +424,16 @@ __device__ __forceinline__ int rank_of(const float* keys, int n, float ki, int p
 // mode written to nvalid[g][1]
 enum { NMS_TRICK = 0, NMS_PER_CLASS = 1, NMS_NONE = 2 };
 
+constexpr int SORT_SPLIT = 16;  // blocks per image of the rank sort: 64 candidates x 16 threads each
+
+// Per image: gather the levels, order by score (descending, ties by concatenated index), write the sorted work arrays with the
+// coordinate-trick offsets.  n <= PT: rank sort spread over SORT_SPLIT blocks -- every block holds all keys in LDS, block s ranks
+// candidates s*64 .. s*64+63 with 16 threads per candidate (each compares against 1/16 of the keys) and writes them straight to
+// their sorted position (one block with one thread per candidate spent 20 us in the n-step comparison loop, measured).
+// n > PT: block 0 runs the in-LDS bitonic sort.
 __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
-  const int g = blockIdx.x, tid = threadIdx.x;
+  const int g = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   const int L = a.num_levels, NS = slot_base(a.slot_off, L, a.topk, L);
   const float* cand = a.cand + (long)g * DD3D_CAND_FIELDS * NS;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // keys[ncap2] | vals[ncap2]
@@ -443,6 +452,8 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   __syncthreads();
   const int n = pref[L];
   const bool suppress = a.do_nms && a.nms_thresh > 0.f;
+  const bool split = suppress && n <= PT;
+  if (s > 0 && (!split || s * 64 >= n)) return;
   int Pn = 4;  // >= 4: the vectorised rank loop reads keys in quads
   while (Pn < n) Pn <<= 1;
   const float* key_src = cand + (a.use_score3d ? 5 : 4) * NS;
@@ -467,124 +478,147 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   __syncthreads();
   mx = red[0];
   for (int w = 1; w < PT / 64; ++w) mx = fmaxf(mx, red[w]);
-  if (suppress) {
-    if (n <= PT) {
-      // rank sort: one candidate per thread, rank = number of candidates that sort before it (n LDS broadcasts)
-      // (measured: the scalar version of this loop -- two dependent ds_read_b32 per step -- took 107 k cycles for n = 511)
-      const float ki = tid < n ? keys[tid] : 0.f;
-      const int vi = tid < n ? vals[tid] : 0;
-      int rank = 0;
-      if (tid < n) rank = rank_of(keys, n, ki, tid);
-      __syncthreads();
-      if (tid < n) {
-        keys[rank] = ki;
-        vals[rank] = vi;
-      }
-    } else {
-      block_bitonic_sort(keys, vals, Pn);
-    }
-  }
-  __syncthreads();
   const int mode = !suppress ? NMS_NONE : (4 * n > 4000 ? NMS_PER_CLASS : NMS_TRICK);  // torchvision 0.10 batched_nms
-  if (tid == 0) {
+  if (s == 0 && tid == 0) {
     a.nvalid[2 * g] = n;
     a.nvalid[2 * g + 1] = mode;
   }
   const float off_unit = mx + 1.0f;
-  for (int p = tid; p < n; p += PT) {
-    const int slot = vals[p];
+  auto emit = [&](int p, int slot) {  // sorted position p <- candidate slot
     const int c = __float_as_int(cand[6 * NS + slot]);
     const float off = mode == NMS_TRICK ? (float)c * off_unit : 0.f;
     a.sort_idx[(long)g * P.ncap + p] = slot;
     a.scls[(long)g * P.ncap + p] = c;
-    float* sb = a.sbox + ((long)g * P.ncap + p) * 4;
-    sb[0] = cand[0 * NS + slot] + off;
-    sb[1] = cand[1 * NS + slot] + off;
-    sb[2] = cand[2 * NS + slot] + off;
-    sb[3] = cand[3 * NS + slot] + off;
+    *reinterpret_cast<float4*>(a.sbox + ((long)g * P.ncap + p) * 4) =
+        make_float4(cand[0 * NS + slot] + off, cand[1 * NS + slot] + off, cand[2 * NS + slot] + off, cand[3 * NS + slot] + off);
+  };
+  if (split) {
+    const int e = s * 64 + (tid >> 4), part = tid & 15;
+    const int chunk = Pn >= 64 ? Pn >> 4 : 4;
+    const int lo = part * chunk, hi = min(Pn, lo + chunk);
+    int rank = 0;
+    if (e < n && lo < hi) rank = rank_of(keys, lo, hi, keys[e], e);
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) rank += __shfl_xor(rank, d, 64);
+    if (part == 0 && e < n) emit(rank, vals[e]);
+    return;
   }
+  if (suppress) block_bitonic_sort(keys, vals, Pn);
+  __syncthreads();
+  for (int p = tid; p < n; p += PT) emit(p, vals[p]);
 }
 
-// [ext] torchvision nms_kernel: bit j of mask[i][cb] = (cb*64+j > i) && IoU(i, cb*64+j) > thr
-__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsK P) {
+// Upper-triangular tile t of an nwords x nwords tile grid -> (rb, cb), cb >= rb; rows first.
+__device__ __forceinline__ void tile_of(int t, int nwords, int& rb, int& cb) {
+  rb = 0;
+  while (t >= nwords - rb) {
+    t -= nwords - rb;
+    ++rb;
+  }
+  cb = rb + t;
+}
+
+constexpr int MASK_BLOCKS = 256;  // blocks per image of the mask kernels; each walks the tiles t = blockIdx.x, + MASK_BLOCKS, ...
+constexpr int MASK_WAVES = 4;     // a 64 x 64 tile is shared by four waves, 16 partners each
+
+// [ext] torchvision nms_kernel.  Word (i, cb) of the mask, cb > i/64: bit j = IoU(i, cb*64+j) > thr (row form, i sorts first).
+// The DIAGONAL word (i, i/64) is stored in COLUMN form: bit r = row (i/64)*64 + r, r < i%64, suppresses i when it is kept -- what
+// the fixed-point resolution of greedy_reduce consumes.  Both forms evaluate the same expression with the earlier box as `a`.
+__global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
-  const int g = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x, lane = threadIdx.x;
+  const int g = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = a.nvalid[2 * g], mode = a.nvalid[2 * g + 1];
-  if (mode == NMS_NONE || cb < rb || rb * 64 >= n || cb * 64 >= n) return;
-  __shared__ float cbox[64][4];
-  __shared__ int ccls[64];
+  if (mode == NMS_NONE) return;
+  const int nwords = (n + 63) / 64, ntiles = nwords * (nwords + 1) / 2;
+  __shared__ float rbox[64][4], cbox[64][4];
+  __shared__ int rcls[64], ccls[64];
+  __shared__ unsigned long long part[MASK_WAVES][64];
   const float* sbox = a.sbox + (long)g * P.ncap * 4;
   const int* scls = a.scls + (long)g * P.ncap;
-  const int cj = cb * 64 + lane;
-  if (cj < n) {
-    cbox[lane][0] = sbox[cj * 4 + 0], cbox[lane][1] = sbox[cj * 4 + 1];
-    cbox[lane][2] = sbox[cj * 4 + 2], cbox[lane][3] = sbox[cj * 4 + 3];
-    ccls[lane] = scls[cj];
+  for (int t = blockIdx.x; t < ntiles; t += MASK_BLOCKS) {
+    int rb, cb;
+    tile_of(t, nwords, rb, cb);
+    if (wave < 2) {  // wave 0 stages the row boxes, wave 1 the column boxes
+      const int src = (wave == 0 ? rb : cb) * 64 + lane;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      int c = -1;
+      if (src < n) v = *reinterpret_cast<const float4*>(sbox + (long)src * 4), c = scls[src];
+      float* dst = wave == 0 ? rbox[lane] : cbox[lane];
+      dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+      (wave == 0 ? rcls : ccls)[lane] = c;
+    }
+    __syncthreads();
+    // lane = row i of the tile (off-diagonal) or column j of the tile (diagonal); partners = the other side, 16 per wave
+    const bool diag = rb == cb;
+    const float* mine = diag ? cbox[lane] : rbox[lane];
+    const float m0 = mine[0], m1 = mine[1], m2 = mine[2], m3 = mine[3];
+    const int mc = diag ? ccls[lane] : rcls[lane];
+    const float sm = (m2 - m0) * (m3 - m1);
+    const int me = (diag ? cb : rb) * 64 + lane;
+    unsigned long long bits = 0;
+    if (me < n) {
+      for (int q = 0; q < 64 / MASK_WAVES; ++q) {
+        const int k = wave * (64 / MASK_WAVES) + q;
+        const float* o = diag ? rbox[k] : cbox[k];
+        const int other = (diag ? rb : cb) * 64 + k;
+        if (other >= n || (diag && k >= lane)) continue;
+        if (mode == NMS_PER_CLASS && (diag ? rcls[k] : ccls[k]) != mc) continue;
+        const float left = fmaxf(m0, o[0]), right = fminf(m2, o[2]);
+        const float top = fmaxf(m1, o[1]), bottom = fminf(m3, o[3]);
+        const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+        const float inter = w * h;
+        const float so = (o[2] - o[0]) * (o[3] - o[1]);
+        // sa = area of the earlier (row) box, sb = of the later one: a float sum is commutative, so one expression serves both forms
+        if (inter / (sm + so - inter) > a.nms_thresh) bits |= 1ull << k;
+      }
+    }
+    part[wave][lane] = bits;
+    __syncthreads();
+    if (wave == 0 && me < n) {
+      unsigned long long v = part[0][lane];
+#pragma unroll
+      for (int w = 1; w < MASK_WAVES; ++w) v |= part[w][lane];
+      a.mask[((long)g * P.ncap + me) * (P.ncap / 64) + cb] = v;
+    }
   }
-  __syncthreads();
-  const int i = rb * 64 + lane;
-  if (i >= n) return;
-  const float ax1 = sbox[i * 4 + 0], ay1 = sbox[i * 4 + 1], ax2 = sbox[i * 4 + 2], ay2 = sbox[i * 4 + 3];
-  const int ac = scls[i];
-  const float sa = (ax2 - ax1) * (ay2 - ay1);
-  unsigned long long bits = 0;
-  const int jmax = min(64, n - cb * 64);
-  for (int j = 0; j < jmax; ++j) {
-    const int col = cb * 64 + j;
-    if (col <= i) continue;
-    if (mode == NMS_PER_CLASS && ccls[j] != ac) continue;
-    const float left = fmaxf(ax1, cbox[j][0]), right = fminf(ax2, cbox[j][2]);
-    const float top = fmaxf(ay1, cbox[j][1]), bottom = fminf(ay2, cbox[j][3]);
-    const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
-    const float inter = w * h;
-    const float sb = (cbox[j][2] - cbox[j][0]) * (cbox[j][3] - cbox[j][1]);
-    if (inter / (sa + sb - inter) > a.nms_thresh) bits |= 1ull << j;
-  }
-  a.mask[((long)g * P.ncap + i) * (P.ncap / 64) + cb] = bits;
 }
 
-// Greedy suppression over a precomputed bit mask (row i, bit j set: j > i and i suppresses j), one block of PT threads.
-// Block row rb = candidates rb*64 .. rb*64+63.  Wave 0 resolves the row's 64 candidates from the DIAGONAL words alone: the
-// loop is fully unrolled with constant lane selects, so `rem` / `keep` live in SGPRs and a step is two v_readlane plus a few
-// scalar ops (the previous ds_bpermute / LDS-chasing version spent 118 cycles per step and 5.7 k cycles per row in the
-// OR phase).  Meanwhile wave w holds word rb+w of the 64 rows (one lane per row), loaded straight from the mask; after
-// the keep bits are published each wave ORs the words of the kept rows with a 6-step butterfly and folds them into
-// removed[rb+w] (fetching all words of an n <= 1024 problem up front measured 10 % SLOWER, A/B on one box).
+// Greedy suppression over a precomputed bit mask, one block of PT threads.  word(i, cw) returns word cw of row i (see
+// nms_mask_kernel: row form above the diagonal, column form ON it).  Block row rb = candidates rb*64 .. rb*64+63.
+//   * Wave 0 resolves the block row from the diagonal words alone.  keep_j = alive_j and no kept earlier row of the block
+//     suppresses j has exactly one solution (induction on j), and the iteration keep <- ballot(alive & !(col & keep)) fixes one
+//     more leading candidate per round at least, so it reaches that solution in <= 64 rounds -- in practice in as many rounds as
+//     the longest suppression chain of the block (a handful).  The previous form walked all 64 candidates with two v_readlane
+//     per step (~2 k cycles per block row, the largest term of the kernel).
+//   * Meanwhile wave w holds word rb+w of the 64 rows (one lane per row); after the keep bits are published each wave ORs the
+//     words of the kept rows with a 6-step butterfly and folds them into removed[rb+w].
 // on_row(rb, keepbits) runs on wave 0 (all 64 lanes) for every block row, in order.
-template <class F>
-__device__ __forceinline__ void greedy_reduce(const unsigned long long* mask, int nw, int n, unsigned long long* removed, F&& on_row) {
+template <class W, class F>
+__device__ __forceinline__ void greedy_reduce(W&& word_of, int n, unsigned long long* removed, F&& on_row) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ unsigned long long sh_keepbits;
   const int nwords = (n + 63) / 64;
   for (int rb = 0; rb < nwords; ++rb) {
     const int i = rb * 64 + lane;
-    unsigned long long keepbits = 0;
     if (wave == 0) {
-      const unsigned long long diag = i < n ? mask[(long)i * nw + rb] : 0ull;
-      const unsigned long long rem0 = removed[rb];
-      unsigned long long rem = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rem0) |
-                               ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rem0 >> 32)) << 32);
-      const int lim = min(64, n - rb * 64);
-      if (lim < 64) rem |= ~0ull << lim;  // rows past n can never be kept
-      const int dlo = (int)(unsigned)diag, dhi = (int)(unsigned)(diag >> 32);
-#pragma unroll
-      for (int j = 0; j < 64; ++j) {
-        const unsigned long long dj = (unsigned)__builtin_amdgcn_readlane(dlo, j) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, j) << 32);
-        if (!((rem >> j) & 1ull)) {
-          keepbits |= 1ull << j;
-          rem |= dj;
-        }
+      const unsigned long long col = i < n ? word_of(i, rb) : 0ull;
+      const bool alive = i < n && !((removed[rb] >> lane) & 1ull);
+      unsigned long long keep = __ballot(alive);
+      for (;;) {
+        const unsigned long long next = __ballot(alive && (col & keep) == 0ull);
+        if (next == keep) break;
+        keep = next;
       }
-      if (lane == 0) sh_keepbits = keepbits;
-      on_row(rb, keepbits);
+      if (lane == 0) sh_keepbits = keep;
+      on_row(rb, keep);
     }
     // words of the later columns: wave w -> word rb + w (+16, +32, ...), lane -> row; issued before the barrier so the loads
-    // overlap wave 0's serial part
+    // overlap wave 0's part
     unsigned long long word[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int cw = rb + wave + 16 * q + (wave == 0 ? 16 : 0);  // wave 0 owns the diagonal; its first later word is rb + 16
-      word[q] = (cw < nwords && i < n) ? mask[(long)i * nw + cw] : 0ull;
+      word[q] = (cw < nwords && i < n) ? word_of(i, cw) : 0ull;
     }
     __syncthreads();
     const unsigned long long kb = sh_keepbits;
@@ -602,6 +636,8 @@ __device__ __forceinline__ void greedy_reduce(const unsigned long long* mask, in
   }
 }
 
+constexpr int FIN_SMALL = 1024;  // up to this many candidates the whole upper triangle of the mask is staged in LDS (128 KiB)
+
 __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -612,12 +648,16 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const int nw = P.ncap / 64;
   const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(a.mask) + (long)g * P.ncap * nw;
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // removed | kept | tkeys | tvals
+  // removed | kept | tkeys | tvals | sidx, the four arrays `cap` entries each; n <= FIN_SMALL: cap = FIN_SMALL, followed by lmask
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  const bool small = n <= FIN_SMALL && mode != NMS_NONE;
+  const int cap = small ? FIN_SMALL : P.ncap2;
   unsigned long long* removed = reinterpret_cast<unsigned long long*>(dyn_lds);  // [NCAP_MAX/64]
-  int* kept = reinterpret_cast<int*>(removed + NCAP_MAX / 64);  // [ncap2] sorted positions that survive NMS, in order
-  float* tkeys = reinterpret_cast<float*>(kept + P.ncap2);      // [ncap2] scratch for the top-k threshold
-  int* tvals = reinterpret_cast<int*>(tkeys + P.ncap2);         // [ncap2]
-  int* sidx = tvals + P.ncap2;                                  // [ncap2] sort_idx staged once (cuts a level off every gather below)
+  int* kept = reinterpret_cast<int*>(removed + NCAP_MAX / 64);  // sorted positions that survive NMS, in order
+  float* tkeys = reinterpret_cast<float*>(kept + cap);          // scratch for the top-k threshold
+  int* tvals = reinterpret_cast<int*>(tkeys + cap);
+  int* sidx = tvals + cap;                                      // sort_idx staged once (cuts a level off every gather below)
+  unsigned long long* lmask = reinterpret_cast<unsigned long long*>(sidx + cap);  // [16][FIN_SMALL]: word cw of row i at cw*FIN_SMALL + i
   for (int i = tid; i < n; i += PT) sidx[i] = sort_idx[i];
   __shared__ int wsum[PT / 64];
   __shared__ int sh_nkeep;
@@ -631,13 +671,33 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   } else {
     for (int i = tid; i < NCAP_MAX / 64; i += PT) removed[i] = 0;
     if (tid == 0) sh_nkeep = 0;
-    __syncthreads();
-    greedy_reduce(mask, nw, n, removed, [&](int rb, unsigned long long keepbits) {
+    auto on_row = [&](int rb, unsigned long long keepbits) {
       // append the kept positions in order (wave 0, lane = row of the block row)
       const int base = sh_nkeep;
       if ((keepbits >> tid) & 1ull) kept[base + __popcll(keepbits & ((1ull << tid) - 1ull))] = rb * 64 + tid;
       if (tid == 0) sh_nkeep = base + __popcll(keepbits);
-    });
+    };
+    if (small) {
+      // one row per thread, its words from the diagonal on: <= 16 independent loads in flight, ONE trip to the L2 / fabric instead
+      // of one per block row (the mask was written by other CUs, usually of other XCDs: ~1.5 us per dependent trip, measured)
+      const int nwords = (n + 63) / 64;
+      unsigned long long w[FIN_SMALL / 64];
+#pragma unroll
+      for (int q = 0; q < FIN_SMALL / 64; ++q) {
+        const int cw = (tid >> 6) + q;
+        w[q] = (tid < n && cw < nwords) ? mask[(long)tid * nw + cw] : 0ull;
+      }
+#pragma unroll
+      for (int q = 0; q < FIN_SMALL / 64; ++q) {
+        const int cw = (tid >> 6) + q;
+        if (cw < FIN_SMALL / 64) lmask[cw * FIN_SMALL + tid] = w[q];
+      }
+      __syncthreads();
+      greedy_reduce([&](int i, int cw) { return lmask[cw * FIN_SMALL + i]; }, n, removed, on_row);
+    } else {
+      __syncthreads();
+      greedy_reduce([&](int i, int cw) { return mask[(long)i * nw + cw]; }, n, removed, on_row);
+    }
     nkeep = sh_nkeep;
   }
 
@@ -939,7 +999,7 @@ __global__ __launch_bounds__(PT) void bev_prepare_kernel(const BevK P) {
     const float ki = tid < n ? keys[tid] : 0.f;
     const int vi = tid < n ? vals[tid] : 0;
     int rank = 0;
-    if (tid < n) rank = rank_of(keys, n, ki, tid);
+    if (tid < n) rank = rank_of(keys, 0, Pn, ki, tid);
     __syncthreads();
     if (tid < n) keys[rank] = ki, vals[rank] = vi;
   } else {
@@ -959,31 +1019,51 @@ __global__ __launch_bounds__(PT) void bev_prepare_kernel(const BevK P) {
   }
 }
 
-__global__ __launch_bounds__(64) void bev_mask_kernel(const BevK P) {
+// Rotated-IoU mask of the aggregated boxes, laid out like nms_mask_kernel's (row form above the diagonal, column form on it;
+// rotated_iou is always called with the earlier box first, as [ext] nms_rotated does).
+__global__ __launch_bounds__(64 * MASK_WAVES) void bev_mask_kernel(const BevK P) {
   const dd3d_bev_args& a = P.a;
-  const int rb = blockIdx.y, cb = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = a.meta[0];
-  if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
-  __shared__ float cbox[64][6];
-  const int cj = cb * 64 + lane;
-  if (cj < n) {
+  const int nwords = (n + 63) / 64, ntiles = nwords * (nwords + 1) / 2;
+  __shared__ float rbox[64][6], cbox[64][6];
+  __shared__ unsigned long long part[MASK_WAVES][64];
+  for (int t = blockIdx.x; t < ntiles; t += MASK_BLOCKS) {
+    int rb, cb;
+    tile_of(t, nwords, rb, cb);
+    if (wave < 2) {
+      const int src = (wave == 0 ? rb : cb) * 64 + lane;
+      float* dst = wave == 0 ? rbox[lane] : cbox[lane];
 #pragma unroll
-    for (int f = 0; f < 6; ++f) cbox[lane][f] = a.sbox[(long)cj * 8 + f];
-  }
-  __syncthreads();
-  const int i = rb * 64 + lane;
-  if (i >= n) return;
-  float mine[6];
+      for (int f = 0; f < 6; ++f) dst[f] = src < n ? a.sbox[(long)src * 8 + f] : 0.f;
+    }
+    __syncthreads();
+    const bool diag = rb == cb;
+    float mine[6];
 #pragma unroll
-  for (int f = 0; f < 6; ++f) mine[f] = a.sbox[(long)i * 8 + f];
-  unsigned long long bits = 0;
-  const int jmax = min(64, n - cb * 64);
-  for (int j = 0; j < jmax; ++j) {
-    if (cb * 64 + j <= i) continue;
-    if (__float_as_int(cbox[j][5]) != __float_as_int(mine[5])) continue;  // other categories are offset out of reach
-    if (rotated_iou(mine, cbox[j]) > a.iou_thresh) bits |= 1ull << j;
+    for (int f = 0; f < 6; ++f) mine[f] = diag ? cbox[lane][f] : rbox[lane][f];
+    const int me = (diag ? cb : rb) * 64 + lane;
+    unsigned long long bits = 0;
+    if (me < n) {
+      for (int q = 0; q < 64 / MASK_WAVES; ++q) {
+        const int k = wave * (64 / MASK_WAVES) + q;
+        const float* o = diag ? rbox[k] : cbox[k];
+        const int other = (diag ? rb : cb) * 64 + k;
+        if (other >= n || (diag && k >= lane)) continue;
+        if (__float_as_int(o[5]) != __float_as_int(mine[5])) continue;  // other categories are offset out of reach
+        const float iou = diag ? rotated_iou(o, mine) : rotated_iou(mine, o);
+        if (iou > a.iou_thresh) bits |= 1ull << k;
+      }
+    }
+    part[wave][lane] = bits;
+    __syncthreads();
+    if (wave == 0 && me < n) {
+      unsigned long long v = part[0][lane];
+#pragma unroll
+      for (int w = 1; w < MASK_WAVES; ++w) v |= part[w][lane];
+      a.mask[(long)me * (P.ncap / 64) + cb] = v;
+    }
   }
-  a.mask[(long)i * (P.ncap / 64) + cb] = bits;
 }
 
 // 1 block: greedy reduce, cap, per-image ordered write-out (optionally with the resize / clip / non-empty filter).
@@ -1016,7 +1096,7 @@ __global__ __launch_bounds__(PT) void bev_finalize_kernel(const BevK P) {
     return;
   }
   const int cap = a.max_dets > 0 ? a.max_dets : 0x7fffffff;
-  greedy_reduce(mask, nw, n, removed, [&](int rb, unsigned long long keepbits) {
+  greedy_reduce([&](int i, int cw) { return mask[(long)i * nw + cw]; }, n, removed, [&](int rb, unsigned long long keepbits) {
     const int base = sh_nkeep;
     // keep[:max_dets] truncates the score-ordered keep list of the WHOLE batch (postprocessing.py:93-94)
     if (((keepbits >> tid) & 1ull) && base + __popcll(keepbits & ((1ull << tid) - 1ull)) < cap)
@@ -1096,19 +1176,19 @@ extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
   while (P.ncap2 < ns) P.ncap2 <<= 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds_sort = (size_t)P.ncap2 * 8;
-  const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 16;
+  const size_t lds_small = (size_t)NCAP_MAX / 64 * 8 + (size_t)FIN_SMALL * 16 + (size_t)FIN_SMALL * (FIN_SMALL / 64) * 8;  // 145 KiB
+  const size_t lds_fin = std::max((size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 16, lds_small);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NCAP_MAX / 64 * 8 + NCAP_MAX * 16);
+                              (int)std::max((size_t)NCAP_MAX / 64 * 8 + (size_t)NCAP_MAX * 16, lds_small));
     attr_done = true;
   }
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(args->G), dim3(PT), lds_sort, st, P);
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(args->G, SORT_SPLIT), dim3(PT), lds_sort, st, P);
   int rc = check_launch("nms_sort_kernel");
   if (rc != DD3D_OK) return rc;
-  const int nb = P.ncap / 64;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, args->G), dim3(64), 0, st, P);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_BLOCKS, args->G), dim3(64 * MASK_WAVES), 0, st, P);
   rc = check_launch("nms_mask_kernel");
   if (rc != DD3D_OK) return rc;
   hipLaunchKernelGGL(nms_finalize_kernel, dim3(args->G), dim3(PT), lds_fin, st, P);
@@ -1141,8 +1221,7 @@ extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
   hipLaunchKernelGGL(bev_prepare_kernel, dim3(1), dim3(PT), lds_prep, st, P);
   int rc = check_launch("bev_prepare_kernel");
   if (rc != DD3D_OK) return rc;
-  const int nb = min(P.ncap, P.ncap2) / 64;
-  hipLaunchKernelGGL(bev_mask_kernel, dim3(nb, nb), dim3(64), 0, st, P);
+  hipLaunchKernelGGL(bev_mask_kernel, dim3(MASK_BLOCKS), dim3(64 * MASK_WAVES), 0, st, P);
   rc = check_launch("bev_mask_kernel");
   if (rc != DD3D_OK) return rc;
   hipLaunchKernelGGL(bev_finalize_kernel, dim3(1), dim3(PT), lds_fin, st, P);
