@@ -14,6 +14,7 @@
 //   read F0 <- chunk 0 (tile kt+1) | MFMAs chunk 1
 // so the fragment reads of the next tile and the DMA issue sit under MFMAs that do not depend on them, and the two waves of a
 // SIMD leave the barrier with matrix work already in hand.
+#include <algorithm>
 #include <cstring>
 #include <stdlib.h>
 
@@ -591,6 +592,159 @@ __global__ __launch_bounds__(256) void upsample2x_add_planes_kernel(float* __res
   }
 }
 
+// ---- effective squeeze-excitation (vovnet.py:180-185,248-249: x * hsigmoid(fc(avgpool(x))) (+ identity)) in TWO launches
+//   gap_mean_kernel        partial[b][rs][c] = sum of the rs-th slice of the H*W rows (two-pass sum, no atomics on the data); the block
+//                          that finishes an image last (a counter per image) folds the partials, in slice order, into mean[b][:]
+//   ese_gate_scale_kernel  block = (64 channels, a run of pixels, image): its 64 gates = hsigmoid(fc_w[co][:] . mean[b][:] + fc_b[co])
+//                          from mean[b][:] staged in LDS, then out = x * gate (+ identity) written as f32 NHWC and / or split planes
+// instead of pool / gate / scale / dd3d_split_planes (4 launches, 7 passes over the map -> 2 launches, 5 passes).  Sums are taken in
+// the order of the three-launch dd3d_ese_nhwc.  A ONE-launch form (persistent grid of 64 blocks, grid-wide barriers between the
+// steps) was built and measured: it cannot use more than a fraction of the chip's blocks without risking a barrier among blocks that
+// are not co-resident, and at that size the streaming phases run at a quarter of the HBM rate -- V2-99 B=1 5.40 -> 6.38 ms,
+// B=16 48.7 -> 54.1 ms (profiles/r02_ese_one_launch.txt).
+constexpr int ESE_MAXC = 4096, ESE_PIXELS = 256;
+
+__global__ __launch_bounds__(256) void gap_mean_kernel(const float* __restrict__ in, float* __restrict__ partial, float* __restrict__ mean,
+                                                       int* __restrict__ counters, int HW, int C, int pitch, int RS, float inv_hw) {
+  const int cg = blockIdx.x, rs = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int rl = tid >> 4, cl = tid & 15;
+  const int c = cg * 64 + cl * 4;
+  const int rows_per = (HW + RS - 1) / RS;
+  const int r0 = rs * rows_per, r1 = min(HW, r0 + rows_per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 16) acc += *reinterpret_cast<const f32x4*>(in + ((long)b * HW + r) * pitch + c);
+  __shared__ f32x4 red[16][16];
+  __shared__ int last;
+  red[rl][cl] = acc;
+  __syncthreads();
+  // the exchange follows the split-K one (conv_common.h): write-through stores + s_waitcnt, a device-scope counter, write-through
+  // loads in the finishing block -- a release FENCE here would write back the whole L2, which still holds the producer's output
+  if (rl == 0 && c < C) {
+    f32x4 s = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][cl];
+    st_sc1(partial + ((long)b * RS + rs) * C + c, s);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int prev = __hip_atomic_fetch_add(counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = prev == (int)(gridDim.x * gridDim.y) - 1;
+    if (last) __hip_atomic_store(counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // left zero for the next launch
+  }
+  __syncthreads();
+  if (!last) return;
+  for (int c4 = tid; c4 * 4 < C; c4 += 256) {
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < RS; r0 += 8) {  // eight slices in flight, added in slice order
+      f32x4 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = ld_sc1(partial + ((long)b * RS + min(r0 + k, RS - 1)) * C + c4 * 4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(t[k]));  // the uses below depend on the wait above
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (r0 + k < RS) m += t[k];
+    }
+    *reinterpret_cast<f32x4*>(mean + (long)b * C + c4 * 4) = m * inv_hw;
+  }
+}
+
+struct EseK {
+  const float* x;
+  const float* identity;
+  float* out;
+  unsigned char* out_planes;
+  const float* fc_w;
+  const float* fc_b;
+  const float* mean;
+  int* status;
+  int B, HW, C, x_pitch, id_pitch, out_pitch, pixels;
+  float pscale;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ese_gate_scale_kernel(const EseK a) {
+  const int cg = blockIdx.x, ps = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C, HW = a.HW;
+  __shared__ float mean_s[ESE_MAXC];
+  __shared__ __attribute__((aligned(16))) float gate_s[64];
+  for (int ci = tid; ci < C; ci += 256) mean_s[ci] = a.mean[(long)b * C + ci];
+  __syncthreads();
+  {
+    // wave w: gates of channels cg*64 + 16w .. +15, lanes stride over the input channels (the summation order of ese_gate_kernel).
+    // The filter rows come from the L2 / fabric at ~1 us a trip: 16 rows x 4 lane-strides = 64 independent loads are issued per
+    // round, so a C = 1024 module needs 4 trips instead of 256 (measured: the dependent form took 126 us on the 2 MB stage-5 map).
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    const int co0 = cg * 64 + wave * 16;
+    for (int i0 = 0; i0 < C; i0 += 256) {
+      float v[16][4];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ci = i0 + u * 64 + lane, co = co0 + k;
+          v[k][u] = (ci < C && co < C) ? a.fc_w[(long)co * C + ci] : 0.f;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ci = i0 + u * 64 + lane;
+        const float m = ci < C ? mean_s[ci] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (ci < C) acc[k] += v[k][u] * m;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float t = acc[k];
+      for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d, 64);
+      const int co = co0 + k;
+      if (lane == 0) gate_s[wave * 16 + k] = co < C ? fminf(fmaxf(t + a.fc_b[co] + 3.0f, 0.f), 6.0f) / 6.0f : 0.f;  // F.relu6(x + 3) / 6
+    }
+  }
+  __syncthreads();
+  const int q = tid & 7, c8 = cg * 8 + q;  // 8 threads per pixel, 8 channels each
+  if (c8 * 8 >= C) return;
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate_s + q * 8), g1 = *reinterpret_cast<const f32x4*>(gate_s + q * 8 + 4);
+  const long M = (long)a.B * HW;
+  const int p0 = ps * a.pixels, p1 = min(HW, p0 + a.pixels);
+  auto one = [&](int p, f32x4& o0, f32x4& o1) {
+    const long m = (long)b * HW + p;
+    const float* px = a.x + m * a.x_pitch + c8 * 8;
+    o0 = *reinterpret_cast<const f32x4*>(px) * g0;
+    o1 = *reinterpret_cast<const f32x4*>(px + 4) * g1;
+    if (a.identity) {
+      const float* pi = a.identity + m * a.id_pitch + c8 * 8;
+      o0 += *reinterpret_cast<const f32x4*>(pi);
+      o1 += *reinterpret_cast<const f32x4*>(pi + 4);
+    }
+  };
+  auto put = [&](int p, f32x4 o0, f32x4 o1) {
+    const long m = (long)b * HW + p;
+    if (a.out) {
+      float* po = a.out + m * a.out_pitch + c8 * 8;
+      *reinterpret_cast<f32x4*>(po) = o0;
+      *reinterpret_cast<f32x4*>(po + 4) = o1;
+    }
+    if constexpr (MODE != DD3D_MATH_F32) {
+      if (a.out_planes) store_planes8<MODE>(a.out_planes, M, m, c8, o0, o1, a.pscale, a.status);
+    }
+  };
+  for (int p = p0 + (tid >> 3); p < p1; p += 64) {  // two pixels 32 apart per round: their loads are independent
+    f32x4 u0, u1, v0, v1;
+    const bool two = p + 32 < p1;
+    one(p, u0, u1);
+    if (two) one(p + 32, v0, v1);
+    put(p, u0, u1);
+    if (two) put(p + 32, v0, v1);
+  }
+}
+
 }  // namespace dd3d
 
 #define DD3D_PLANE_MODE_SWITCH(KERNEL, ...)                                                                                          \
@@ -628,4 +782,37 @@ extern "C" int dd3d_upsample2x_add_planes(float* fine, const float* coarse, void
   unsigned char* o = reinterpret_cast<unsigned char*>(fine_planes);
   DD3D_PLANE_MODE_SWITCH(upsample2x_add_planes_kernel, fine, coarse, o, B, H, W, C / 8, fine_pitch, coarse_pitch, ps, status)
   return check_launch("upsample2x_add_planes kernel");
+}
+
+extern "C" int dd3d_ese_fused(const float* x, const float* identity, float* out, void* out_planes, const float* fc_w, const float* fc_b, float* partial,
+                              float* mean, int32_t* counters, int32_t B, int32_t HW, int32_t C, int32_t x_pitch, int32_t id_pitch, int32_t out_pitch,
+                              int32_t rsplit, int32_t math_mode, float plane_scale, int32_t* status, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(x && (out || out_planes) && fc_w && fc_b && partial && mean && counters && B > 0 && B <= 65535 && HW > 0, "dd3d_ese_fused: bad arguments");
+  DD3D_REQUIRE(C > 0 && C <= ESE_MAXC && (C % 8) == 0 && (x_pitch % 4) == 0 && (!out || (out_pitch % 4) == 0) && (!identity || (id_pitch % 4) == 0),
+               "dd3d_ese_fused: C=%d must be a multiple of 8 up to %d, pitches multiples of 4", C, ESE_MAXC);
+  DD3D_REQUIRE(!out_planes || (C % 32) == 0, "dd3d_ese_fused: split planes need C %% 32 == 0 (C=%d)", C);
+  DD3D_REQUIRE(rsplit >= 1 && rsplit <= 1024, "dd3d_ese_fused: rsplit=%d", rsplit);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int CG = (C + 63) / 64;
+  hipLaunchKernelGGL(gap_mean_kernel, dim3(CG, rsplit, B), dim3(256), 0, st, x, partial, mean, counters, HW, C, x_pitch, rsplit, 1.0f / (float)HW);
+  int rc = check_launch("gap_mean_kernel");
+  if (rc != DD3D_OK) return rc;
+  EseK a;
+  a.x = x, a.identity = identity, a.out = out, a.out_planes = reinterpret_cast<unsigned char*>(out_planes), a.fc_w = fc_w, a.fc_b = fc_b;
+  a.mean = mean, a.status = status;
+  a.B = B, a.HW = HW, a.C = C, a.x_pitch = x_pitch, a.id_pitch = id_pitch, a.out_pitch = out_pitch, a.pixels = ESE_PIXELS;
+  a.pscale = plane_scale > 0.f ? plane_scale : 1.f;
+  const dim3 grid(CG, (HW + ESE_PIXELS - 1) / ESE_PIXELS, B);
+  DD3D_REQUIRE(grid.y <= 65535, "dd3d_ese_fused: H*W=%d too large", HW);
+  if (!out_planes) math_mode = DD3D_MATH_F32;
+  switch (math_mode) {
+    case DD3D_MATH_F32: hipLaunchKernelGGL(ese_gate_scale_kernel<DD3D_MATH_F32>, grid, dim3(256), 0, st, a); break;
+    case DD3D_MATH_BF16X3: hipLaunchKernelGGL(ese_gate_scale_kernel<DD3D_MATH_BF16X3>, grid, dim3(256), 0, st, a); break;
+    case DD3D_MATH_BF16X2: hipLaunchKernelGGL(ese_gate_scale_kernel<DD3D_MATH_BF16X2>, grid, dim3(256), 0, st, a); break;
+    case DD3D_MATH_BF16: hipLaunchKernelGGL(ese_gate_scale_kernel<DD3D_MATH_BF16>, grid, dim3(256), 0, st, a); break;
+    case DD3D_MATH_F16X2: hipLaunchKernelGGL(ese_gate_scale_kernel<DD3D_MATH_F16X2>, grid, dim3(256), 0, st, a); break;
+    default: DD3D_REQUIRE(false, "dd3d_ese_fused: math mode %d", math_mode);
+  }
+  return check_launch("ese_gate_scale_kernel");
 }

@@ -661,6 +661,41 @@ class PlanBase:
         self.ops.append(CallOp(_f, name, dict(kind="upsample2x_add", fine=fine, coarse=coarse)))
         self.f32_written(fine, name)
 
+    def ese(self, x, identity, out, fc, name="ese"):
+        Cc, HW = x.C, x.H * x.W
+        rs = max(1, min(64, HW // 256))
+        cr = fc.out_channels  # real channels; the buffers may be padded to a 32-multiple (zero channels stay zero: 0 * gate + 0)
+        w = torch.zeros((Cc, Cc), dtype=torch.float32)
+        w[:cr, :cr] = fc.weight.detach().float().reshape(cr, cr).cpu()
+        b = torch.zeros(Cc, dtype=torch.float32)
+        b[:cr] = fc.bias.detach().float().cpu()
+        w, b = self._vec(w), self._vec(b)
+        partial = torch.zeros((x.B, rs, Cc), dtype=torch.float32, device=self.device)
+        mean = torch.zeros((x.B, Cc), dtype=torch.float32, device=self.device)
+        counters = torch.zeros(x.B, dtype=torch.int32, device=self.device)  # per-image arrival counters of the pooling pass; the kernel leaves them zero
+        import os
+        fused = os.environ.get("DD3D_ESE_FUSED", "1") != "0"  # 0: the three-launch dd3d_ese_nhwc + a separate split (A/B measurements)
+        planes = fused and bool(out.np) and Cc % 32 == 0
+
+        def _f(lib, st):
+            if not fused:
+                hip.check(
+                    lib.dd3d_ese_nhwc(x.ptr, identity.ptr if identity is not None else None, out.ptr, w.data_ptr(), b.data_ptr(), partial.data_ptr(),
+                                      mean.data_ptr(), x.B, HW, Cc, x.pitch, identity.pitch if identity is not None else 0, out.pitch, rs, st), name)
+                return
+            # pool (+ per-image mean), then gate + scale (+ identity) -> f32 and split planes of the result: two launches, no separate split
+            hip.check(
+                lib.dd3d_ese_fused(x.ptr, identity.ptr if identity is not None else None, out.ptr if out.buf.has_f32 else None,
+                                   out.pptr if planes else None, w.data_ptr(), b.data_ptr(), partial.data_ptr(), mean.data_ptr(), counters.data_ptr(), x.B,
+                                   HW, Cc, x.pitch, identity.pitch if identity is not None else 0, out.pitch, rs, self.math,
+                                   out.buf.plane_scale if planes else 1.0, self.status.data_ptr(), st), name)
+
+        op = CallOp(_f, name, dict(kind="ese", x=x, identity=identity, out=out, weight=w, bias=b, planes=planes))
+        op.keep = [w, b, partial, mean, counters]
+        self.ops.append(op)
+        if out.np and not planes:
+            self.f32_written(out, name)
+
     # ------------------------------------------------------------------ side branches
     def branch(self, b):
         """with plan.branch(b): ops appended inside run on side stream b, concurrently with what the main stream does until
@@ -1014,28 +1049,6 @@ class ForwardPlan(PlanBase):
                 cat = nxt
             outs[sname] = prev = dst
         return {k: outs[k] for k in vov._out_features}
-
-    def ese(self, x, identity, out, fc, name="ese"):
-        Cc, HW = x.C, x.H * x.W
-        rs = max(1, min(64, HW // 256))
-        cr = fc.out_channels  # real channels; the buffers may be padded to a 32-multiple (zero channels stay zero: 0 * gate + 0)
-        w = torch.zeros((Cc, Cc), dtype=torch.float32)
-        w[:cr, :cr] = fc.weight.detach().float().reshape(cr, cr).cpu()
-        b = torch.zeros(Cc, dtype=torch.float32)
-        b[:cr] = fc.bias.detach().float().cpu()
-        w, b = self._vec(w), self._vec(b)
-        partial = torch.zeros((x.B, rs, Cc), dtype=torch.float32, device=self.device)
-        gate = torch.zeros((x.B, Cc), dtype=torch.float32, device=self.device)
-
-        def _f(lib, st):
-            hip.check(
-                lib.dd3d_ese_nhwc(x.ptr, identity.ptr if identity is not None else None, out.ptr, w.data_ptr(), b.data_ptr(), partial.data_ptr(),
-                                  gate.data_ptr(), x.B, HW, Cc, x.pitch, identity.pitch if identity is not None else 0, out.pitch, rs, st),
-                name
-            )
-
-        self.ops.append(CallOp(_f, name, dict(kind="ese", x=x, identity=identity, out=out, weight=w, bias=b)))
-        self.f32_written(out, name)
 
     # ------------------------------------------------------------------ FPN ([ext] detectron2 FPN.forward)
     def _fpn(self, fpn, feats):

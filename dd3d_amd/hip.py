@@ -113,7 +113,7 @@ EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
     "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8",
-    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_upsample2x_add_planes"
+    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_upsample2x_add_planes", "dd3d_ese_fused"
 ]
 
 
@@ -164,6 +164,7 @@ def lib():
     L.dd3d_math_planes.argtypes = [C.c_int32]
     L.dd3d_maxpool2x2_planes.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_float, C.c_void_p, C.c_void_p]
     L.dd3d_upsample2x_add_planes.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 7 + [C.c_float, C.c_void_p, C.c_void_p]
+    L.dd3d_ese_fused.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 8 + [C.c_float, C.c_void_p, C.c_void_p]
     L.dd3d_split_planes.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_float, C.c_void_p, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the .so is stale

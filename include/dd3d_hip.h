@@ -224,6 +224,16 @@ int dd3d_ese_nhwc(const float* x, const float* identity, float* out, const float
                   float* gate, int32_t B, int32_t HW, int32_t C, int32_t x_pitch, int32_t id_pitch, int32_t out_pitch,
                   int32_t rsplit, void* stream);
 
+/* The same module in two launches that also write the split planes of the result (pool + per-image mean; gate + scale (+ identity)
+ * -> f32 NHWC `out` (may be NULL) and / or the split planes of `math_mode` in `out_planes` (may be NULL; C % 32 == 0; layout and
+ * plane_scale as dd3d_split_planes)): 5 passes over the map instead of the 7 of dd3d_ese_nhwc + dd3d_split_planes.  Same summation
+ * order as dd3d_ese_nhwc.  C % 8 == 0, C <= 4096.
+ *   workspaces: partial [B][rsplit][C], mean [B][C], counters int32 [B] -- zero before the first launch, left zero by the kernel
+ *   status OR-ed with DD3D_STATUS_F16_OVERFLOW as dd3d_split_planes; may be NULL */
+int dd3d_ese_fused(const float* x, const float* identity, float* out, void* out_planes, const float* fc_w, const float* fc_b, float* partial,
+                   float* mean, int32_t* counters, int32_t B, int32_t HW, int32_t C, int32_t x_pitch, int32_t id_pitch, int32_t out_pitch,
+                   int32_t rsplit, int32_t math_mode, float plane_scale, int32_t* status, void* stream);
+
 /* fine[b,y,x,:] += coarse[b,y/2,x/2,:].  Replaces the FPN top-down step of detectron2 FPN.forward [ext]:
  * prev = lateral + F.interpolate(prev, scale_factor=2, mode="nearest").  H, W (of `fine`) even; C % 4 == 0. */
 int dd3d_upsample2x_add_nhwc(float* fine, const float* coarse, int32_t B, int32_t H, int32_t W, int32_t C,

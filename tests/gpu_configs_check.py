@@ -1,7 +1,7 @@
 """Dev tool: run the other BASELINE.json configurations at full size through the HIP path (graph replay) and report time,
 detections and peak memory:  DD3D-V2-99 KITTI 384x1280 (B = 1 and 4), NuscenesDD3D-DLA34 896x1600 (one 6-camera sample).
 
-    python tests/gpu_configs_check.py
+    python tests/gpu_configs_check.py [substring of the experiment name, e.g. v99]
 """
 import os
 import sys
@@ -25,7 +25,10 @@ CASES = [("dd3d_kitti_v99", "v99_kitti", "kitti", 1, 384, 1280), ("dd3d_kitti_v9
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     for exp, tag, ds, B, H, W in CASES:
+        if only not in exp:
+            continue
         torch.cuda.reset_peak_memory_stats()
         cfg = get_cfg(exp)
         model = build_model(cfg)

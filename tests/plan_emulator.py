@@ -111,6 +111,8 @@ def _track(forms, name, d):
         if d["identity"] is not None:
             forms.reads(d["identity"], "f32", name)
         forms.wrote(d["out"], "f32")
+        if d.get("planes"):
+            forms.wrote(d["out"], "planes")
 
 
 def emulate(plan, stop_before=("select_decode", )):
