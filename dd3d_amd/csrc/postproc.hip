@@ -592,13 +592,14 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void nms_mask_kernel(const NmsK P)
 //     per step (~2 k cycles per block row, the largest term of the kernel).
 //   * Meanwhile wave w holds word rb+w of the 64 rows (one lane per row); after the keep bits are published each wave ORs the
 //     words of the kept rows with a 6-step butterfly and folds them into removed[rb+w].
-// on_row(rb, keepbits) runs on wave 0 (all 64 lanes) for every block row, in order.
+// on_row(rb, keepbits) runs on wave 0 (all 64 lanes) for every block row, in order.  [rb_begin, rb_end): the block rows to resolve
+// (callers that stage the mask in pieces walk the rows chunk by chunk).
 template <class W, class F>
-__device__ __forceinline__ void greedy_reduce(W&& word_of, int n, unsigned long long* removed, F&& on_row) {
+__device__ __forceinline__ void greedy_reduce(W&& word_of, int n, unsigned long long* removed, F&& on_row, int rb_begin = 0, int rb_end = 1 << 30) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ unsigned long long sh_keepbits;
   const int nwords = (n + 63) / 64;
-  for (int rb = 0; rb < nwords; ++rb) {
+  for (int rb = rb_begin; rb < min(rb_end, nwords); ++rb) {
     const int i = rb * 64 + lane;
     if (wave == 0) {
       const unsigned long long col = i < n ? word_of(i, rb) : 0ull;
@@ -637,6 +638,7 @@ __device__ __forceinline__ void greedy_reduce(W&& word_of, int n, unsigned long 
 }
 
 constexpr int FIN_SMALL = 1024;  // up to this many candidates the whole upper triangle of the mask is staged in LDS (128 KiB)
+constexpr int FIN_LDS_BYTES = 156 * 1024;  // dynamic LDS of nms_finalize_kernel (the rest of the CU's 160 KiB: its static arrays)
 
 __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
@@ -648,16 +650,18 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const int nw = P.ncap / 64;
   const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(a.mask) + (long)g * P.ncap * nw;
 
-  // removed | kept | tkeys | tvals | sidx, the four arrays `cap` entries each; n <= FIN_SMALL: cap = FIN_SMALL, followed by lmask
+  // removed | kept | sidx | stage, the two arrays `cap` entries each (n <= FIN_SMALL: cap = FIN_SMALL).  `stage` holds mask words
+  // during the greedy pass and the top-k scratch (tkeys | tvals, `cap` entries each) after it.
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   const bool small = n <= FIN_SMALL && mode != NMS_NONE;
   const int cap = small ? FIN_SMALL : P.ncap2;
   unsigned long long* removed = reinterpret_cast<unsigned long long*>(dyn_lds);  // [NCAP_MAX/64]
   int* kept = reinterpret_cast<int*>(removed + NCAP_MAX / 64);  // sorted positions that survive NMS, in order
-  float* tkeys = reinterpret_cast<float*>(kept + cap);          // scratch for the top-k threshold
+  int* sidx = kept + cap;                                       // sort_idx staged once (cuts a level off every gather below)
+  unsigned long long* stage = reinterpret_cast<unsigned long long*>(sidx + cap);
+  float* tkeys = reinterpret_cast<float*>(stage);               // scratch for the top-k threshold
   int* tvals = reinterpret_cast<int*>(tkeys + cap);
-  int* sidx = tvals + cap;                                      // sort_idx staged once (cuts a level off every gather below)
-  unsigned long long* lmask = reinterpret_cast<unsigned long long*>(sidx + cap);  // [16][FIN_SMALL]: word cw of row i at cw*FIN_SMALL + i
+  const int stage_words = (FIN_LDS_BYTES - NCAP_MAX / 64 * 8 - cap * 8) / 8;
   for (int i = tid; i < n; i += PT) sidx[i] = sort_idx[i];
   __shared__ int wsum[PT / 64];
   __shared__ int sh_nkeep;
@@ -677,10 +681,12 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
       if ((keepbits >> tid) & 1ull) kept[base + __popcll(keepbits & ((1ull << tid) - 1ull))] = rb * 64 + tid;
       if (tid == 0) sh_nkeep = base + __popcll(keepbits);
     };
+    // The mask was written by other CUs, usually of other XCDs: a dependent trip to the L2 / fabric costs ~1.5 us (measured), and one
+    // such trip per block row was most of this kernel.  The words are therefore brought into LDS in as few trips as the LDS allows,
+    // <= 16 independent loads per thread per trip.
+    const int nwords = (n + 63) / 64;
     if (small) {
-      // one row per thread, its words from the diagonal on: <= 16 independent loads in flight, ONE trip to the L2 / fabric instead
-      // of one per block row (the mask was written by other CUs, usually of other XCDs: ~1.5 us per dependent trip, measured)
-      const int nwords = (n + 63) / 64;
+      // everything at once: one row per thread, its words from the diagonal on; word cw of row i at cw * FIN_SMALL + i
       unsigned long long w[FIN_SMALL / 64];
 #pragma unroll
       for (int q = 0; q < FIN_SMALL / 64; ++q) {
@@ -690,13 +696,38 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
 #pragma unroll
       for (int q = 0; q < FIN_SMALL / 64; ++q) {
         const int cw = (tid >> 6) + q;
-        if (cw < FIN_SMALL / 64) lmask[cw * FIN_SMALL + tid] = w[q];
+        if (cw < FIN_SMALL / 64) stage[cw * FIN_SMALL + tid] = w[q];
       }
       __syncthreads();
-      greedy_reduce([&](int i, int cw) { return lmask[cw * FIN_SMALL + i]; }, n, removed, on_row);
+      greedy_reduce([&](int i, int cw) { return stage[cw * FIN_SMALL + i]; }, n, removed, on_row);
     } else {
+      // chunks of R block rows: the R * 64 rows' words from column rb0 on, row-major with an odd pitch (conflict-free both ways)
       __syncthreads();
-      greedy_reduce([&](int i, int cw) { return mask[(long)i * nw + cw]; }, n, removed, on_row);
+      for (int rb0 = 0; rb0 < nwords;) {
+        const int wrow = nwords - rb0, pitch = wrow | 1;
+        const int R = min(wrow, min(stage_words / (64 * pitch), 16 * PT / (64 * wrow)));  // fits the stage and 16 loads per thread
+        if (R < 1) {  // (not reachable with NCAP_MAX = 8192: one block row of 128 words needs 8256 stage words)
+          greedy_reduce([&](int i, int cw) { return mask[(long)i * nw + cw]; }, n, removed, on_row, rb0, nwords);
+          break;
+        }
+        const int total = R * 64 * wrow;
+        unsigned long long w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int idx = tid + k * PT;
+          const int rl = idx / wrow, c = idx - rl * wrow, i = rb0 * 64 + rl;
+          w[k] = (idx < total && i < n) ? mask[(long)i * nw + rb0 + c] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int idx = tid + k * PT;
+          const int rl = idx / wrow, c = idx - rl * wrow;
+          if (idx < total) stage[rl * pitch + c] = w[k];
+        }
+        __syncthreads();
+        greedy_reduce([&](int i, int cw) { return stage[(i - rb0 * 64) * pitch + (cw - rb0)]; }, n, removed, on_row, rb0, rb0 + R);
+        rb0 += R;
+      }
     }
     nkeep = sh_nkeep;
   }
@@ -1176,13 +1207,11 @@ extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
   while (P.ncap2 < ns) P.ncap2 <<= 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds_sort = (size_t)P.ncap2 * 8;
-  const size_t lds_small = (size_t)NCAP_MAX / 64 * 8 + (size_t)FIN_SMALL * 16 + (size_t)FIN_SMALL * (FIN_SMALL / 64) * 8;  // 145 KiB
-  const size_t lds_fin = std::max((size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 16, lds_small);
+  const size_t lds_fin = FIN_LDS_BYTES;  // removed + kept + sidx (<= 65 KiB at NCAP_MAX) + the mask stage / top-k scratch
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)std::max((size_t)NCAP_MAX / 64 * 8 + (size_t)NCAP_MAX * 16, lds_small));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS_BYTES);
     attr_done = true;
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(args->G, SORT_SPLIT), dim3(PT), lds_sort, st, P);

@@ -26,8 +26,9 @@ CASES = [("dd3d_kitti_v99", "v99_kitti", "kitti", 1, 384, 1280), ("dd3d_kitti_v9
 
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else ""
+    only_b = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     for exp, tag, ds, B, H, W in CASES:
-        if only not in exp:
+        if only not in exp or (only_b and B != only_b):
             continue
         torch.cuda.reset_peak_memory_stats()
         cfg = get_cfg(exp)
