@@ -64,3 +64,53 @@ def test_staircase_needs_as_many_rounds_as_it_is_long():
     got, rounds = ballot_iteration(sup, alive)
     assert (got == sequential(sup, alive)).all() and got.tolist() == [i % 2 == 0 for i in range(64)]
     assert 32 <= rounds <= 65
+
+
+# ---- the two index schedules of the NMS kernels, restated with the constants read out of the source
+def _constants():
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dd3d_amd", "csrc", "postproc.hip")).read()
+    val = lambda name: int(eval(re.search(rf"constexpr int {name} = ([0-9*+ ]+);", src).group(1)))  # noqa: E731  (digits, * and + only)
+    return {k: val(k) for k in ("PT", "NCAP_MAX", "FIN_SMALL", "FIN_LDS_BYTES", "MASK_BLOCKS")}
+
+
+def test_tile_walk_covers_the_upper_triangle_once():
+    """nms_mask_kernel / bev_mask_kernel: tile t -> (rb, cb) by peeling rows of decreasing length (postproc.hip::tile_of)."""
+    def tile_of(t, nwords):
+        rb = 0
+        while t >= nwords - rb:
+            t -= nwords - rb
+            rb += 1
+        return rb, rb + t
+    for nwords in list(range(1, 20)) + [59, 64, 128]:
+        tiles = [tile_of(t, nwords) for t in range(nwords * (nwords + 1) // 2)]
+        assert sorted(tiles) == [(r, c) for r in range(nwords) for c in range(r, nwords)]
+
+
+def test_finalize_mask_staging_fits_the_lds_for_every_size():
+    """nms_finalize_kernel: the mask words travel to LDS in one piece (n <= FIN_SMALL) or in chunks of R block rows; every chunk
+    must fit the stage left beside the index arrays, need <= 16 loads per thread, and make progress."""
+    k = _constants()
+    PT, FIN_SMALL = k["PT"], k["FIN_SMALL"]
+    assert k["FIN_LDS_BYTES"] + 4096 <= 160 * 1024  # dynamic + the kernel's static arrays inside a CU's LDS
+    # small mode: removed + kept + sidx + the whole triangle [FIN_SMALL / 64][FIN_SMALL], then the top-k scratch in the same stage
+    stage_words = (k["FIN_LDS_BYTES"] - k["NCAP_MAX"] // 64 * 8 - FIN_SMALL * 8) // 8
+    assert stage_words >= FIN_SMALL // 64 * FIN_SMALL and stage_words >= FIN_SMALL
+    ncap2 = 2048
+    while ncap2 <= k["NCAP_MAX"]:
+        stage_words = (k["FIN_LDS_BYTES"] - k["NCAP_MAX"] // 64 * 8 - ncap2 * 8) // 8
+        assert stage_words >= ncap2  # tkeys | tvals alias the stage after the greedy pass
+        for n in range(FIN_SMALL + 1, ncap2 + 1, 61):
+            nwords = (n + 63) // 64
+            rb0, trips = 0, 0
+            while rb0 < nwords:
+                wrow = nwords - rb0
+                pitch = wrow | 1
+                R = min(wrow, stage_words // (64 * pitch), 16 * PT // (64 * wrow))
+                assert R >= 1, (ncap2, n, rb0)
+                assert R * 64 * pitch <= stage_words and R * 64 * wrow <= 16 * PT
+                rb0 += R
+                trips += 1
+            assert trips <= nwords
+        ncap2 *= 2
