@@ -348,6 +348,9 @@ def test_cabi_argument_validation_without_a_gpu(hiplib):
     cl = hip.ConvLaunch()
     assert L.dd3d_conv2d_igemm_f32(C.byref(cl), None) != 0 and "null descriptor" in err()
     assert L.dd3d_resize_bilinear_u8(C.byref(hip.ResizeArgs()), None) != 0 and "bad arguments" in err()
+    assert L.dd3d_ese_fused(None, None, None, None, None, None, None, None, None, 1, 4, 64, 64, 0, 64, 1, 0, 1.0, None, None) != 0
+    assert "dd3d_ese_fused: bad arguments" in err()
+    assert L.dd3d_ese_nhwc(None, None, None, None, None, None, None, 1, 4, 64, 64, 0, 64, 1, None) != 0 and "bad arguments" in err()
     with pytest.raises(RuntimeError, match="null pointer"):
         hip.check(L.dd3d_format_boxes3d(None, None, None, None, 5, None), "format_boxes3d")
 
