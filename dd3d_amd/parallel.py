@@ -44,6 +44,20 @@ def owner_of_image(g, B):
     return g // B
 
 
+def inference_shard(total_size, group_size, rank, world_size):
+    """Dataset indices rank `rank` evaluates -- the arithmetic of the reference's InferenceGroupSampler
+    (tridet/data/samplers/group_sampler.py:14-35): the dataset is a sequence of in-order groups (group_size = 1 for KITTI, the 6
+    cameras of a sample for nuScenes); every rank takes a contiguous run of WHOLE groups, ceil(groups / world) of them, the last ranks
+    possibly fewer or none.  A rank's per-step batch must then be a multiple of group_size, which is what keeps a sample's cameras
+    on one rank for the BEV aggregation that follows the gather."""
+    assert total_size > 0 and group_size > 0
+    assert total_size % group_size == 0, f"The total size must be divisible by group size: total size={total_size}, group size={group_size}"
+    num_groups = total_size // group_size
+    shard_size = ((num_groups - 1) // world_size + 1) * group_size
+    begin = min(shard_size * rank, total_size)
+    return range(begin, min(shard_size * (rank + 1), total_size))
+
+
 def gather_candidates(pairs, group=None):
     """The step's only exchange: all_gather every rank's record (ForwardPlan.gather_pairs(): one (record, [W x record]) pair) into
     the rank-major gathered buffer."""

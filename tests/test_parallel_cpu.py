@@ -4,6 +4,8 @@ segment of the gathered buffer, and every rank can see every rank's counts (dd3d
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -69,3 +71,20 @@ def test_gather_candidates_gloo_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), B, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_inference_shard_follows_the_reference_group_sampler():
+    """group_sampler.py:27-35: shard_size = ((num_groups - 1) // world + 1) * group_size; rank r takes [r * shard, (r + 1) * shard) cut at
+    the dataset size.  Values below are that formula worked by hand; the properties are what the BEV aggregation relies on."""
+    from dd3d_amd.parallel import inference_shard
+    assert list(inference_shard(18, 6, 0, 2)) == list(range(0, 12)) and list(inference_shard(18, 6, 1, 2)) == list(range(12, 18))
+    assert [len(inference_shard(3769, 1, r, 8)) for r in range(8)] == [472] * 7 + [465]  # KITTI val on 8 GPUs
+    assert [len(inference_shard(36114, 6, r, 8)) for r in range(8)] == [4518] * 7 + [4488]  # nuScenes val: 6019 samples x 6 cameras
+    assert list(inference_shard(12, 6, 3, 4)) == []  # more ranks than groups: the tail ranks get nothing
+    for total, group, world in [(36, 6, 4), (42, 6, 4), (7, 1, 3), (6, 6, 8), (600, 6, 7)]:
+        shards = [inference_shard(total, group, r, world) for r in range(world)]
+        flat = [i for sh in shards for i in sh]
+        assert flat == list(range(total))  # contiguous, in rank order, complete, disjoint
+        assert all(len(sh) % group == 0 and (len(sh) == 0 or sh[0] % group == 0) for sh in shards)  # whole groups only
+    with pytest.raises(AssertionError, match="divisible by group size"):
+        inference_shard(13, 6, 0, 2)
