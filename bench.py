@@ -8,10 +8,12 @@ A step = one forward pass of the hot path (uint8 image already resident in HBM -
 batch of synthetic 384x1280 KITTI-shaped frames, ``--batch`` images per GPU (default 1 = BASELINE.json configs[1]
 "DD3D-DLA34 KITTI3D 384x1280 bs=1 fp32 inference"; one image per GPU per step as the north star shards them).
 For N > 1 every rank forwards its own images and the step includes ONE RCCL all_gather of every rank's decoded-candidate record, after
-which each rank runs the batched NMS of the images it owns (dd3d_amd/parallel.py).  Steps are issued through PipelinedForward (default:
-sixteen plan slots on sixteen compute streams + one exchange/NMS stream, so several single-image steps are in flight and share the chip, and the
-collective runs under the next steps' trunks; `--pipeline 0` issues one step at a time and that figure is also reported in
-`config`); every one of the K timed steps does all of its work and is complete before the closing synchronize.
+which each rank runs the batched NMS of the images it owns (dd3d_amd/parallel.py).  Steps are issued through PipelinedForward: `--pipeline`
+plan slots on `--compute-streams` compute streams + one exchange/NMS stream; a slot's launch plan covers `--microbatch` queued
+single-image requests (a step = one request; the slot's graphs are enqueued when its last request arrives, the collective runs under
+the next slots' trunks).  `--pipeline 0` issues one step at a time and that figure is also reported in `config`.  Every one of the K
+timed steps does all of its work and is complete before the closing synchronize (a partly filled slot is flushed and runs in full).
+Every slot's graphs are replayed once at construction and the untimed warm-up covers every slot at least twice, whatever --warmup says.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch,
 conv_igemm_planes_kernel<2,2,4,2,...> of csrc/conv_planes.hip): algorithmic FLOPs of one launch / its mean duration measured here with
@@ -61,6 +63,8 @@ def parse_args():
                          "0 = one step at a time")
     ap.add_argument("--compute-streams", type=int, default=int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "16")),
                     help="PipelinedForward: streams the slots' trunks are issued on (> 1 lets consecutive steps share the chip)")
+    ap.add_argument("--microbatch", type=int, default=int(os.environ.get("DD3D_BENCH_MICROBATCH", "1")),
+                    help="PipelinedForward: queued requests (steps) one slot's launch plan covers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=200, help="upper bound; the CPU leg stops after ~12 s of work")
     ap.add_argument("--math", default=None, help="arithmetic of the convolutions: f16x2 (default) | bf16x3 | f32 | bf16x2 | bf16 (dd3d_amd.engine.default_math)")
@@ -115,7 +119,7 @@ def main():
     if args.pipeline > 0:
         try:
             runner = PipelinedForward(model, B, *_padded(model, args.height, args.width), depth=args.pipeline,
-                                      compute_streams=min(args.compute_streams, args.pipeline))
+                                      compute_streams=min(args.compute_streams, args.pipeline), microbatch=args.microbatch)
             plan = runner.plan
             runner.stage_all(inputs)
         except Exception as e:  # symmetric across ranks (same code, same sizes): every rank falls back together; reported in the JSON
@@ -131,14 +135,20 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    flush = getattr(runner, "flush", lambda: None)  # (a partly filled micro-batch slot runs in full before the clock stops)
+    # untimed warm-up: --warmup steps, but never fewer than two rounds over every slot of the pipeline (round 2's driver command,
+    # --warmup 5 on 16 slots, left 11 slots cold inside the timed block)
+    warm = max(args.warmup, 2 * args.pipeline * args.microbatch) if args.pipeline > 0 else args.warmup
+    for _ in range(warm):
         runner.step()
+    flush()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.step()
+    flush()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -158,6 +168,7 @@ def main():
         tb = time.perf_counter()
         for _ in range(args.steps):
             runner.step()
+        flush()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -168,7 +179,7 @@ def main():
             eb = float(t.item())
         block_ms.append(eb / args.steps * 1e3)
 
-    # for transparency: the same forward issued strictly one step at a time on one stream (not part of the timed region)
+    # for transparency: the same forward issued strictly one slot at a time on one stream (not part of the timed region)
     serial_ms = None
     if world == 1 and args.pipeline > 0:
         slot = runner.slots[0]
@@ -181,7 +192,7 @@ def main():
             slot.pre_graph.replay()
             slot.post_graph.replay()
         torch.cuda.synchronize()
-        serial_ms = (time.perf_counter() - t1) / 50 * 1e3
+        serial_ms = (time.perf_counter() - t1) / 50 * 1e3 / args.microbatch  # (one replay covers `microbatch` requests)
 
     for pl in ([sl.plan for sl in runner.slots] if hasattr(runner, "slots") else [plan]):
         pl.check_status()  # a half-range overflow of the f16x2 arithmetic would invalidate the run: fail loudly
@@ -197,20 +208,25 @@ def main():
             "workload": f"DD3D-DLA34 KITTI3D {args.height}x{args.width} bs={B}/GPU fp32 inference (BASELINE.json configs[1]); "
                         "uint8 image in HBM -> normalise/pad -> DLA-34 -> FPN P3-P7 -> FCOS2D/3D heads -> select/decode -> NMS",
             "global_batch": world * B, "parallelism": f"dp{world}" + ("+rccl_allgather_candidates" if world > 1 else ""),
-            "hip_graph": not args.no_graph, "pipeline_slots": args.pipeline, "compute_streams": args.compute_streams if args.pipeline else 1, "gflop_per_image": GFLOP_PER_IMAGE,
+            "hip_graph": not args.no_graph, "pipeline_slots": args.pipeline, "compute_streams": args.compute_streams if args.pipeline else 1,
+            "microbatch": args.microbatch if args.pipeline else 1, "warmup_steps_run": warm, "gflop_per_image": GFLOP_PER_IMAGE,
             "achieved_tflops_per_gpu": round(value / world * GFLOP_PER_IMAGE / 1e3, 2),
             "math": math_name, "split_planes": bool(plan.use_planes),
             "issue": (f"{args.pipeline} plan slots on {min(args.compute_streams, args.pipeline)} compute streams + 1 exchange/NMS stream "
-                      "(dd3d_amd.parallel.PipelinedForward): several single-image steps in flight share the chip; every step does all "
-                      "of its work and all K steps are complete at the closing synchronize") if args.pipeline else "one step at a time",
+                      f"(dd3d_amd.parallel.PipelinedForward); a slot's launch plan covers {args.microbatch} queued single-image request(s) "
+                      "(a step = one request of bs images; the slot is enqueued when its last request arrives, a partly filled slot is "
+                      "flushed -- and runs in full -- before the clock stops); every step does all of its work and all K steps are "
+                      "complete at the closing synchronize") if args.pipeline else "one step at a time",
             "pipeline_error": pipeline_error,
-            "ms_per_step_one_at_a_time": None if serial_ms is None else round(serial_ms, 4),
-            "images_per_s_one_at_a_time": None if serial_ms is None else round(B / serial_ms * 1e3, 2),
+            # one slot's two graph halves replayed back to back on one stream, nothing else in flight (per request: / microbatch)
+            "ms_per_step_one_slot_at_a_time": None if serial_ms is None else round(serial_ms, 4),
+            "images_per_s_one_slot_at_a_time": None if serial_ms is None else round(B / serial_ms * 1e3, 2),
             "frac_of_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4),
         },
         "blocks": {"n": len(block_ms), "steps_each": args.steps, "ms_per_step": [round(x, 4) for x in block_ms],
                    "median_ms_per_step": round(srt[len(srt) // 2], 4), "min_ms_per_step": round(srt[0], 4), "max_ms_per_step": round(srt[-1], 4),
                    "median_images_per_s": round(world * B / srt[len(srt) // 2] * 1e3, 2),
+                   "block0_over_median": round(block_ms[0] / srt[len(srt) // 2], 4),
                    "note": "block 0 is the timed region `value` comes from; the others repeat it"},
     }
 

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
-template <int TM, int TN, int WM, int WN, int MODE>
+template <int TM, int TN, int WM, int WN, int MODE, bool ALLOW_SK = true>
 static int launch_planes_tile(const ConvKArgs& ka, hipStream_t st) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
@@ -404,21 +404,25 @@ static int launch_planes_tile(const ConvKArgs& ka, hipStream_t st) {
   constexpr int NTHR = 64 * (WM * WN + PW);
   constexpr int STAGE = NP * (BM + BN) * 64;
   // LDS ring budgets (KiB): what a block may take decides how many blocks -- of this launch or of another stream's -- share a CU
-  constexpr int BUDGET = (WM * WN == 8 ? DD3D_LDS_KIB_8W : DD3D_LDS_KIB_4W) * 1024;
+  constexpr int BUDGET = ((WM * WN == 8 || STAGE > 32 * 1024) ? DD3D_LDS_KIB_8W : DD3D_LDS_KIB_4W) * 1024;  // (a big 4-wave tile owns its CU anyway)
   constexpr int NS0 = BUDGET / STAGE;
   constexpr int NS = NS0 > 4 ? 4 : (NS0 < 2 ? 2 : NS0);
   const size_t lds = (size_t)NS * STAGE;
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false, PW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true, PW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  static unsigned long long attr_done[4];
+  if (lds_opt_in_needed(attr_done)) {
+    if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false, PW>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    if constexpr (ALLOW_SK)
+      if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true, PW>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
   }
-  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true, PW>), grid, dim3(NTHR), lds, st, ka);
-  else hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false, PW>), grid, dim3(NTHR), lds, st, ka);
+  if constexpr (!ALLOW_SK) DD3D_REQUIRE(ka.splitk == 1, "dd3d_conv2d_igemm_f32: this tile has no split-K form (its accumulators fill the register file)");
+  if constexpr (ALLOW_SK) {
+    if (ka.splitk > 1) {
+      hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true, PW>), grid, dim3(NTHR), lds, st, ka);
+      return check_launch("launch_planes_tile split-K kernel");
+    }
+  }
+  hipLaunchKernelGGL((conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false, PW>), grid, dim3(NTHR), lds, st, ka);
   return check_launch("conv_igemm_planes kernel");
 }
 
@@ -435,6 +439,11 @@ static int launch_planes_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st)
     case DD3D_TILE_64x64_W4K2:
     case DD3D_TILE_64x64_W4: return launch_planes_tile<1, 1, 2, 2, MODE>(ka, st);
     case DD3D_TILE_128x64_W4: return launch_planes_tile<2, 1, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_256x128_T42: return launch_planes_tile<4, 2, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_128x256_T24: return launch_planes_tile<2, 4, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_256x256_W8:
+      if constexpr (Planes<MODE>::NP <= 2) return launch_planes_tile<4, 2, 2, 4, MODE, false>(ka, st);
+      break;
   }
   DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no split-plane kernel", tile_cfg);
 }

@@ -279,26 +279,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
-template <int TM, int TN, int WM, int WN, int MODE>
+template <int TM, int TN, int WM, int WN, int MODE, bool ALLOW_SK = true>
 static int launch_row_tile(const ConvKArgs& ka, hipStream_t st) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
   constexpr int A2 = 2 * NP * (BM + 16) * 64, BST = NP * BN * 64;
-  constexpr int BUDGET = (WM * WN == 8 ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
+  // (a 4-wave block whose two A stages alone exceed half a CU's LDS owns its CU anyway: it takes the 8-wave budget)
+  constexpr int BUDGET = ((WM * WN == 8 || A2 > 64 * 1024) ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
   constexpr int NSB = (A2 + 3 * BST <= BUDGET) ? 3 : 2;
   static_assert(A2 + NSB * BST + 64 <= 160 * 1024, "tile does not fit the LDS");
   const size_t lds = (size_t)A2 + (size_t)NSB * BST + 64;  // + the zero bytes invalid taps read
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  static unsigned long long attr_done[4];
+  if (lds_opt_in_needed(attr_done)) {
+    if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    if constexpr (ALLOW_SK)
+      if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
   }
-  if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>), grid, dim3(NTHR), lds, st, ka);
-  else hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>), grid, dim3(NTHR), lds, st, ka);
+  if constexpr (!ALLOW_SK) DD3D_REQUIRE(ka.splitk == 1, "dd3d_conv2d_igemm_f32: this tile has no split-K form (its accumulators fill the register file)");
+  if constexpr (ALLOW_SK) {
+    if (ka.splitk > 1) {
+      hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>), grid, dim3(NTHR), lds, st, ka);
+      return check_launch("launch_row_tile split-K kernel");
+    }
+  }
+  hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>), grid, dim3(NTHR), lds, st, ka);
   return check_launch("conv_igemm_planes_row kernel");
 }
 
@@ -315,6 +320,11 @@ static int launch_row_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st) {
     case DD3D_TILE_64x64_W4K2:
     case DD3D_TILE_64x64_W4: return launch_row_tile<1, 1, 2, 2, MODE>(ka, st);
     case DD3D_TILE_128x64_W4: return launch_row_tile<2, 1, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_256x128_T42: return launch_row_tile<4, 2, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_128x256_T24: return launch_row_tile<2, 4, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_256x256_W8:
+      if constexpr (Planes<MODE>::NP <= 2) return launch_row_tile<4, 2, 2, 4, MODE, false>(ka, st);
+      break;
   }
   DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no row-shared split-plane kernel", tile_cfg);
 }

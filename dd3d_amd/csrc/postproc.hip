@@ -403,6 +403,7 @@ struct NmsK {
   dd3d_nms_args a;
   int ncap;   // round_up(levels*topk, 64)
   int ncap2;  // next power of two >= levels*topk (size of the LDS sort arrays)
+  int fin_lds;  // dynamic LDS bytes nms_finalize_kernel was launched with
 };
 
 // Number of keys[lo, hi) that sort before (ki, position pos) in descending order, ties by position: the initial order of the
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   unsigned long long* stage = reinterpret_cast<unsigned long long*>(sidx + cap);
   float* tkeys = reinterpret_cast<float*>(stage);               // scratch for the top-k threshold
   int* tvals = reinterpret_cast<int*>(tkeys + cap);
-  const int stage_words = (FIN_LDS_BYTES - NCAP_MAX / 64 * 8 - cap * 8) / 8;
+  const int stage_words = (P.fin_lds - NCAP_MAX / 64 * 8 - cap * 8) / 8;
   for (int i = tid; i < n; i += PT) sidx[i] = sort_idx[i];
   __shared__ int wsum[PT / 64];
   __shared__ int sh_nkeep;
@@ -1207,12 +1208,14 @@ extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
   while (P.ncap2 < ns) P.ncap2 <<= 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds_sort = (size_t)P.ncap2 * 8;
-  const size_t lds_fin = FIN_LDS_BYTES;  // removed + kept + sidx (<= 65 KiB at NCAP_MAX) + the mask stage / top-k scratch
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS_BYTES);
-    attr_done = true;
+  // removed + kept + sidx + the mask stage / top-k scratch.  Images that can never exceed FIN_SMALL candidates take the staged-triangle
+  // path only (137 KiB); larger ones get everything the CU has beside the kernel's static arrays (the stage then holds more block rows).
+  const size_t lds_fin = P.ncap2 <= FIN_SMALL ? (size_t)NCAP_MAX / 64 * 8 + FIN_SMALL * 8 + (size_t)(FIN_SMALL / 64) * FIN_SMALL * 8 : (size_t)FIN_LDS_BYTES;
+  P.fin_lds = (int)lds_fin;
+  static unsigned long long attr_done[4];
+  if (lds_opt_in_needed(attr_done)) {
+    if (lds_opt_in(reinterpret_cast<const void*>(nms_sort_kernel), (size_t)(NCAP_MAX * 8), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    if (lds_opt_in(reinterpret_cast<const void*>(nms_finalize_kernel), (size_t)(FIN_LDS_BYTES), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(args->G, SORT_SPLIT), dim3(PT), lds_sort, st, P);
   int rc = check_launch("nms_sort_kernel");
@@ -1240,12 +1243,10 @@ extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds_prep = (size_t)P.ncap2 * 8;
   const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bev_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NCAP_MAX * 8);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bev_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              NCAP_MAX / 64 * 8 + NCAP_MAX * 4);
-    attr_done = true;
+  static unsigned long long attr_done[4];
+  if (lds_opt_in_needed(attr_done)) {
+    if (lds_opt_in(reinterpret_cast<const void*>(bev_prepare_kernel), (size_t)(NCAP_MAX * 8), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    if (lds_opt_in(reinterpret_cast<const void*>(bev_finalize_kernel), (size_t)(NCAP_MAX / 64 * 8 + NCAP_MAX * 4), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
   }
   hipLaunchKernelGGL(bev_prepare_kernel, dim3(1), dim3(PT), lds_prep, st, P);
   int rc = check_launch("bev_prepare_kernel");

@@ -150,10 +150,9 @@ static int launch_stem(const dd3d_smallc_args* a, hipStream_t st) {
   constexpr int PH = (TH - 1) * S + KH, PW = (TW - 1) * S + (CIN == 4 ? 8 : KW);
   const size_t lds = (size_t)3 * PH * PW * CIN * 2;
   auto k = stem_conv_bf16x3_kernel<CIN, KH, KW, S, NT, TH, TW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  static unsigned long long attr_done[4];
+  if (lds_opt_in_needed(attr_done)) {
+    if (lds_opt_in(reinterpret_cast<const void*>(k), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
   }
   StemK P;
   P.a = *a;

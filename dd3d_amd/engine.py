@@ -249,7 +249,9 @@ MATH_TILES = {  # tile configurations instantiated per arithmetic mode
                       hip.TILE_128x64_W4, hip.TILE_128x64_K2, hip.TILE_64x128_K2, hip.TILE_64x64_W4K2),
 }
 # the split-plane kernel (csrc/conv_planes.hip): one barrier per K-tile for every tile, so no "two K-tiles per barrier" variants
-PLANE_TILES = (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4, hip.TILE_128x64_W4)
+PLANE_TILES = (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4, hip.TILE_128x64_W4,
+               hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8)
+BIG_WAVE_TILES = (hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8)  # 8 accumulator blocks per wave; picked by the measured table only
 PLANE_TILE_ALIAS = {hip.TILE_128x64_K2: hip.TILE_128x64, hip.TILE_64x128_K2: hip.TILE_64x128, hip.TILE_64x64_W4K2: hip.TILE_64x64_W4}
 for _m in (hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2):
     MATH_TILES[_m] = PLANE_TILES
@@ -276,7 +278,8 @@ def kernel_signature(op):
     """Name of the kernel instantiation a ConvOp launches, as rocprofv3 prints it (bench.py / profiles bookkeeping)."""
     cfg = op.L.tile_cfg
     tm_tn_wm_wn = {hip.TILE_256x128: (2, 2, 4, 2), hip.TILE_128x128: (2, 1, 2, 4), hip.TILE_128x64: (1, 1, 4, 2), hip.TILE_64x128: (1, 1, 2, 4),
-                   hip.TILE_128x128_W4: (2, 2, 2, 2), hip.TILE_64x64_W4: (1, 1, 2, 2), hip.TILE_128x64_W4: (2, 1, 2, 2)}
+                   hip.TILE_128x128_W4: (2, 2, 2, 2), hip.TILE_64x64_W4: (1, 1, 2, 2), hip.TILE_128x64_W4: (2, 1, 2, 2),
+                   hip.TILE_256x128_T42: (4, 2, 2, 2), hip.TILE_128x256_T24: (2, 4, 2, 2), hip.TILE_256x256_W8: (4, 2, 2, 4)}
     sk = "true" if op.L.splitk > 1 else "false"
     if op.in_planes:
         tm, tn, wm, wn = tm_tn_wm_wn[PLANE_TILE_ALIAS.get(cfg, cfg)]
@@ -288,10 +291,10 @@ def kernel_signature(op):
                and os.environ.get("DD3D_CONV_ROW", "1") != "0")
         if row:  # csrc/conv_planes_row.hip: the three taps of a filter row share one A stage
             a2, bst = 2 * np_ * (bm + 16) * 64, np_ * bn * 64
-            nsb = 3 if a2 + 3 * bst <= (152 if wm * wn == 8 else 76) * 1024 else 2
+            nsb = 3 if a2 + 3 * bst <= (152 if (wm * wn == 8 or a2 > 65536) else 76) * 1024 else 2
             return f"dd3d::conv_igemm_planes_row_kernel<{tm}, {tn}, {wm}, {wn}, {nsb}, {op.math}, {sk}>"
         stage = np_ * (bm + bn) * 64
-        ns = max(2, min(4, ((144 if wm * wn == 8 else 72) * 1024) // stage))
+        ns = max(2, min(4, ((144 if (wm * wn == 8 or stage > 32768) else 72) * 1024) // stage))
         return f"dd3d::conv_igemm_planes_kernel<{tm}, {tn}, {wm}, {wn}, {ns}, {op.math}, {sk}, 0>"
     if op.math == hip.MATH_BF16X3:
         return f"dd3d::conv_igemm_bf16x3_kernel ({hip.TILE_NAMES[cfg]}, split-K {sk})"
@@ -335,6 +338,8 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
     nk = Kpad // 32
     best = None
     for cfg in allowed:
+        if cfg in BIG_WAVE_TILES:
+            continue  # (no analytic model: the measured table or an explicit `tile=` selects them)
         bm, bn = hip.TILE_SHAPES[cfg]
         if bn == 32 and N > 32:
             continue
@@ -518,8 +523,10 @@ class PlanBase:
         self.world_size = 1
         self.zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)  # padded-tap source of the DMA conv
         self.math = default_math()
-        self._split = {}
-        self._descaled = {}
+        # Packed filters, their 16-bit term planes and the de-scaled epilogue vectors.  A plan built for a model shares the MODEL's store
+        # (ForwardPlan.__init__ -> adopt_weight_store): every plan / pipeline slot of the model then reads the SAME device copies, so steps
+        # in flight on several slots hit the same L2 / MALL lines instead of streaming one private copy of the weights per slot.
+        self._packed, self._split, self._descaled = {}, {}, {}
         import math as _math
         # DD3D_MATH_F16X2: every split-plane activation holds value * act_scale (a power of two; |value| <= 65504 / act_scale or the
         # status word trips and the forward raises; terms below 2^-24 / act_scale are lost).  DD3D_F16_ACT_SCALE overrides.
@@ -545,6 +552,23 @@ class PlanBase:
             raise FloatingPointError(
                 f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}, or a "
                 "NaN / inf): lower DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
+
+    def adopt_weight_store(self, model):
+        """Use the model's weight store (created on first use; dropped by DD3D.invalidate_plans when the weights change)."""
+        store = model.__dict__.setdefault("_weight_store", {})
+        dev = store.setdefault(str(self.device), {"packed": {}, "split": {}, "descaled": {}})
+        self._packed, self._split, self._descaled = dev["packed"], dev["split"], dev["descaled"]
+
+    def pack(self, weights, cache=True):
+        """pack_filter with the plan's store in front: one packed copy per filter (list of filters) and device.  `cache=False` for
+        filters built on the fly (their storage is not owned by the model, so its address may be recycled)."""
+        if not cache:
+            return pack_filter(weights, self.device)
+        ws = list(weights) if isinstance(weights, (list, tuple)) else [weights]
+        key = tuple((w.data_ptr(), tuple(w.shape), w._version) for w in ws)
+        if key not in self._packed:
+            self._packed[key] = (ws, pack_filter(weights, self.device))  # (the sources stay referenced: their addresses are the key)
+        return self._packed[key][1]
 
     def split_weight(self, wp, math=hip.MATH_BF16X3):
         """16-bit term planes of a packed filter, built once per filter and mode (the towers share theirs over 5 levels)."""
@@ -616,7 +640,7 @@ class PlanBase:
             self.ops.append(op)
             self.f32_written(vout, name)
             return op
-        w, meta = pack_filter(weight, self.device)
+        w, meta = self.pack(weight, cache=not explicit and getattr(conv, "groups", 1) == 1)
         seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res,
                "write_f32": write_f32, "write_planes": write_planes}
         op = ConvOp(self, meta, conv.stride, conv.padding, [seg], relu, name=name, in_relu=in_relu)
@@ -777,6 +801,7 @@ class ForwardPlan(PlanBase):
         # the candidate exchange between select/decode and NMS exists when there are several ranks; `exchange=True` keeps its
         # buffers and the two-phase launch for one rank too (single-GPU check of the RCCL transport, tests/gpu_rccl_check.py)
         self.exchange = world_size > 1 if exchange is None else bool(exchange)
+        self.adopt_weight_store(model)
         self._trunk(model, B, Hp, Wp)
         # ---- heads + post-processing
         self._heads(model, self.features)
@@ -1132,7 +1157,7 @@ class ForwardPlan(PlanBase):
                 if i >= len(tower):
                     continue
                 conv = tower[i]
-                w, meta = pack_filter(conv.weight, dev)
+                w, meta = self.pack(conv.weight)
                 for l in range(L):
                     # ModuleListDial: level l uses norm[l] (normalization.py:30-40)
                     norm = conv.norm[l] if isinstance(conv.norm, torch.nn.ModuleList) else conv.norm
@@ -1157,7 +1182,7 @@ class ForwardPlan(PlanBase):
                 key = tuple(id(c[l if len(c) > 1 else 0]) for c in convs)
                 if key not in ws:
                     mods = [c[l if len(c) > 1 else 0] for c in convs]
-                    w, metas = pack_filter([m.weight for m in mods], dev)
+                    w, metas = self.pack([m.weight for m in mods])
                     b = torch.cat([
                         m.bias.detach().float().cpu() if m.bias is not None else torch.zeros(m.out_channels) for m in mods
                     ])
@@ -1228,16 +1253,16 @@ class ForwardPlan(PlanBase):
         n_max = max(m["N"] for _, m, _ in pred_groups)
         npad = (n_max + 31) // 32 * 32
         meta = dict(pred_groups[0][1], N=n_max, Npad=npad)
-        padded, all_segs = {}, []
+        all_segs = []
         for _, m, segs in pred_groups:
             assert (m["Cin"], m["KH"], m["KW"], m["Kpad"]) == (meta["Cin"], meta["KH"], meta["KW"], meta["Kpad"])
             for sg in segs:
-                key = sg["w"].data_ptr()
-                if key not in padded:
+                key = ("predictor_pad", sg["w"].data_ptr(), npad)
+                if key not in self._packed:  # (the store keeps the source referenced: its address is the key)
                     wpad = torch.zeros((npad, m["Kpad"]), dtype=torch.float32, device=dev)
                     wpad[:sg["w"].shape[0]] = sg["w"]
-                    padded[key] = wpad
-                all_segs.append(dict(sg, w=padded[key]))
+                    self._packed[key] = (sg["w"], wpad)
+                all_segs.append(dict(sg, w=self._packed[key][1]))
         self.ops.append(ConvOp(self, meta, 1, 1, all_segs, relu=False, name="predictors"))
 
     # ------------------------------------------------------------------ selection / decode / NMS
@@ -1416,6 +1441,7 @@ class DenseDepthPlan(ForwardPlan):
     the input resolution fused with the focal-length scaling."""
     def __init__(self, model, B, Hp, Wp, device=None, dry_run=False):
         PlanBase.__init__(self, device or model.device, dry_run=dry_run)
+        self.adopt_weight_store(model)
         self._trunk(model, B, Hp, Wp)
         dev, feats, head = self.device, self.features, model.fcos3d_head
         L, Cf = len(feats), feats[0].C
@@ -1424,7 +1450,7 @@ class DenseDepthPlan(ForwardPlan):
         cur = list(feats)
         for i, conv in enumerate(head.box3d_tower):
             dst = ping if i % 2 == 0 else pong
-            w, meta = pack_filter(conv.weight, dev)
+            w, meta = self.pack(conv.weight)
             segs = []
             for l in range(L):
                 norm = conv.norm[l] if isinstance(conv.norm, torch.nn.ModuleList) else conv.norm
@@ -1436,7 +1462,7 @@ class DenseDepthPlan(ForwardPlan):
         segs, self.dd_raw = [], []
         meta = None
         for l, conv in enumerate(head.dense_depth):
-            w, meta = pack_filter(conv.weight, dev)
+            w, meta = self.pack(conv.weight)
             b = conv.bias.detach().float().cpu() if conv.bias is not None else torch.zeros(1)
             sc = head.scales_depth[l].scale.detach().float().cpu() if head.use_scale else torch.ones(1)
             off = head.offsets_depth[l].bias.detach().float().cpu() if head.use_scale else torch.zeros(1)

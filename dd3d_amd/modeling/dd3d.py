@@ -67,8 +67,9 @@ class DD3D(nn.Module):
 
     # ------------------------------------------------------------------ plan management
     def invalidate_plans(self):
-        """Call after changing weights in place (plans hold packed copies of the weights)."""
+        """Call after changing weights in place (plans read packed copies of the weights, shared by all plans of the model)."""
         self._plans = {}
+        self.__dict__.pop("_weight_store", None)
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -77,7 +78,7 @@ class DD3D(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._plans = {}
+        self.invalidate_plans()
         return r
 
     def _sync_flags(self):
@@ -108,9 +109,11 @@ class DD3D(nn.Module):
             self._plans.pop(next(iter(self._plans)))
 
     # ------------------------------------------------------------------ host side of forward
-    def stage_inputs(self, batched_inputs, plan=None):
+    def stage_inputs(self, batched_inputs, plan=None, first=0, partial=False):
         """core.py:65-72: gather images/intrinsics; the padded canvas geometry is ImageList.from_tensors'
-        (image_list.py:120-142).  Returns (plan, image_sizes)."""
+        (image_list.py:120-142).  Returns (plan, image_sizes).  `first` (with a fixed `plan` only): the batch goes to positions
+        [first, first + len(batch)) of a plan; `partial` allows a batch shorter than the plan's (PipelinedForward micro-batches, the
+        short last batch of a shard): the other positions keep what they held and their outputs are the caller's to ignore."""
         images = [x["image"] for x in batched_inputs]
         image_sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         div = self.backbone.size_divisibility
@@ -128,26 +131,31 @@ class DD3D(nn.Module):
             if torch.allclose(K[0], torch.eye(3)):
                 raise ValueError("Intrinsics is Identity.")  # image_list.py:57-62
         if plan is None:
+            assert first == 0 and not partial
             plan = self.get_plan(B, H, W)
-        elif (B, H, W) != (plan.B, plan.Hp, plan.Wp):
-            # a fixed plan (DistributedForward / PipelinedForward): a short batch would broadcast silently into the size / intrinsics
-            # buffers, a smaller canvas would run on a larger padded canvas than the reference's ImageList (other border features)
-            raise ValueError(f"batch of {B} images on a {H}x{W} canvas does not fit the fixed launch plan (B={plan.B}, {plan.Hp}x{plan.Wp}); "
-                             "pad the batch / canvas or build a plan for this geometry")
+        elif (H, W) != (plan.Hp, plan.Wp) or first < 0 or first + B > plan.B or (B != plan.B and not partial):
+            # a fixed plan (DistributedForward / PipelinedForward): a short batch would leave stale images in the other positions (allowed
+            # only where the caller says so: `partial`), a smaller canvas would run on a larger padded canvas than the reference's
+            # ImageList (other border features)
+            raise ValueError(f"batch of {B} images on a {H}x{W} canvas at position {first} does not fit the fixed launch plan "
+                             f"(B={plan.B}, {plan.Hp}x{plan.Wp}); pad the batch / canvas or build a plan for this geometry")
+        sl = slice(first, first + B)
         for i, im in enumerate(images):
             assert im.dtype == torch.uint8 and im.shape[0] == 3, "expected uint8 (3,H,W) images (dataset_mapper.py:127)"
-            plan.in_u8[i, :, :im.shape[1], :im.shape[2]].copy_(im, non_blocking=True)
+            plan.in_u8[first + i, :, :im.shape[1], :im.shape[2]].copy_(im, non_blocking=True)
         sizes = torch.tensor(image_sizes, dtype=torch.int32)
         outsz = torch.tensor(
             [[s[0], s[1], x.get("height", s[0]), x.get("width", s[1])] for s, x in zip(image_sizes, batched_inputs)],
             dtype=torch.float32
         )
-        plan.in_sizes.copy_(sizes, non_blocking=True)
-        plan.in_K.copy_(K.reshape(B, 9), non_blocking=True)
-        plan.in_outsize.copy_(outsz, non_blocking=True)
+        plan.in_sizes[sl].copy_(sizes, non_blocking=True)
+        plan.in_K[sl].copy_(K.reshape(B, 9), non_blocking=True)
+        plan.in_outsize[sl].copy_(outsz, non_blocking=True)
         if plan.has_bev_inputs:  # BEV stages need camera->global poses and sample membership
-            plan.in_pose.copy_(torch.tensor([self._pose_vec(x) for x in batched_inputs], dtype=torch.float32), non_blocking=True)
-            plan.in_group.copy_(torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32), non_blocking=True)
+            plan.in_pose[sl].copy_(torch.tensor([self._pose_vec(x) for x in batched_inputs], dtype=torch.float32), non_blocking=True)
+            # sample ids are per request: offset by the position so that requests sharing a plan never merge their samples
+            groups = torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32) + first
+            plan.in_group[sl].copy_(groups, non_blocking=True)
         return plan, image_sizes
 
     @staticmethod
@@ -189,7 +197,7 @@ class DD3D(nn.Module):
             if not self.only_box2d:
                 r.pred_boxes3d = Boxes3D(
                     d[:, 10:14].contiguous(), d[:, 14:16].contiguous(), d[:, 16:17].contiguous(), d[:, 17:20].contiguous(),
-                    inv_K[i][None].expand(n, 3, 3)
+                    inv_K[g][None].expand(n, 3, 3)
                 )
                 r.scores_3d = d[:, 5].contiguous()
             self._collect_extra(r, d, plan)
@@ -214,7 +222,7 @@ class DD3D(nn.Module):
             import warnings
             warnings.warn(f"dd3d_amd: {e}; switching this model to math='bf16x3'")
             self.math = "bf16x3"
-            self._plans.clear()
+            self._plans.clear()  # (the weight store is keyed by arithmetic mode: the packed filters stay, the bf16x3 planes are added)
             plan, image_sizes = self.stage_inputs(batched_inputs)
             plan.run()
             return self.collect(plan, batched_inputs, image_sizes)

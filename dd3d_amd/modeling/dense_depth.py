@@ -74,14 +74,19 @@ class DD3DDenseDepth(nn.Module):
             raise NotImplementedError("dd3d_amd implements the inference math only")
         return super().train(False)
 
+    def invalidate_plans(self):
+        """Plans read packed copies of the weights (one store per model, shared by its plans): drop both."""
+        self._plans = {}
+        self.__dict__.pop("_weight_store", None)
+
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
-        self._plans = {}
+        self.invalidate_plans()
         return r
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._plans = {}
+        self.invalidate_plans()
         return r
 
     def get_plan(self, B, Hp, Wp):
@@ -102,7 +107,23 @@ class DD3DDenseDepth(nn.Module):
     @torch.no_grad()
     def predict_dense_depth(self, batched_inputs):
         """dense_depth.py:121-151 up to (not including) the losses: a list over pyramid levels of (B, Hp, Wp) depth maps at the
-        padded input resolution, on the model's device."""
+        padded input resolution, on the model's device.  The default f16x2 arithmetic is guarded exactly as in DD3D.forward: a kernel
+        that met an activation outside the half range trips the plan's status word, the maps are NOT returned, and a model on the
+        default arithmetic re-runs (from then on) with the three-term bf16 split."""
+        try:
+            return self._predict_dense_depth(batched_inputs)
+        except FloatingPointError as e:
+            from dd3d_amd import hip
+            from dd3d_amd.engine import default_math
+            if self.math is not None or default_math() != hip.MATH_F16X2:
+                raise  # the mode was asked for explicitly
+            import warnings
+            warnings.warn(f"dd3d_amd: {e}; switching this model to math='bf16x3'")
+            self.math = "bf16x3"
+            self._plans.clear()
+            return self._predict_dense_depth(batched_inputs)
+
+    def _predict_dense_depth(self, batched_inputs):
         images = [x["image"] for x in batched_inputs]
         div = self.backbone.size_divisibility
         H = max(int(im.shape[-2]) for im in images)
@@ -123,6 +144,7 @@ class DD3DDenseDepth(nn.Module):
                 raise ValueError("Intrinsics is Identity.")  # image_list.py:57-62
             plan.in_K.copy_(K.reshape(B, 9), non_blocking=True)
         plan.run()
+        plan.check_status()  # one 4-byte read behind the forward (the caller is about to consume the maps anyway); raises and clears
         return [m for m in plan.depth_maps]
 
     def forward(self, batched_inputs):

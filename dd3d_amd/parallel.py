@@ -58,6 +58,29 @@ def inference_shard(total_size, group_size, rank, world_size):
     return range(begin, min(shard_size * (rank + 1), total_size))
 
 
+def padded_inference_shard(total_size, group_size, rank, world_size, batch_size):
+    """`inference_shard` for runners that hold a collective in every step: (indices, valid) of equal length ON EVERY RANK.
+
+    The reference's sampler hands the tail ranks fewer items or none (KITTI val on 8 GPUs: 7 x 472 + 465), and its forward has no
+    collective, so ranks may stop early.  Here every step of every rank takes part in one all_gather: a rank that stops early -- or the
+    short final batch of a shard -- would leave the others waiting in RCCL until the watchdog fires.  This helper pads every rank's
+    shard to the SAME number of whole batches, steps = ceil(shard_size / batch_size) of the largest shard: padding entries repeat the
+    rank's last real index (rank with an empty shard: index 0, any valid image) and carry valid = False; the caller feeds them like
+    any other image and drops their outputs (`DistributedForward.forward(batch, valid=...)` does).  batch_size must be a multiple of
+    group_size so that a nuScenes sample never straddles two steps."""
+    assert batch_size > 0 and batch_size % group_size == 0, "a step's batch must hold whole groups"
+    own = list(inference_shard(total_size, group_size, rank, world_size))
+    largest = len(inference_shard(total_size, group_size, 0, world_size))  # rank 0 always holds a full shard
+    steps = -(-largest // batch_size)
+    n = steps * batch_size
+    fill = own[-group_size:] if own else list(range(group_size))  # a whole group, so that padded nuScenes batches stay group-complete
+    idx, valid = list(own), [True] * len(own)
+    while len(idx) < n:
+        idx += fill
+        valid += [False] * len(fill)
+    return idx[:n], valid[:n]
+
+
 def gather_candidates(pairs, group=None):
     """The step's only exchange: all_gather every rank's record (ForwardPlan.gather_pairs(): one (record, [W x record]) pair) into
     the rank-major gathered buffer."""
@@ -111,36 +134,63 @@ class DistributedForward:
         else:
             p.launch(p.num_pre_nms_ops)
 
-    def forward(self, batched_inputs):
-        plan, image_sizes = self.model.stage_inputs(batched_inputs, plan=self.plan)
+    def forward(self, batched_inputs, valid=None):
+        """One step.  Every rank must call this the same number of times (each call holds the step's collective): feed the ranks with
+        `padded_inference_shard`.  A batch shorter than the plan's (the last batch of a shard, or none at all) is completed with the
+        images the plan's buffers already hold -- the step still runs in full -- and only the given images are returned; `valid`
+        (list of bool, from padded_inference_shard) drops padding images from the result as well."""
+        image_sizes = []
+        if len(batched_inputs):
+            _, image_sizes = self.model.stage_inputs(batched_inputs, plan=self.plan, partial=len(batched_inputs) < self.plan.B)
         self.step()
-        return self.model.collect(plan, batched_inputs, image_sizes)
+        if not len(batched_inputs):
+            torch.cuda.current_stream().synchronize()
+            return []
+        out = self.model.collect(self.plan, batched_inputs, image_sizes)
+        if valid is not None:
+            assert len(valid) == len(out)
+            out = [o for o, v in zip(out, valid) if v]
+        return out
 
 
 class PipelinedForward:
-    """Throughput mode of the same step: `depth` plan slots (each with its own buffers and its own pair of captured hipGraph
-    halves); the trunk + heads + select/decode of step i+1 run on the compute stream while the candidate exchange (RCCL) and the NMS
-    stages of step i run on the post stream, so the collective and the latency-bound tail never stall the MFMA kernels.
-    Results are identical to `DistributedForward` (same kernels, same buffers per slot); only the order on the device changes.
+    """Throughput mode of the same step: `depth` plan slots (each with its own activation buffers and its own pair of captured hipGraph
+    halves; the packed weights are the model's, shared by all slots); the trunk + heads + select/decode of step i+1 run on a compute
+    stream while the candidate exchange (RCCL) and the NMS stages of step i run on the post stream, so the collective and the
+    latency-bound tail never stall the MFMA kernels.  Results are identical to `DistributedForward` (same kernels, same buffers per
+    slot); only the order on the device changes.
 
-        h = runner.submit(batched_inputs)   # stages the inputs, enqueues both halves, returns at once
-        out = runner.result(h)              # waits for that step only
-    """
-    def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1):
+        h = runner.submit(batched_inputs)   # stages the inputs, enqueues the slot's graphs once it is full, returns at once
+        out = runner.result(h)              # waits for that request only
+
+    `microbatch` = M > 1: a slot's launch plan covers M REQUESTS of B images each (plan batch M * B).  Requests are staged into the
+    slot one after the other and the slot is enqueued when the M-th arrives (or at `flush()` / `result()` of one of its requests,
+    with the unfilled positions holding whatever they held before -- their outputs are never read).  Per-request semantics are
+    unchanged: every image is convolved, decoded and NMS-ed on its own, so a request's result does not depend on what shares its slot;
+    what changes is that the small backbone / FPN launches cover M x the pixels each (256 CUs are not filled by one 384 x 1280
+    image's coarse levels) and there are M x fewer launches per image.
+
+    Every slot's graphs are replayed once at construction, so the first timed step of a caller does not pay a first-launch cost.
+
+    Numeric guard: `result()` raises FloatingPointError when the default f16x2 arithmetic met an activation outside the half range
+    (dd3d_amd.engine.PlanBase.check_status); unlike `DD3D.forward` the runner does not rebuild itself on the three-term arithmetic --
+    steps of several slots (and, with several ranks, a collective per step) are in flight.  Serve a model whose activation range has
+    not been validated with `model.math = "bf16x3"`; with several ranks every rank must treat the error as fatal for the run."""
+    def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1, microbatch=1):
         from dd3d_amd.engine import ForwardPlan
-        assert depth >= 1 and compute_streams >= 1
+        assert depth >= 1 and compute_streams >= 1 and microbatch >= 1
         self.model = model
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.exchange = self.world > 1 or bool(force_exchange)
-        self.B = B
+        self.B, self.microbatch = B, int(microbatch)
         model._sync_flags()
         # compute_streams > 1: consecutive steps' trunks are issued on different streams and may share the chip
         self.compute_streams = [torch.cuda.Stream() for _ in range(compute_streams)]
         self.post_stream = torch.cuda.Stream()
         self.slots = []
         for _ in range(depth):
-            p = ForwardPlan(model, B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
+            p = ForwardPlan(model, B * self.microbatch, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
             p.launch()  # warm-up outside capture
             torch.cuda.synchronize()
             pre, post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -153,12 +203,27 @@ class PipelinedForward:
             slot.pre_done, slot.post_done, slot.released = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             slot.post_done.record()
             slot.released.record()
-            slot.inputs = slot.image_sizes = None
+            slot.requests = [None] * self.microbatch  # (inputs, image_sizes) of the requests staged into the slot
+            slot.fill, slot.enqueued, slot.generation = 0, True, 0
             slot.compute_stream = self.compute_streams[len(self.slots) % compute_streams]
             self.slots.append(slot)
         torch.cuda.synchronize()
+        # first replay of every slot's graphs (a hipGraph's first launch uploads it: ~10x a steady replay), on the streams they will use;
+        # a collective is NOT issued here (the ranks would have to agree on it) -- the post half runs on the zeroed record
+        for slot in self.slots:
+            with torch.cuda.stream(slot.compute_stream):
+                slot.pre_graph.replay()
+                slot.pre_done.record(slot.compute_stream)
+            self.post_stream.wait_event(slot.pre_done)
+            with torch.cuda.stream(self.post_stream):
+                slot.post_graph.replay()
+                slot.post_done.record(self.post_stream)
+        torch.cuda.synchronize()
+        for slot in self.slots:
+            slot.plan.status.zero_()
         self.plan = self.slots[0].plan
         self._next = 0
+        self._filling = None  # the slot requests are being staged into
 
     def _enqueue(self, slot):
         cs, ps = slot.compute_stream, self.post_stream
@@ -172,6 +237,9 @@ class PipelinedForward:
                 gather_candidates(slot.plan.gather_pairs())
             slot.post_graph.replay()
             slot.post_done.record(ps)
+        slot.enqueued = True
+        if self._filling is slot:
+            self._filling = None
 
     def _acquire(self):
         slot = self.slots[self._next % len(self.slots)]
@@ -179,21 +247,41 @@ class PipelinedForward:
         # the slot's previous step must be over before its buffers are rewritten (a no-op wait when it finished long ago)
         slot.compute_stream.wait_event(slot.post_done)
         slot.compute_stream.wait_event(slot.released)
+        slot.fill, slot.enqueued = 0, False
+        slot.generation += 1
         return slot
+
+    def _position(self):
+        """(slot, position) the next request goes to."""
+        if self._filling is None:
+            self._filling = self._acquire()
+        slot = self._filling
+        j = slot.fill
+        slot.fill += 1
+        return slot, j
 
     def step(self):
-        """One step on inputs already resident in the slot's buffers (bench: `stage_all`)."""
-        slot = self._acquire()
-        self._enqueue(slot)
+        """One request on inputs already resident in the slot's buffers (bench: `stage_all`); the slot is enqueued when its
+        `microbatch`-th request arrives.  Returns the slot."""
+        slot, j = self._position()
+        if slot.fill == self.microbatch:
+            self._enqueue(slot)
         return slot
 
+    def flush(self):
+        """Enqueue a partly filled slot (the whole plan runs; the unfilled positions' outputs are never read)."""
+        if self._filling is not None and not self._filling.enqueued:
+            self._enqueue(self._filling)
+
     def stage_all(self, batched_inputs):
+        """The same B inputs into every position of every slot (bench: inputs resident before the timed region)."""
         for slot in self.slots:
-            self.model.stage_inputs(batched_inputs, plan=slot.plan)
+            for j in range(self.microbatch):
+                self.model.stage_inputs(batched_inputs, plan=slot.plan, first=j * self.B, partial=True)
         torch.cuda.synchronize()
 
     def submit(self, batched_inputs):
-        slot = self._acquire()
+        slot, j = self._position()
         # device-resident inputs (DeviceInputMapper / DeviceResizer outputs) were produced on the caller's current stream: the staging
         # copies on the slot's compute stream must order after them, and the allocator must not recycle them before the copies ran
         slot.compute_stream.wait_stream(torch.cuda.current_stream())
@@ -201,18 +289,25 @@ class PipelinedForward:
             if x["image"].is_cuda:
                 x["image"].record_stream(slot.compute_stream)
         with torch.cuda.stream(slot.compute_stream):
-            _, slot.image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan)
-        slot.inputs = batched_inputs
-        self._enqueue(slot)
-        return slot
+            _, image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan, first=j * self.B, partial=True)
+        slot.requests[j] = (batched_inputs, image_sizes)
+        if slot.fill == self.microbatch:
+            self._enqueue(slot)
+        return (slot, j, slot.generation)
 
-    def result(self, slot):
+    def result(self, handle):
+        slot, j, gen = handle if isinstance(handle, tuple) else (handle, 0, handle.generation)
+        assert gen == slot.generation, "the slot of this request has been re-used: collect results within `depth` slots of submitting"
+        if not slot.enqueued:
+            self.flush()
         slot.post_done.synchronize()
-        out = self.model.collect(slot.plan, slot.inputs, slot.image_sizes)
+        inputs, image_sizes = slot.requests[j]
+        out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
         slot.released.record()  # the copies out of the detection buffer are enqueued: later steps of this slot order after them
         return out
 
     def synchronize(self):
+        self.flush()
         for cs in self.compute_streams:
             cs.synchronize()
         self.post_stream.synchronize()

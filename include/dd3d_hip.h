@@ -146,7 +146,12 @@ int dd3d_math_planes(int32_t math_mode);
 #define DD3D_TILE_128x64_K2 9  /* 8 waves, two K-tiles (64 k) per barrier */
 #define DD3D_TILE_64x128_K2 10
 #define DD3D_TILE_64x64_W4K2 11
-#define DD3D_TILE_COUNT 12
+/* split-plane kernels only: wave tiles of 128 x 64 / 64 x 128 outputs (8 accumulator blocks per wave) -- one ds_read_b128 per two MFMAs
+ * in the two-term modes instead of two per three; 4-wave blocks hold one wave per SIMD (up to 512 registers each) */
+#define DD3D_TILE_256x128_T42 12 /* 4 waves (2 x 2), wave tile 128 x 64 */
+#define DD3D_TILE_128x256_T24 13 /* 4 waves (2 x 2), wave tile 64 x 128 */
+#define DD3D_TILE_256x256_W8 14  /* 8 waves (2 x 4), wave tile 128 x 64; one- and two-term modes only */
+#define DD3D_TILE_COUNT 15
 /* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
 int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
 int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);
