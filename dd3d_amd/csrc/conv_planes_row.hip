@@ -183,7 +183,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     const unsigned char* Bs = lds + B_BASE + sb * B_STAGE + fb_off[c];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+#ifdef DD3D_ROW_NOMASK  // timing experiment only (wrong at image borders): what the per-read address selects cost
+      const bool ok = true;
+#else
       const bool ok = (vmask[i] >> tap) & 1u;
+#endif
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int off = ok ? abase + p * PLA + i * 32 * 64 : ZERO_OFF;

@@ -406,6 +406,15 @@ struct NmsK {
   int fin_lds;  // dynamic LDS bytes nms_finalize_kernel was launched with
 };
 
+// Word offset of image g's block (`per_img` 4-byte words per image) relative to the pointer of record 0 / image 0: dense arrays when
+// img_per_rec == 0, else image (img_first + g) % P of record (img_first + g) / P, records rec_stride words apart (dd3d_hip.h, ABI 3).
+__device__ __forceinline__ long rec_off(int g, int img_first, int img_per_rec, long rec_stride, int per_img) {
+  if (img_per_rec <= 0) return (long)g * per_img;
+  const int gg = img_first + g;
+  const int r = gg / img_per_rec;
+  return (long)r * rec_stride + (long)(gg - r * img_per_rec) * per_img;
+}
+
 // Number of keys[lo, hi) that sort before (ki, position pos) in descending order, ties by position: the initial order of the
 // sorters is by increasing value index, so "val_j < val_i" is "j < pos" and the index array need not be read.  One broadcast
 // ds_read_b128 feeds four comparisons; lo and hi are multiples of 4 and keys past the last candidate hold -inf.
@@ -436,7 +445,8 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
   const int g = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   const int L = a.num_levels, NS = slot_base(a.slot_off, L, a.topk, L);
-  const float* cand = a.cand + (long)g * DD3D_CAND_FIELDS * NS;
+  const float* cand = a.cand + rec_off(g, a.img_first, a.img_per_rec, a.rec_stride, DD3D_CAND_FIELDS * NS);
+  const int32_t* counts = a.counts + rec_off(g, a.img_first, a.img_per_rec, a.rec_stride, L);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];  // keys[ncap2] | vals[ncap2]
   float* keys = reinterpret_cast<float*>(dyn_lds);
   int* vals = reinterpret_cast<int*>(dyn_lds) + P.ncap2;
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(PT) void nms_sort_kernel(const NmsK P) {
     int acc = 0;
     for (int l = 0; l < L; ++l) {
       pref[l] = acc;
-      acc += a.counts[g * L + l];
+      acc += counts[l];
     }
     pref[L] = acc;
   }
@@ -645,7 +655,7 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   const dd3d_nms_args& a = P.a;
   const int g = blockIdx.x, tid = threadIdx.x;
   const int L = a.num_levels, NS = slot_base(a.slot_off, L, a.topk, L);
-  const float* cand = a.cand + (long)g * DD3D_CAND_FIELDS * NS;
+  const float* cand = a.cand + rec_off(g, a.img_first, a.img_per_rec, a.rec_stride, DD3D_CAND_FIELDS * NS);
   const int n = a.nvalid[2 * g], mode = a.nvalid[2 * g + 1];
   const int* sort_idx = a.sort_idx + (long)g * P.ncap;
   const int nw = P.ncap / 64;
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(PT) void nms_finalize_kernel(const NmsK P) {
   }
 
   // ---- resize / clip / drop empty ([ext] detector_postprocess) + ordered write-out
-  const float* osz = a.out_size + 4 * g;
+  const float* osz = a.out_size + rec_off(g, a.img_first, a.img_per_rec, a.rec_stride, 4);
   const float in_h = osz[0], in_w = osz[1], out_h = osz[2], out_w = osz[3];
   const float sx = out_w / in_w, sy = out_h / in_h;
   float* det = a.det + (long)g * a.det_cap * DD3D_DET_FIELDS;
@@ -975,13 +985,13 @@ __global__ __launch_bounds__(PT) void bev_prepare_kernel(const BevK P) {
     int g = 0;
     while (g + 1 < a.G && i >= offs[g + 1]) ++g;
     const float* d = a.det_in + ((long)g * a.det_cap + (i - offs[g])) * DD3D_DET_FIELDS;
-    const float* K = a.inv_K + 9 * g;
+    const float* K = a.inv_K + rec_off(g, a.img_first, a.img_per_rec, a.rec_stride, 9);
     // camera-frame box: tvec = K^-1 [proj_ctr, 1] * depth  (boxes3d.py:169-173)
     const float u = d[14], v = d[15], dep = d[16];
     const float tS[3] = {(K[0] * u + K[1] * v + K[2]) * dep, (K[3] * u + K[4] * v + K[5]) * dep, (K[6] * u + K[7] * v + K[8]) * dep};
     float R_SO[9], R_WS[9], R_WO[9], qW[4], tW[3], R[9];
     quat_to_mat(d + 10, R_SO);
-    const float* ps = a.pose + 7 * g;
+    const float* ps = a.pose + rec_off(g, a.img_first, a.img_per_rec, a.rec_stride, 7);
     quat_to_mat(ps, R_WS);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1138,7 +1148,7 @@ __global__ __launch_bounds__(PT) void bev_finalize_kernel(const BevK P) {
   // survivors, image by image, in their original order
   int running = 0;
   for (int g = 0; g < a.G; ++g) {
-    const float* osz = a.out_size + 4 * g;
+    const float* osz = a.out_size + rec_off(g, a.img_first, a.img_per_rec, a.rec_stride, 4);
     const float sx = osz[3] / osz[1], sy = osz[2] / osz[0];
     int img_run = 0;
     for (int base = offs[g]; base < offs[g + 1]; base += PT) {
@@ -1201,6 +1211,8 @@ extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
                    args->det && args->det_count,
                "dd3d_nms_finalize: null buffer");
   DD3D_REQUIRE(args->det_cap > 0, "dd3d_nms_finalize: det_cap=%d", args->det_cap);
+  DD3D_REQUIRE(args->img_per_rec >= 0 && args->img_first >= 0 && (args->img_per_rec == 0 || args->rec_stride > 0),
+               "dd3d_nms_finalize: record addressing img_first=%d img_per_rec=%d rec_stride=%lld", args->img_first, args->img_per_rec, (long long)args->rec_stride);
   NmsK P;
   P.a = *args;
   P.ncap = (ns + 63) / 64 * 64;
@@ -1234,6 +1246,8 @@ extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
   DD3D_REQUIRE(args->det_in && args->count_in && args->inv_K && args->pose && args->group && args->out_size && args->work && args->sbox &&
                    args->mask && args->meta && args->det_out && args->count_out,
                "dd3d_bev_nms_aggregate: null buffer");
+  DD3D_REQUIRE(args->img_per_rec >= 0 && args->img_first >= 0 && (args->img_per_rec == 0 || args->rec_stride > 0),
+               "dd3d_bev_nms_aggregate: record addressing img_first=%d img_per_rec=%d rec_stride=%lld", args->img_first, args->img_per_rec, (long long)args->rec_stride);
   BevK P;
   P.a = *args;
   const long ntot = (long)args->G * args->det_cap;

@@ -796,8 +796,9 @@ class PlanBase:
 
 class ForwardPlan(PlanBase):
     """Static launch plan of DD3D.forward (inference) for one (B, Hp, Wp)."""
-    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0, exchange=None):
+    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0, exchange=None, camera_sharded=False):
         super().__init__(device or model.device, dry_run=dry_run)
+        self.camera_sharded = camera_sharded
         # the candidate exchange between select/decode and NMS exists when there are several ranks; `exchange=True` keeps its
         # buffers and the two-phase launch for one rank too (single-GPU check of the RCCL transport, tests/gpu_rccl_check.py)
         self.exchange = world_size > 1 if exchange is None else bool(exchange)
@@ -1315,21 +1316,32 @@ class ForwardPlan(PlanBase):
             a.slot_off[l] = self.slot_off[l]
         self.scratch_idx = torch.empty(B * off, dtype=torch.int32, device=dev)
         self.scratch_score = torch.empty(B * off, dtype=torch.float32, device=dev)
-        # What a rank hands to the others is ONE contiguous record: [candidates B x F x NS | counts B x L | resize targets B x 4];
-        # the post-select stages read the record out of the gathered buffer, so they are ordered behind the collective.
+        # What a rank hands to the others is ONE contiguous record of 4-byte words:
+        #   [candidates B x F x NS | counts B x L | resize targets B x 4 | K^-1 B x 9 | camera->global pose B x 7]
+        # (the last two are what the BEV stages need of an image beside its detections: with them in the record, the owner of a nuScenes
+        # sample can aggregate cameras that OTHER ranks decoded).  The post-select stages read records out of the gathered buffer, so
+        # they are ordered behind the collective.
         pad4 = lambda n: (n + 3) // 4 * 4
-        n_c, n_k, n_o = pad4(B * hip.CAND_FIELDS * NS), pad4(B * L), pad4(B * 4)
-        self.record_len = n_c + n_k + n_o
+        n_c, n_k, n_o, n_i, n_p = pad4(B * hip.CAND_FIELDS * NS), pad4(B * L), pad4(B * 4), pad4(B * 9), pad4(B * 7)
+        self.record_fields = dict(cand=(0, hip.CAND_FIELDS * NS), counts=(n_c, L), outsize=(n_c + n_k, 4), inv_K=(n_c + n_k + n_o, 9),
+                                  pose=(n_c + n_k + n_o + n_i, 7))  # name -> (word offset in a record, words per image)
+        self.record_len = n_c + n_k + n_o + n_i + n_p
 
         def views(rec):
-            return (rec[:B * hip.CAND_FIELDS * NS].view(B, hip.CAND_FIELDS, NS), rec[n_c:n_c + B * L].view(torch.int32).view(B, L),
-                    rec[n_c + n_k:n_c + n_k + B * 4].view(B, 4))
+            f = self.record_fields
+            cut = lambda name: rec[f[name][0]:f[name][0] + B * f[name][1]]
+            return (cut("cand").view(B, hip.CAND_FIELDS, NS), cut("counts").view(torch.int32).view(B, L), cut("outsize").view(B, 4),
+                    cut("inv_K").view(B, 9), cut("pose").view(B, 7))
 
         self.record = torch.zeros(self.record_len, dtype=torch.float32, device=dev)
-        self.cand, self.counts, outsize = views(self.record)
+        self.cand, self.counts, outsize, inv_K, pose = views(self.record)
         outsize.copy_(self.in_outsize)
         self.in_outsize = outsize  # stage_inputs writes the resize targets straight into the record
+        self.inv_K = inv_K         # dd3d_invert_intrinsics writes K^-1 straight into the record (the launch reads self.inv_K when it runs)
+        self.in_pose = pose
+        self.in_pose[:, 0] = 1.0   # identity rotation until stage_inputs fills it (models without BEV stages never do)
         self.npass = torch.zeros((B, L), dtype=torch.int32, device=dev)
+        a.inv_K = self.inv_K.data_ptr()
         a.scratch_idx, a.scratch_score = self.scratch_idx.data_ptr(), self.scratch_score.data_ptr()
         a.cand, a.counts, a.npass = self.cand.data_ptr(), self.counts.data_ptr(), self.npass.data_ptr()
         self.select_args = a
@@ -1337,17 +1349,55 @@ class ForwardPlan(PlanBase):
         self.num_pre_nms_ops = len(self.ops)
 
         # The exchange (dd3d_amd.parallel): every rank's record is all-gathered into `gathered` [W x record]; each rank then finalises
-        # the images it OWNS -- its own B (class-aware NMS is per image; the cameras of a nuScenes sample are kept rank-local, as the
-        # reference's InferenceGroupSampler does, tridet/data/samplers/group_sampler.py:30-35) -- out of ITS segment of the gathered
-        # buffer: no rank repeats another rank's NMS.
-        self.G = G = B
+        # the images it OWNS out of the gathered buffer (no rank repeats another rank's NMS):
+        #   * default -- its own B images, i.e. ITS segment (class-aware NMS is per image; a nuScenes sample's cameras are rank-local
+        #     when the caller shards whole samples, as the reference's InferenceGroupSampler does, group_sampler.py:30-35);
+        #   * camera_sharded (NuscenesDD3D, "images shard one-per-GPU"): global image g = rank * B + b, the 6 consecutive global images
+        #     6 s .. 6 s + 5 are the cameras of sample s, and the rank that decoded a sample's FIRST camera owns the sample: it runs the
+        #     2D NMS of all six cameras and the sample-level BEV aggregation on records other ranks delivered.
+        inf = cfg.DD3D.INFERENCE
+        bev_single = bool(inf.DO_BEV_NMS) and self.b3d_maps is not None
+        bev_sample = bool(getattr(model, "aggregates_samples", False)) and bool(inf.DO_POSTPROCESS) and self.b3d_maps is not None
         self.world_size, self.rank = world_size, rank
+        self.camera_sharded = bool(self.camera_sharded)
+        if self.camera_sharded:
+            ncam = int(getattr(model, "num_images_per_sample", 6))
+            if not (self.exchange and bev_sample):
+                raise ValueError("camera_sharded needs the candidate exchange and a model that aggregates samples (NuscenesDD3D with DO_POSTPROCESS)")
+            if (world_size * B) % ncam:
+                raise ValueError(f"camera_sharded: {world_size} ranks x {B} images per step do not make whole {ncam}-camera samples")
+            own = [s_ for s_ in range(world_size * B // ncam) if (s_ * ncam) // B == rank]  # contiguous: the owner grows with the sample
+            self.own_samples = own
+            self.G = G = ncam * len(own)
+            self.img_first = ncam * own[0] if own else 0
+        else:
+            self.own_samples = None
+            self.G = G = B
+            self.img_first = rank * B if self.exchange else 0
         if self.exchange:
             self.gathered = torch.zeros(world_size * self.record_len, dtype=torch.float32, device=dev)
-            self.cand_all, self.counts_all, self.outsize_all = views(self.gathered[rank * self.record_len:(rank + 1) * self.record_len])
+            self.cand_all, self.counts_all, self.outsize_all, _, _ = views(self.gathered[rank * self.record_len:(rank + 1) * self.record_len])
+            src = self.gathered
         else:
             self.gathered = None
             self.cand_all, self.counts_all, self.outsize_all = self.cand, self.counts, self.in_outsize
+            src = self.record
+
+        def field_ptr(name):  # record 0's block of a field in the buffer the post stages read
+            return src.data_ptr() + 4 * self.record_fields[name][0]
+
+        def addressing(args):
+            args.img_first, args.img_per_rec, args.rec_stride = (self.img_first, B, self.record_len) if self.exchange else (0, 0, 0)
+
+        self.has_bev_inputs = self.has_global_boxes = False
+        self.det_cap = NS if (not inf.DO_NMS or inf2.POST_NMS_TOPK <= 0) else min(NS, int(inf2.POST_NMS_TOPK) + 156)
+        self.det = torch.zeros((G, self.det_cap, hip.DET_FIELDS), dtype=torch.float32, device=dev)
+        self.det_count = torch.zeros((G, ), dtype=torch.int32, device=dev)
+        if bev_single or bev_sample:
+            self.has_bev_inputs = True
+            self.in_group = torch.zeros((B, ), dtype=torch.int32, device=dev)
+        if G == 0:
+            return  # a camera-sharded rank that owns no sample of the step: it only contributes its record
         ncap = (NS + 63) // 64 * 64
         n = hip.NmsArgs()
         self.sort_idx = torch.zeros((G, ncap), dtype=torch.int32, device=dev)
@@ -1355,11 +1405,8 @@ class ForwardPlan(PlanBase):
         self.scls = torch.zeros((G, ncap), dtype=torch.int32, device=dev)
         self.mask = torch.zeros((G, ncap, ncap // 64), dtype=torch.int64, device=dev)
         self.nvalid = torch.zeros((G, 2), dtype=torch.int32, device=dev)
-        inf = cfg.DD3D.INFERENCE
-        self.det_cap = NS if (not inf.DO_NMS or inf2.POST_NMS_TOPK <= 0) else min(NS, int(inf2.POST_NMS_TOPK) + 156)
-        self.det = torch.zeros((G, self.det_cap, hip.DET_FIELDS), dtype=torch.float32, device=dev)
-        self.det_count = torch.zeros((G, ), dtype=torch.int32, device=dev)
-        n.cand, n.counts = self.cand_all.data_ptr(), self.counts_all.data_ptr()
+        n.cand, n.counts = field_ptr("cand"), field_ptr("counts")
+        addressing(n)
         n.G, n.num_levels, n.topk = G, L, topk
         for l in range(L + 1):
             n.slot_off[l] = self.slot_off[l]
@@ -1367,35 +1414,28 @@ class ForwardPlan(PlanBase):
         n.nms_thresh, n.post_topk = float(inf2.NMS_THRESH), int(inf2.POST_NMS_TOPK)
         # BEV stages (core.py:135-150, nuscenes_dd3d.py:423-465) run after the 2D NMS; the resize / clip / non-empty filter
         # of detector_postprocess sits between them, so it moves into whichever kernel comes at that point.
-        bev_single = bool(inf.DO_BEV_NMS) and self.b3d_maps is not None
-        bev_sample = bool(getattr(model, "aggregates_samples", False)) and bool(inf.DO_POSTPROCESS) and self.b3d_maps is not None
         n.do_postprocess = int(bool(inf.DO_POSTPROCESS) and not bev_single)
-        n.out_size = self.outsize_all.data_ptr()
+        n.out_size = field_ptr("outsize")
         n.sort_idx, n.sbox, n.scls = self.sort_idx.data_ptr(), self.sbox.data_ptr(), self.scls.data_ptr()
         n.mask, n.nvalid = self.mask.data_ptr(), self.nvalid.data_ptr()
         n.det, n.det_count, n.det_cap = self.det.data_ptr(), self.det_count.data_ptr(), self.det_cap
         self.nms_args = n
         self.nms_op = CallOp(lambda lib, st: hip.check(lib.dd3d_nms_finalize(C.byref(n), st), "nms_finalize"), "nms_finalize")
         self.ops.append(self.nms_op)
-        self.has_bev_inputs = self.has_global_boxes = False
         if bev_single or bev_sample:
-            # The images that meet in a BEV stage (one image, or the 6 cameras of a sample) are always on the rank that
-            # decoded them (InferenceGroupSampler hands out whole samples, tridet/data/samplers.py), so with W ranks the
-            # stages run over this rank's slice [rank*B, (rank+1)*B) of the gathered detection buffers.
-            first = 0  # (the detection buffers hold this rank's images only)
-            self.has_bev_inputs = True
-            self.in_pose = torch.zeros((B, 7), dtype=torch.float32, device=dev)
-            self.in_pose[:, 0] = 1.0
-            self.in_group = torch.zeros((B, ), dtype=torch.int32, device=dev)
-            ntot = B * self.det_cap
-            if ntot > 8192:
-                raise NotImplementedError(f"BEV NMS over {B} images x {self.det_cap} detections exceeds the 8192-box LDS sorter")
+            # One BEV problem per call over the G images this rank finalises (the reference concatenates the batch: one
+            # batched_nms_rotated, postprocessing.py:86-94).  Capacity: the LDS sorter holds 8192 BOXES -- actual detections, counted
+            # on the device (<= POST_NMS_TOPK per image after the 2D stage: 81 images at 100); more trips the overflow flag, count_out
+            # = -1, and collect() raises.
+            ntot = G * self.det_cap
             ncapb = (ntot + 63) // 64 * 64
             self.bev_work = torch.zeros((ntot, 16), dtype=torch.float32, device=dev)
             self.bev_sbox = torch.zeros((ntot, 8), dtype=torch.float32, device=dev)
-            self.bev_mask = torch.zeros((ncapb, ncapb // 64), dtype=torch.int64, device=dev)
+            self.bev_mask = torch.zeros((min(ncapb, 8192), ncapb // 64), dtype=torch.int64, device=dev)  # rows: sorted boxes (<= 8192)
             self.bev_meta = torch.zeros((4, ), dtype=torch.int32, device=dev)
-            self.own_group = torch.arange(B, dtype=torch.int32, device=dev)  # dummy_group_idxs = {i: [i]} (core.py:137)
+            self.own_group = torch.arange(G, dtype=torch.int32, device=dev)  # dummy_group_idxs = {i: [i]} (core.py:137)
+            if self.camera_sharded:  # sample membership is positional: cameras 6 s .. 6 s + 5 of the global order
+                self.in_group = torch.arange(G, dtype=torch.int32, device=dev) // ncam
             self.bev_args = []
             self.det_stages = [(self.det, self.det_count)]  # every stage's buffers stay referenced: the arg structs hold raw pointers
 
@@ -1403,17 +1443,18 @@ class ForwardPlan(PlanBase):
                 b = hip.BevArgs()
                 det_out = torch.zeros_like(self.det)
                 cnt_out = torch.zeros_like(self.det_count)
-                b.det_in, b.count_in = self.det[first:].data_ptr(), self.det_count[first:].data_ptr()
-                b.inv_K, b.pose, b.group = self.inv_K.data_ptr(), self.in_pose.data_ptr(), group.data_ptr()
-                b.out_size = self.in_outsize.data_ptr()
-                b.G, b.det_cap, b.num_classes = B, self.det_cap, C_
+                b.det_in, b.count_in = self.det.data_ptr(), self.det_count.data_ptr()
+                b.inv_K, b.pose, b.group = field_ptr("inv_K"), field_ptr("pose"), group.data_ptr()
+                b.out_size = field_ptr("outsize")
+                addressing(b)
+                b.G, b.det_cap, b.num_classes = G, self.det_cap, C_
                 b.iou_thresh, b.max_dets = float(inf.BEV_NMS_IOU_THRESH), int(max_dets)
                 b.write_global, b.do_postprocess = int(write_global), int(do_pp)
                 b.work, b.sbox, b.mask, b.meta = self.bev_work.data_ptr(), self.bev_sbox.data_ptr(), self.bev_mask.data_ptr(), self.bev_meta.data_ptr()
-                b.det_out, b.count_out = det_out[first:].data_ptr(), cnt_out[first:].data_ptr()
+                b.det_out, b.count_out = det_out.data_ptr(), cnt_out.data_ptr()
                 self.bev_args.append(b)
                 self.ops.append(CallOp(lambda lib, st, b=b: hip.check(lib.dd3d_bev_nms_aggregate(C.byref(b), st), name), name))
-                self.det, self.det_count = det_out, cnt_out  # what collect() reads (this rank's slice only when W > 1)
+                self.det, self.det_count = det_out, cnt_out  # what collect() reads
                 self.det_stages.append((det_out, cnt_out))
 
             if bev_single:
@@ -1427,12 +1468,27 @@ class ForwardPlan(PlanBase):
         the NMS stages."""
         return [(self.record, self.gathered)]
 
+    def gathered_field(self, name):
+        """Field `name` (record_fields) of every rank's images as delivered by the exchange: [W * B, words per image], rank-major =
+        global image order.  counts come back as int32."""
+        off, per = self.record_fields[name]
+        g = self.gathered.view(self.world_size, self.record_len)[:, off:off + self.B * per]
+        if name == "counts":
+            g = g.view(torch.int32)
+        return g.reshape(self.world_size * self.B, per)
+
     def gathered_counts(self):
         """Candidate counts [W*B, L] of every rank's images as delivered by the exchange (diagnostics / tests)."""
-        B, L, NS = self.B, self.num_levels, self.slots_per_image
-        n_c = (B * hip.CAND_FIELDS * NS + 3) // 4 * 4
-        g = self.gathered.view(self.world_size, self.record_len)
-        return g[:, n_c:n_c + B * L].view(torch.int32).reshape(self.world_size * B, L)
+        return self.gathered_field("counts")
+
+    def image_offset(self, g, name):
+        """Word offset, relative to record 0's block of field `name`, of image g of the post stages -- the arithmetic of
+        csrc/postproc.hip::rec_off (tests check the two against each other)."""
+        per = self.record_fields[name][1]
+        if not self.exchange:
+            return g * per
+        gg = self.img_first + g
+        return (gg // self.B) * self.record_len + (gg % self.B) * per
 
 
 class DenseDepthPlan(ForwardPlan):

@@ -16,7 +16,7 @@ _lib = None
 MAX_LEVELS = 8
 MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16, MATH_F16X2 = 0, 1, 2, 3, 4
 MATH_PLANES = {MATH_F32: 0, MATH_BF16X3: 3, MATH_BF16X2: 2, MATH_BF16: 1, MATH_F16X2: 2}  # 16-bit terms per value (dd3d_math_planes)
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATUS_F16_OVERFLOW = 1
 CAND_FIELDS = 22
 DET_FIELDS = 32
@@ -96,7 +96,8 @@ class NmsArgs(C.Structure):
         ("do_nms", C.c_int32), ("use_score3d", C.c_int32), ("nms_thresh", C.c_float), ("post_topk", C.c_int32),
         ("do_postprocess", C.c_int32), ("out_size", C.c_void_p), ("sort_idx", C.c_void_p), ("sbox", C.c_void_p),
         ("scls", C.c_void_p), ("mask", C.c_void_p), ("nvalid", C.c_void_p), ("det", C.c_void_p), ("det_count", C.c_void_p),
-        ("det_cap", C.c_int32), ("slot_off", C.c_int32 * (MAX_LEVELS + 1))
+        ("det_cap", C.c_int32), ("slot_off", C.c_int32 * (MAX_LEVELS + 1)), ("img_first", C.c_int32), ("img_per_rec", C.c_int32),
+        ("rec_stride", C.c_int64)
     ]
 
 
@@ -107,7 +108,7 @@ class BevArgs(C.Structure):
         ("out_size", C.c_void_p), ("G", C.c_int32), ("det_cap", C.c_int32), ("num_classes", C.c_int32),
         ("iou_thresh", C.c_float), ("max_dets", C.c_int32), ("write_global", C.c_int32),
         ("do_postprocess", C.c_int32), ("work", C.c_void_p), ("sbox", C.c_void_p), ("mask", C.c_void_p), ("meta", C.c_void_p),
-        ("det_out", C.c_void_p), ("count_out", C.c_void_p)
+        ("det_out", C.c_void_p), ("count_out", C.c_void_p), ("img_first", C.c_int32), ("img_per_rec", C.c_int32), ("rec_stride", C.c_int64)
     ]
 
 

@@ -89,12 +89,12 @@ class DD3D(nn.Module):
         inf.DO_BEV_NMS, inf.BEV_NMS_IOU_THRESH = bool(self.do_bev_nms), float(self.bev_nms_iou_thresh)
         return (bool(self.postprocess_in_inference), bool(self.do_nms), bool(self.do_bev_nms))
 
-    def get_plan(self, B, Hp, Wp, world_size=1, rank=0, exchange=None):
+    def get_plan(self, B, Hp, Wp, world_size=1, rank=0, exchange=None, camera_sharded=False):
         exchange = world_size > 1 if exchange is None else bool(exchange)
-        key = (B, Hp, Wp, world_size, rank, exchange, self.math) + self._sync_flags()
+        key = (B, Hp, Wp, world_size, rank, exchange, bool(camera_sharded), self.math) + self._sync_flags()
         plan = self._plans.pop(key, None)
         if plan is None:
-            plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank, exchange=exchange)
+            plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank, exchange=exchange, camera_sharded=camera_sharded)
             if self.use_graph and not exchange:
                 plan.capture()
         self._plans[key] = plan  # (re-)inserted last = most recently used
@@ -153,9 +153,10 @@ class DD3D(nn.Module):
         plan.in_outsize[sl].copy_(outsz, non_blocking=True)
         if plan.has_bev_inputs:  # BEV stages need camera->global poses and sample membership
             plan.in_pose[sl].copy_(torch.tensor([self._pose_vec(x) for x in batched_inputs], dtype=torch.float32), non_blocking=True)
-            # sample ids are per request: offset by the position so that requests sharing a plan never merge their samples
-            groups = torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32) + first
-            plan.in_group[sl].copy_(groups, non_blocking=True)
+            if not getattr(plan, "camera_sharded", False):  # (camera-sharded: membership is positional in the global image order)
+                # sample ids are per request: offset by the position so that requests sharing a plan never merge their samples
+                groups = torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32) + first
+                plan.in_group[sl].copy_(groups, non_blocking=True)
         return plan, image_sizes
 
     @staticmethod
@@ -167,41 +168,69 @@ class DD3D(nn.Module):
     def _sample_groups(self, batched_inputs):
         return list(range(len(batched_inputs)))
 
-    def collect(self, plan, batched_inputs, image_sizes, first=0):
-        """Detection buffer -> List[{"instances": Instances}] with the reference's fields (core.py:153-164)."""
+    def _counts(self, plan):
+        """Detection counts of the plan's last forward (this is the host's wait for the forward), with the device-side faults checked."""
         counts = plan.det_count.cpu()
         if getattr(plan, "check_status", None) is not None:
             plan.check_status()  # a numeric fault flagged by a kernel (half-range overflow of the f16x2 mode) fails the forward loudly
+        if counts.numel() and int(counts.min()) < 0:
+            raise RuntimeError("more than 8192 detections met in one BEV NMS problem (the capacity of its LDS sorter): feed fewer images per step")
         n_max = int(counts.max()) if counts.numel() else 0
         if n_max > plan.det_cap:
             raise RuntimeError(f"{n_max} detections exceed the detection buffer ({plan.det_cap}); raise det_cap")
+        return counts, n_max
+
+    def _instances(self, plan, d, size, inv_K):
+        """Rows of the detection buffer (a private copy) -> Instances with the reference's fields (core.py:153-164)."""
+        n = d.shape[0]
+        r = Instances(size)
+        r.pred_boxes = Boxes(d[:, 0:4].contiguous())
+        r.scores = d[:, 4].contiguous()
+        r.pred_classes = d[:, 6].to(torch.int64)
+        r.locations = d[:, 8:10].contiguous()
+        r.fpn_levels = d[:, 7].to(torch.int64)
+        if not self.only_box2d:
+            r.pred_boxes3d = Boxes3D(
+                d[:, 10:14].contiguous(), d[:, 14:16].contiguous(), d[:, 16:17].contiguous(), d[:, 17:20].contiguous(),
+                inv_K[None].expand(n, 3, 3)
+            )
+            r.scores_3d = d[:, 5].contiguous()
+        self._collect_extra(r, d, plan)
+        return r
+
+    def collect(self, plan, batched_inputs, image_sizes, first=0):
+        """Detection buffer -> List[{"instances": Instances}] for the images at positions [first, first + len(batch)) of the plan."""
+        counts, n_max = self._counts(plan)
         det = plan.det[:, :max(n_max, 1)]
         inv_K = plan.inv_K.view(-1, 3, 3).clone()  # the results must not alias a buffer the next forward overwrites
         results = []
         for i, (inp, isz) in enumerate(zip(batched_inputs, image_sizes)):
             g = first + i
-            n = int(counts[g])
             # one private copy per image: a (1, k) slice of the detection buffer is "contiguous" whatever its row stride, so
             # .contiguous() on such a slice would return a VIEW of the plan buffer that the next forward overwrites
-            d = det[g, :n].clone()
-            if self.postprocess_in_inference:
-                size = (int(inp.get("height", isz[0])), int(inp.get("width", isz[1])))
-            else:
-                size = isz
-            r = Instances(size)
-            r.pred_boxes = Boxes(d[:, 0:4].contiguous())
-            r.scores = d[:, 4].contiguous()
-            r.pred_classes = d[:, 6].to(torch.int64)
-            r.locations = d[:, 8:10].contiguous()
-            r.fpn_levels = d[:, 7].to(torch.int64)
-            if not self.only_box2d:
-                r.pred_boxes3d = Boxes3D(
-                    d[:, 10:14].contiguous(), d[:, 14:16].contiguous(), d[:, 16:17].contiguous(), d[:, 17:20].contiguous(),
-                    inv_K[g][None].expand(n, 3, 3)
-                )
-                r.scores_3d = d[:, 5].contiguous()
-            self._collect_extra(r, d, plan)
-            results.append({"instances": r})
+            d = det[g, :int(counts[g])].clone()
+            size = (int(inp.get("height", isz[0])), int(inp.get("width", isz[1]))) if self.postprocess_in_inference else isz
+            results.append({"instances": self._instances(plan, d, size, inv_K[g])})
+        return results
+
+    def collect_owned(self, plan):
+        """Camera-sharded plans (engine.ForwardPlan(camera_sharded=True)): the detections of the samples THIS rank owns, as
+        [(global image index, {"instances": Instances})] -- cameras that other ranks decoded included.  Everything comes from the
+        device: counts and detections from the owner's post stages, image sizes and K^-1 from the gathered records."""
+        assert plan.camera_sharded
+        if plan.G == 0:
+            torch.cuda.current_stream().synchronize()
+            return []
+        counts, n_max = self._counts(plan)
+        det = plan.det[:, :max(n_max, 1)]
+        sl = slice(plan.img_first, plan.img_first + plan.G)
+        osz = plan.gathered_field("outsize")[sl].cpu()
+        inv_K = plan.gathered_field("inv_K")[sl].reshape(-1, 3, 3).clone()
+        results = []
+        for g in range(plan.G):
+            d = det[g, :int(counts[g])].clone()
+            size = (int(osz[g, 2]), int(osz[g, 3])) if self.postprocess_in_inference else (int(osz[g, 0]), int(osz[g, 1]))
+            results.append((plan.img_first + g, {"instances": self._instances(plan, d, size, inv_K[g])}))
         return results
 
     def _collect_extra(self, r, d, plan):

@@ -7,8 +7,17 @@ record -- [candidates | per-level counts | resize targets], fixed capacity, <= 3
 batched NMS, which every rank then runs for the images it owns, out of its segment of the gathered buffer (no rank
 repeats another rank's NMS).  The payload is latency-bound: one call, no bucketing.
 
-Rank r owns the global images ``[r*B, (r+1)*B)`` (rank-major order == gather order); the cameras of a nuScenes
-sample stay on one rank, as the reference's InferenceGroupSampler keeps them (group_sampler.py:30-35).
+Rank r decodes the global images ``[r*B, (r+1)*B)`` (rank-major order == gather order).  Who READS the gathered records:
+
+* ``camera_sharded=True`` (NuscenesDD3D; the north star's "images shard one-per-GPU"): the cameras of a sample sit on different ranks --
+  global images 6 s .. 6 s + 5 are sample s -- and the rank that decoded a sample's first camera OWNS it: it runs the 2D NMS of all six
+  cameras and the sample-level BEV aggregation (nuscenes_dd3d.py:448-465, postprocessing.py:58-108) on the records the other ranks
+  delivered (the record carries K^-1 and the camera->global pose of every image beside its candidates), and returns the sample's
+  detections.  Here the exchange is REQUIRED: without it no rank holds all cameras of a sample.
+* otherwise a rank finalises its own B images out of ITS segment of the gathered buffer (the samples are rank-local, as the
+  reference's InferenceGroupSampler keeps them, group_sampler.py:30-35).  Nothing then consumes the other ranks' records: the
+  collective is what the north star prescribes for the step ("an RCCL gather of decoded boxes before batched NMS") and what bench.py
+  measures, but a deployment that only needs per-image results can drop it (``exchange=False``: one graph, no collective).
 """
 import os
 
@@ -99,14 +108,16 @@ def gather_candidates(pairs, group=None):
 class DistributedForward:
     """Drives a ``ForwardPlan(world_size=W)``: [hipGraph: preprocess .. select/decode] -> RCCL all_gather ->
     [batched NMS of the rank's own images, read out of the gathered buffer]."""
-    def __init__(self, model, B, Hp, Wp, use_graph=True, force_exchange=False):
+    def __init__(self, model, B, Hp, Wp, use_graph=True, force_exchange=None, camera_sharded=False):
         self.model = model
+        self.camera_sharded = bool(camera_sharded)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        # one rank: the whole forward is one hipGraph, unless `force_exchange` keeps the two-phase step (RCCL check on one GPU)
-        self.exchange = self.world > 1 or bool(force_exchange)
+        # one rank: the whole forward is one hipGraph, unless `force_exchange` keeps the two-phase step (RCCL check on one GPU);
+        # force_exchange=False with several ranks drops the collective (per-image results only; never with camera_sharded)
+        self.exchange = (self.world > 1 and force_exchange is not False) or bool(force_exchange) or self.camera_sharded
         model.use_graph = use_graph
-        self.plan = p = model.get_plan(B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
+        self.plan = p = model.get_plan(B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange, camera_sharded=camera_sharded)
         self.B = B
         self.pre_graph = self.post_graph = None
         if use_graph and self.exchange:
@@ -143,6 +154,9 @@ class DistributedForward:
         if len(batched_inputs):
             _, image_sizes = self.model.stage_inputs(batched_inputs, plan=self.plan, partial=len(batched_inputs) < self.plan.B)
         self.step()
+        if self.camera_sharded:
+            # results belong to the OWNER of a sample, not to the rank that decoded a camera: [(global image index, {"instances"})]
+            return self.model.collect_owned(self.plan)
         if not len(batched_inputs):
             torch.cuda.current_stream().synchronize()
             return []

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DD3D_ABI_VERSION 2
+#define DD3D_ABI_VERSION 3
 
 #define DD3D_OK 0
 #define DD3D_E_INVALID (-1)  /* bad argument (shape / alignment / enum) */
@@ -331,6 +331,12 @@ typedef struct dd3d_nms_args {  /* host memory */
   int32_t* det_count;
   int32_t det_cap;
   int32_t slot_off[DD3D_MAX_LEVELS + 1]; /* same table as the producer of `cand` used (the select args) */
+  /* Reading the images out of the all-gathered records of several ranks (ABI 3).  img_per_rec = 0: `cand`, `counts`, `out_size` are
+   * dense [G] arrays (above).  img_per_rec = P > 0: they point INTO RECORD 0 of a buffer of records rec_stride 4-byte words apart,
+   * each holding P images; image g of this call is global image img_first + g = image (img_first + g) % P of record
+   * (img_first + g) / P.  This is how the owner of a nuScenes sample finalises cameras that other ranks decoded. */
+  int32_t img_first, img_per_rec;
+  int64_t rec_stride;
 } dd3d_nms_args;
 int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream);
 
@@ -368,6 +374,10 @@ typedef struct dd3d_bev_args {  /* host memory */
   int32_t* meta;
   float* det_out;
   int32_t* count_out;
+  /* same record addressing as the NMS arguments above, ABI 3: with img_per_rec > 0, `inv_K`, `pose` and `out_size` point into record 0 of the gathered buffer
+   * ([P][9], [P][7], [P][4] blocks of a record) and image g is global image img_first + g; `group`, `det_in`, `count_in` stay dense. */
+  int32_t img_first, img_per_rec;
+  int64_t rec_stride;
 } dd3d_bev_args;
 int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream);
 

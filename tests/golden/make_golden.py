@@ -39,6 +39,10 @@ CASES = {
     "dla34_nusc_128x224_b6_bevnms": ("dd3d_nusc_dla34", "dla34_nusc", 6, 128, 224, False),
     # BASELINE.json configs[3]: NuscenesDD3D on the V2-99 backbone (levels p2-p6, canvas padded to /64)
     "v99_nusc_64x128_b6": ("dd3d_nusc_v99", "v99_nusc", 6, 64, 128, False),
+    # BASELINE.json configs[1] / configs[2] at their stated size, final detections only (round-2 verdict: the reference itself, not
+    # only the oracle, at 384x1280): one forward of tridet.modeling.dd3d.core.DD3D each on the build container's CPU
+    "dla34_kitti_384x1280_b1_dets": ("dd3d_kitti_dla34", "dla34_kitti", 1, 384, 1280, False),
+    "v99_kitti_384x1280_b1_dets": ("dd3d_kitti_v99", "v99_kitti", 1, 384, 1280, False),
 }
 # the 128x224 images yield few candidates at the default threshold; lower it so that the BEV stages have work to do.  The
 # second case also trips the per-sample cap (nuscenes_dd3d.py:333, postprocessing.py:93-94).
@@ -48,7 +52,8 @@ EXTRA_OVERRIDES = {
     "dla34_nusc_128x224_b6_bevnms": {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}, "INFERENCE": {"DO_BEV_NMS": True},
                                               "NUSC": {"INFERENCE": {"MAX_NUM_DETS_PER_SAMPLE": 60}}}},
 }
-DETECTIONS_ONLY = {"dla34_nusc_128x224_b6_bevnms"}  # same head maps as the case above
+DETECTIONS_ONLY = {"dla34_nusc_128x224_b6_bevnms", "dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets"}  # no head maps
+NO_IMAGES = {"dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets"}  # (the padded canvas is 5.9 MB; the small cases pin it)
 NO_FEATURES = {"v99_nusc_64x128_b6"}  # the V2-99 features are covered by the KITTI case; keeps the fixture small
 
 
@@ -160,7 +165,8 @@ def main(only=None):
                 _, _, _, extra = ref.fcos2d_head(feats)
                 for l, t in enumerate(extra["cls_tower_out"]):
                     out[f"attr{l}"], out[f"speed{l}"] = ref.attr_logits(t).numpy(), ref.speed(t).numpy()
-            out["images"] = il.tensor.numpy()
+            if name not in NO_IMAGES:
+                out["images"] = il.tensor.numpy()
             for l in range(len(feats) if name not in DETECTIONS_ONLY else 0):
                 if l >= 2 and name not in NO_FEATURES:  # the fine levels are large; their content is covered by the head maps below
                     out[f"feat{l}"] = feats[l].numpy()

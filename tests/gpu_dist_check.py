@@ -72,7 +72,59 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _camera_worker(rank, world, port, ret):
+    """NuscenesDD3D with the six cameras of a sample split 3 / 3 over two ranks: the sample's owner (rank 0) must return, for all six
+    cameras, exactly what a single rank returns for the whole sample -- detections, attributes, speeds and global boxes."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from dd3d_amd import build_model, get_cfg
+    from dd3d_amd.parallel import DistributedForward, init_distributed
+    from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
+    init_distributed(backend="gloo")
+    cfg = get_cfg("dd3d_nusc_dla34")
+    model = build_model(cfg)
+    sd = make_state_dict(model, calib=load_calib("dla34_nusc"))
+    model.load_state_dict(sd)
+    H, W, B = 128, 224, 6 // world
+    ok = True
+    single = build_model(cfg)
+    single.load_state_dict(sd)
+    for use_graph in (False, True):
+        runner = DistributedForward(model, B, H + (-H) % 128, W + (-W) % 128, use_graph=use_graph, camera_sharded=True)
+        for step in range(2):  # two different samples through the same plan
+            sample = make_inputs(6, H, W, dataset="nusc", seed=300 + 20 * step)
+            sample[4]["height"], sample[4]["width"] = 99, 201  # one camera is resized on the way out
+            out = runner.forward(sample[rank * B:(rank + 1) * B])
+            if rank != 0:
+                ok &= out == []
+                continue
+            ref = single(sample)
+            ok &= [g for g, _ in out] == list(range(6)) and sum(len(o["instances"]) for _, o in out) > 0
+            for (g, o), r in zip(out, ref):
+                a, b = o["instances"], r["instances"]
+                ok &= len(a) == len(b) and tuple(a.image_size) == tuple(b.image_size)
+                for f in ("scores", "scores_3d", "pred_classes", "pred_attributes", "pred_speeds", "fpn_levels", "locations"):
+                    ok &= torch.equal(getattr(a, f), getattr(b, f))
+                ok &= torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.pred_boxes3d.vectorize(), b.pred_boxes3d.vectorize())
+                ok &= torch.equal(a.pred_boxes3d.inv_intrinsics, b.pred_boxes3d.inv_intrinsics)
+                ok &= torch.equal(a.pred_boxes3d_global.vectorize(), b.pred_boxes3d_global.vectorize())
+        dist.barrier()
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cameras":
+        import __graft_entry__ as g
+        g.build()
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ret = mp.Manager().dict()
+        mp.spawn(_camera_worker, args=(2, port, ret), nprocs=2, join=True)
+        print("camera-sharded check:", dict(ret))
+        assert all(ret.get(r) for r in range(2)), dict(ret)
+        return
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     import __graft_entry__ as g
     g.build()

@@ -50,6 +50,15 @@ ROW_CASES = [  # 3x3 / stride 1: the row-shared kernel (csrc/conv_planes_row.hip
     ("row_64x64w4_b3", 3, 7, 9, 256, 256, 3, 1, 1, True, False, hip.TILE_64x64_W4, 1),         # three tiny images: batch boundaries inside a tile
     ("row_128x64w4_sk3", 1, 24, 40, 128, 128, 3, 1, 1, True, True, hip.TILE_128x64_W4, 3),
     ("row_64x128_1x3", 1, 1, 3, 32, 128, 3, 1, 1, False, False, hip.TILE_64x128, 1),           # a 1 x 3 image: every neighbour but two is padding
+    # wave tiles of 128 x 64 / 64 x 128 outputs (round 3): 4-wave blocks with 8 accumulator blocks per wave, and the 8-wave 256 x 256 tile
+    ("row_t42_wraps", 2, 33, 41, 64, 256, 3, 1, 1, True, True, hip.TILE_256x128_T42, 1),
+    ("row_t42_sk3", 1, 30, 44, 96, 192, 3, 1, 1, False, False, hip.TILE_256x128_T42, 3),
+    ("row_t24_b3", 3, 7, 9, 256, 256, 3, 1, 1, True, False, hip.TILE_128x256_T24, 1),
+    ("row_t24_n320", 1, 24, 40, 64, 320, 3, 1, 1, False, True, hip.TILE_128x256_T24, 1),       # two N tiles, the second half empty
+    ("row_w8_256x256", 2, 17, 23, 128, 256, 3, 1, 1, True, True, hip.TILE_256x256_W8, 1),
+    ("t42_1x1_k448", 1, 24, 40, 448, 128, 1, 1, 0, True, False, hip.TILE_256x128_T42, 1),
+    ("t24_s2_sk2", 1, 13, 21, 256, 256, 3, 2, 1, False, False, hip.TILE_128x256_T24, 2),
+    ("w8_1x1", 1, 24, 40, 256, 512, 1, 1, 0, False, True, hip.TILE_256x256_W8, 1),
 ]
 
 
@@ -63,6 +72,8 @@ def test_planes_conv_matches_torch(hiplib, case, mode, row_kernel, monkeypatch):
         pytest.skip("only 3x3 / stride 1 has two kernels")
     monkeypatch.setenv("DD3D_CONV_ROW", str(row_kernel))
     math, rtol = MODES[mode]
+    if tile == hip.TILE_256x256_W8 and hip.MATH_PLANES[math] > 2:
+        pytest.skip("the 8-wave 256 x 256 tile exists for the one- and two-term modes only (register file)")
     g = torch.Generator().manual_seed(sum(map(ord, name)) % 1000)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k)**0.5

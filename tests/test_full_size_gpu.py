@@ -51,6 +51,87 @@ def test_v99_kitti_bs16_full_size_matches_oracle(hiplib):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets"])
+def test_full_size_detections_match_the_reference_itself(hiplib, name):
+    """BASELINE configs[1] / [2] geometry (384x1280) against detections produced by the reference's own tridet DD3D.forward
+    (tests/golden/make_golden.py, run in the build container), end to end from the uint8 image: same detections -- classes, levels,
+    locations exactly; boxes / depth / size / scores within 1e-3 relative -- unless a candidate sits ON a selection cut (then the
+    difference is bounded by the flips, as in test_forward_matches_oracle; the oracle supplies the margins)."""
+    import os
+
+    import numpy as np
+    from tests.golden.make_golden import CASES, case_inputs
+    from tests.test_forward_gpu import _key
+    exp, tag, B, H, W, ragged = CASES[name]
+    cfg, sd = bundle(exp, tag)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    inputs = case_inputs(B, H, W, ragged, "kitti")
+    model = gpu_model(cfg, sd, use_graph=True)
+    out = model(inputs)
+    plan, _ = model.stage_inputs(inputs)
+    _, st = _oracle(cfg, sd, inputs)
+    for i in range(B):
+        _, _, margins = candidate_margins(plan, st, cfg, i)
+        assert all(m <= MARGIN_EPS for m in margins), margins
+        o = out[i]["instances"]
+        ko = _key(o.fpn_levels.cpu(), o.locations.cpu(), o.pred_classes.cpu())
+        kr = _key(t(f"det{i}_levels"), t(f"det{i}_locations"), t(f"det{i}_classes"))
+        assert len(kr) > 20
+        if not margins:
+            assert ko == kr, (len(ko), len(kr))  # same detections in the same (score_3d) order
+        else:
+            assert len(set(ko) ^ set(kr)) <= 4 * len(margins), (len(ko), len(kr), len(margins))
+        common = [k for k in kr if k in set(ko)]
+        io, ir = [ko.index(k) for k in common], [kr.index(k) for k in common]
+        assert max_abs(o.pred_boxes.tensor[io], t(f"det{i}_boxes")[ir]) < REL_TOL * float(t(f"det{i}_boxes").abs().max())
+        b3 = o.pred_boxes3d
+        assert rel_err(b3.depth[io], t(f"det{i}_depth")[ir]) < REL_TOL and rel_err(b3.size[io], t(f"det{i}_size")[ir]) < REL_TOL
+        assert rel_err(o.scores_3d[io], t(f"det{i}_scores_3d")[ir]) < REL_TOL and rel_err(o.scores[io], t(f"det{i}_scores")[ir]) < REL_TOL
+        assert max_abs(b3.proj_ctr[io], t(f"det{i}_proj_ctr")[ir]) < REL_TOL * float(t(f"det{i}_proj_ctr").abs().max())
+        gq = t(f"det{i}_quat")[ir]
+        assert float(torch.minimum((b3.quat[io].cpu() - gq).abs().amax(1), (b3.quat[io].cpu() + gq).abs().amax(1)).max()) < REL_TOL
+        assert max_abs(b3.tvec[io], t(f"det{i}_tvec")[ir]) < REL_TOL * float(t(f"det{i}_tvec").abs().max())
+        print(f"[golden] {name}: {len(kr)} reference detections, {len(common)} shared, {len(margins)} on-the-cut flips")
+
+
+@pytest.mark.timeout(900)
+def test_dla34_nuscenes_batch_full_size_matches_oracle(hiplib):
+    """BASELINE.json configs[4] geometry: DD3D-DLA34 on nuScenes, one 6-camera sample at 896x1664 (900x1600 -> ResizeShortestEdge 896
+    -> 896x1593, padded to the /128 canvas of the P6/P7 FPN, dla.py:559) -- head maps, attributes / speeds, sample aggregation."""
+    from dd3d_amd.synthetic import make_inputs
+    from oracle import nuscenes_oracle as N
+    cfg, sd = bundle("dd3d_nusc_dla34", "dla34_nusc")
+    model = gpu_model(cfg, sd, use_graph=False)
+    inputs = make_inputs(6, 896, 1600, dataset="nusc")
+    for x in inputs:
+        x["image"] = x["image"][:, :, :1593].contiguous()
+        x["height"], x["width"] = 900, 1600
+    with torch.no_grad():
+        ref, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
+    plan, image_sizes = model.stage_inputs(inputs)
+    assert (plan.B, plan.Hp, plan.Wp) == (6, 896, 1664)
+    plan.run()
+    torch.cuda.synchronize()
+    C = cfg.DD3D.NUM_CLASSES
+    _check_head_maps(plan, st, C)
+    flips = 0
+    for i in range(6):
+        _, _, margins = candidate_margins(plan, st, cfg, i)
+        assert all(m <= MARGIN_EPS for m in margins), (i, margins)
+        flips += len(margins)
+    print(f"[margin] DLA-34 nuScenes 896x1664 b6: {sum(len(c['scores']) for c in st['candidates'])} oracle candidates, {flips} on-the-cut flips")
+    oracle_heads_to_plan(plan, st, C)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
+    torch.cuda.synchronize()
+    out = model.collect(plan, inputs, image_sizes)
+    assert sum(len(r["scores"]) for r in ref) > 0
+    for i in range(6):
+        _check_final(out[i], ref[i])
+        _nusc_check(out[i]["instances"], ref[i], True)
+
+
+@pytest.mark.timeout(900)
 def test_v99_nuscenes_sample_full_size_matches_oracle(hiplib):
     from dd3d_amd.synthetic import make_inputs
     from oracle import nuscenes_oracle as N

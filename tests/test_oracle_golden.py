@@ -26,7 +26,8 @@ def test_oracle_matches_reference_golden(name):
     with torch.no_grad():
         res, st = N.nuscenes_dd3d_forward(sd, cfg, inputs) if nusc else O.dd3d_forward(sd, cfg, inputs)
     t = lambda k: torch.from_numpy(g[k])
-    assert torch.equal(st["images"], t("images"))
+    if "images" in g:  # (the full-size detection fixtures leave the 5.9 MB canvas out; the small cases pin it)
+        assert torch.equal(st["images"], t("images"))
     for l in range(5 if name not in DETECTIONS_ONLY else 0):
         if nusc:
             assert torch.allclose(st["attr"][l], t(f"attr{l}"), rtol=1e-5, atol=2e-5) and torch.allclose(st["speed"][l], t(f"speed{l}"), rtol=1e-5, atol=2e-5)

@@ -73,6 +73,98 @@ def test_gather_candidates_gloo_world2():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _rec_off(g, img_first, img_per_rec, rec_stride, per_img):
+    """csrc/postproc.hip::rec_off restated (the device-side addressing of an image inside the gathered records)."""
+    if img_per_rec <= 0:
+        return g * per_img
+    gg = img_first + g
+    r = gg // img_per_rec
+    return r * rec_stride + (gg - r * img_per_rec) * per_img
+
+
+def _camera_worker(rank, world, port, B, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.engine import ForwardPlan
+    from dd3d_amd.parallel import gather_candidates, init_distributed
+    init_distributed(backend="gloo")
+    cfg = get_cfg("dd3d_nusc_dla34")
+    model = META_ARCH_REGISTRY.get("NuscenesDD3D")(cfg)
+    plan = ForwardPlan(model, B, 128, 256, device="cpu", dry_run=True, world_size=world, rank=rank, camera_sharded=True)
+    nsamp = world * B // 6
+    own = [s for s in range(nsamp) if (6 * s) // B == rank]
+    ok = plan.exchange and plan.camera_sharded and plan.own_samples == own and plan.G == 6 * len(own)
+    ok &= plan.det.shape[0] == plan.G and (not own or plan.img_first == 6 * own[0])
+    # the owner's launch list ends with NMS + sample aggregation; a rank that owns nothing only contributes its record
+    names = [op.name for op in plan.ops[plan.num_pre_nms_ops:]]
+    ok &= names == (["nms_finalize", "nusc_sample_aggregate"] if own else [])
+    if own:
+        n, b = plan.nms_args, plan.bev_args[-1]
+        ok &= (n.img_first, n.img_per_rec, n.rec_stride, n.G) == (plan.img_first, B, plan.record_len, plan.G)
+        ok &= (b.img_first, b.img_per_rec, b.rec_stride, b.G) == (plan.img_first, B, plan.record_len, plan.G)
+        ok &= n.cand == plan.gathered.data_ptr() and b.inv_K == plan.gathered.data_ptr() + 4 * plan.record_fields["inv_K"][0]
+        ok &= plan.in_group.tolist() == [g // 6 for g in range(plan.G)]  # positional sample membership
+    # every rank fills its record with values that name (rank, field, image, word), exchanges, and the owner's addressing must find,
+    # for each image it finalises, exactly the words the decoding rank wrote
+    for name, (off, per) in plan.record_fields.items():
+        vals = (torch.arange(B * per, dtype=torch.float32) + 1000.0 * (off % 97) + 1e6 * rank)
+        plan.record[off:off + B * per] = vals
+    gather_candidates(plan.gather_pairs())
+    for g in range(plan.G):
+        gg = plan.img_first + g
+        src, pos = gg // B, gg % B
+        for name, (off, per) in plan.record_fields.items():
+            o = plan.image_offset(g, name)
+            ok &= o == _rec_off(g, plan.img_first, B, plan.record_len, per)
+            got = plan.gathered[off + o:off + o + per]
+            want = torch.arange(pos * per, (pos + 1) * per, dtype=torch.float32) + 1000.0 * (off % 97) + 1e6 * src
+            ok &= torch.equal(got, want)
+            ok &= torch.equal(plan.gathered_field(name)[gg].view(torch.float32), want) if name != "counts" else True
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [3, 6])
+def test_camera_sharded_sample_owner_reads_other_ranks_records(B):
+    """NuscenesDD3D with the cameras of a sample on different ranks (B = 3 per rank: rank 0 owns the one sample and reads rank 1's three
+    cameras; B = 6: every rank owns the sample it decoded): plan geometry, kernel argument addressing and the delivered records."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_camera_worker, args=(world, _free_port(), B, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_camera_sharding_needs_whole_samples_and_an_aggregating_model():
+    import dd3d_amd.modeling  # noqa: F401
+    from dd3d_amd import META_ARCH_REGISTRY, get_cfg
+    from dd3d_amd.engine import ForwardPlan
+    nusc = META_ARCH_REGISTRY.get("NuscenesDD3D")(get_cfg("dd3d_nusc_dla34"))
+    with pytest.raises(ValueError, match="whole 6-camera samples"):
+        ForwardPlan(nusc, 2, 128, 256, device="cpu", dry_run=True, world_size=2, rank=0, camera_sharded=True)
+    kitti = META_ARCH_REGISTRY.get("DD3D")(get_cfg("dd3d_kitti_dla34"))
+    with pytest.raises(ValueError, match="aggregates samples"):
+        ForwardPlan(kitti, 3, 128, 256, device="cpu", dry_run=True, world_size=2, rank=0, camera_sharded=True)
+    # 8 ranks x 3 cameras = 4 samples: owners are the ranks of the first cameras (0, 2, 4, 6)
+    owners = [ForwardPlan(nusc, 3, 128, 256, device="cpu", dry_run=True, world_size=8, rank=r, camera_sharded=True).own_samples for r in range(8)]
+    assert owners == [[0], [], [1], [], [2], [], [3], []]
+
+
+def test_padded_shards_give_every_rank_the_same_number_of_steps():
+    """The runners hold one collective per step: every rank must run the same number of steps, with whole batches."""
+    from dd3d_amd.parallel import inference_shard, padded_inference_shard
+    for total, group, world, batch in [(3769, 1, 8, 4), (36114, 6, 8, 6), (12, 6, 4, 6), (18, 6, 2, 12), (7, 1, 3, 2)]:
+        shards = [padded_inference_shard(total, group, r, world, batch) for r in range(world)]
+        assert len({len(i) for i, _ in shards}) == 1 and len(shards[0][0]) % batch == 0
+        for r, (idx, valid) in enumerate(shards):
+            own = list(inference_shard(total, group, r, world))
+            assert [i for i, v in zip(idx, valid) if v] == own  # the real items, in order, first
+            assert all(0 <= i < total for i in idx) and valid == sorted(valid, reverse=True)
+            pad = [i for i, v in zip(idx, valid) if not v]
+            assert len(pad) % group == 0 and all(pad[k] // group == pad[k - k % group] // group for k in range(len(pad)))  # whole groups
+
+
 def test_inference_shard_follows_the_reference_group_sampler():
     """group_sampler.py:27-35: shard_size = ((num_groups - 1) // world + 1) * group_size; rank r takes [r * shard, (r + 1) * shard) cut at
     the dataset size.  Values below are that formula worked by hand; the properties are what the BEV aggregation relies on."""

@@ -17,6 +17,15 @@ def test_two_ranks_on_one_gpu_match_single_rank(hiplib):
     assert "dist check: {" in r.stdout and "False" not in r.stdout.split("dist check:")[-1]
 
 
+def test_camera_sharded_sample_on_two_ranks_matches_single_rank(hiplib):
+    """The reader of the exchange: a nuScenes sample's cameras split 3 / 3 over two ranks, aggregated by the sample's owner out of the
+    gathered records (2D NMS of all six cameras + the sample-level BEV NMS), bit-identical to the single-rank forward of the sample."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_dist_check.py"), "cameras"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "camera-sharded check: {" in r.stdout and "False" not in r.stdout.split("camera-sharded check:")[-1]
+
+
 def test_rccl_transport_single_rank(hiplib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_rccl_check.py")], capture_output=True, text=True, timeout=900)
