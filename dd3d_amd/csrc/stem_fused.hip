@@ -1,0 +1,268 @@
+// The full-resolution stem of DLA-34 in ONE launch (gfx950):  uint8 image -> (x - mean) / std -> base_layer 7x7 3->16 + BN + ReLU ->
+// level0 3x3 16->16 + BN + ReLU -> level1 3x3 stride 2 16->32 + BN + ReLU  (tridet/modeling/feature_extractor/dla.py:271-280,327-344,
+// core.py:61-66), DD3D_MATH_F16X2 arithmetic (every operand = two IEEE-half terms, three products, f32 accumulation).
+//
+// Launch by launch these layers are HBM-bound: 230 MB per 384 x 1280 image move through HBM for 2.9 GMAC (preprocess 9 MB, base_layer
+// 39, level0 63, level1 47, the plane split 31, ...), 71 us per image at batch 8.  Here a block owns an 8 x 32 tile of level1 outputs and
+// keeps everything between the uint8 pixels and those outputs in its LDS:
+//
+//   image patch  25 x 74 x 4 ch   (region A, 29 KiB)   normalised on the fly, zero outside the real image (ImageList padding)
+//   base tile    19 x 67 x 16 ch  (region B, 80 KiB)   zero outside the canvas (= the zero padding level0's filter sees)
+//   level0 tile  17 x 65 x 16 ch  (region A, 70 KiB)   overwrites the image patch
+//   level1 tile   8 x 32 x 32 ch  (region B, 32 KiB f32) staged for coalesced stores
+//
+// all as two planes of halves (hi, lo of value x plane scale), pixel-major rows of Cin halves, exactly the operand form of
+// v_mfma_f32_16x16x32_f16: lane l holds 8 consecutive k of pixel (l & 15), and with the k orders of stem_conv.hip
+//   Cin 4 : k = (dh * 8 + dw) * 4 + c   one 32-k chunk = one filter row, lane quarter q reads pixels dw = 2q, 2q + 1
+//   Cin 16: k = (dh * 3 + dw) * 16 + c  one chunk = two taps, quarter q reads tap 2 chunk + (q >> 1), channels 8 (q & 1) .. + 8
+// those are 16 contiguous bytes of a tile.  A 16-pixel MFMA row group is 16 CONSECUTIVE pixels of the flattened tile (rows wrap), so no
+// tile width is wasted.  HBM traffic per image: 1.5 MB in, 15.7 (+ 15.7 f32) MB out.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace dd3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct StemFusedK {
+  dd3d_stem_args a;
+};
+
+constexpr int SF_TH = 8, SF_TW = 32;                      // level1 outputs per block
+constexpr int SF_R0 = 2 * SF_TH + 1, SF_C0 = 2 * SF_TW + 1;  // level0 tile 17 x 65
+constexpr int SF_RB = SF_R0 + 2, SF_CB = SF_C0 + 2;          // base tile 19 x 67
+constexpr int SF_RI = SF_RB + 6, SF_CI = SF_CB + 7;          // image patch 25 x 74 (the Cin-4 reads run to tap slot 7)
+constexpr int SF_NB = SF_RB * SF_CB, SF_N0 = SF_R0 * SF_C0, SF_N1 = SF_TH * SF_TW;  // 1273, 1105, 256 pixels
+constexpr int SF_GB = (SF_NB + 15) / 16, SF_G0 = (SF_N0 + 15) / 16, SF_G1 = SF_N1 / 16;  // 80, 70, 16 row groups
+constexpr int SF_IMG_PLANE = SF_RI * SF_CI * 8;   // bytes per plane
+constexpr int SF_B_PLANE = SF_GB * 16 * 32;
+constexpr int SF_0_PLANE = SF_G0 * 16 * 32;
+constexpr int SF_REGION_A = 2 * SF_0_PLANE > 2 * SF_IMG_PLANE ? 2 * SF_0_PLANE : 2 * SF_IMG_PLANE;
+constexpr int SF_REGION_B = 2 * SF_B_PLANE;
+constexpr int SF_LDS = SF_REGION_A + SF_REGION_B;
+constexpr int SF_WAVES = 8;
+static_assert(SF_LDS <= 160 * 1024 && SF_N1 * 32 * 4 <= SF_REGION_B, "stem tile does not fit the LDS");
+
+// value -> (hi, lo) halves of value * plane scale; returns nonzero if the scaled value leaves the half range
+__device__ __forceinline__ int sf_split(float v, float pscale, _Float16& hi, _Float16& lo) {
+  const float s = v * pscale;
+  hi = (_Float16)s;
+  lo = (_Float16)(s - (float)hi);
+  return !(fabsf(s) <= 65504.f);
+}
+
+// acc += (hi + lo) x (whi + wlo) without the lo x lo term
+__device__ __forceinline__ f32x4 sf_mfma3(f16x8 ahi, f16x8 alo, f16x8 whi, f16x8 wlo, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi, acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const StemFusedK P) {
+  const dd3d_stem_args& a = P.a;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const regA = lds;                 // image patch, then the level0 tile
+  unsigned char* const regB = lds + SF_REGION_A;   // base tile, then the level1 staging
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q4 = lane >> 4, n_lane = lane & 15;
+  const int b = blockIdx.z;
+  const int oh0 = blockIdx.y * SF_TH, ow0 = blockIdx.x * SF_TW;  // level1 tile origin
+  const int Ho = a.Hp >> 1, Wo = a.Wp >> 1;
+  const float pscale = a.plane_scale;
+  int ovf = 0;
+
+  // ------------------------------------------------------------------ stage 0: image patch (normalise, split)
+  {
+    const int ih0 = 2 * oh0 - 5, iw0 = 2 * ow0 - 5;  // level1 -> level0 (-1) -> base (-1) -> image (-3)
+    const int vh = a.sizes[2 * b], vw = a.sizes[2 * b + 1];
+    const long plane = (long)a.Hp * a.Wp;
+    const uint8_t* src = a.src + (long)b * 3 * plane;
+    for (int pix = tid; pix < SF_RI * SF_CI; pix += 64 * SF_WAVES) {
+      const int pr = pix / SF_CI, pc = pix - pr * SF_CI;
+      const int ih = ih0 + pr, iw = iw0 + pc;
+      f16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+      if ((unsigned)ih < (unsigned)vh && (unsigned)iw < (unsigned)vw) {
+        const uint8_t* p = src + (long)ih * a.Wp + iw;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float x = ((float)p[c * plane] - a.mean[c]) / a.stdv[c];  // the division is kept: torch's (x - mean) / std
+          _Float16 h, l;
+          sf_split(x, pscale, h, l);  // |x| < 3: always inside the half range
+          hi[c] = h, lo[c] = l;
+        }
+      }
+      *reinterpret_cast<f16x4*>(regA + pix * 8) = hi;
+      *reinterpret_cast<f16x4*>(regA + SF_IMG_PLANE + pix * 8) = lo;
+    }
+  }
+
+  // ------------------------------------------------------------------ stage 1: base_layer 7x7 (3 -> 16), Cin padded to 4
+  {
+    f16x8 w[7][2];
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w1);
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) w[ch][pl] = *reinterpret_cast<const f16x8*>(wp + ((ch * 2 + pl) * 16 + n_lane) * 64 + q4 * 16);
+    const float sc = a.scale1[n_lane], bi = a.bias1[n_lane];
+    __syncthreads();
+    const int rb0 = 2 * oh0 - 2, cb0 = 2 * ow0 - 2;  // canvas position of the base tile's origin
+    for (int g = wave; g < SF_GB; g += SF_WAVES) {
+      const int p = min(g * 16 + n_lane, SF_NB - 1);
+      const int r = p / SF_CB, c = p - r * SF_CB;
+      const unsigned char* base = regA + (r * SF_CI + c + 2 * q4) * 8;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        const unsigned char* src = base + ch * SF_CI * 8;  // filter row ch: pixels (r + ch, c + 2 q4), (.., + 1): 16 bytes, 8-byte aligned
+        const u32x2 h0 = *reinterpret_cast<const u32x2*>(src), h1 = *reinterpret_cast<const u32x2*>(src + 8);
+        const u32x2 l0 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE), l1 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE + 8);
+        acc = sf_mfma3(__builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]}), __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]}),
+                       w[ch][0], w[ch][1], acc);
+      }
+      // C/D map of the 16x16 MFMA: column (channel) = lane & 15, row (pixel of the group) = (lane >> 4) * 4 + e
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int po = g * 16 + q4 * 4 + e;
+        const int pr = po / SF_CB, pc = po - pr * SF_CB;
+        const bool inside = (unsigned)(rb0 + pr) < (unsigned)a.Hp && (unsigned)(cb0 + pc) < (unsigned)a.Wp;  // else: level0's zero padding
+        const float v = inside ? fmaxf(acc[e] * sc + bi, 0.f) : 0.f;
+        _Float16 h, l;
+        ovf |= sf_split(v, pscale, h, l);
+        *reinterpret_cast<_Float16*>(regB + po * 32 + n_lane * 2) = h;  // (po < SF_GB * 16: the padded tail of the plane absorbs it)
+        *reinterpret_cast<_Float16*>(regB + SF_B_PLANE + po * 32 + n_lane * 2) = l;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ stage 2: level0 3x3 (16 -> 16)
+  {
+    f16x8 w[5][2];
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w2);
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) w[ch][pl] = *reinterpret_cast<const f16x8*>(wp + ((ch * 2 + pl) * 16 + n_lane) * 64 + q4 * 16);
+    const float sc = a.scale2[n_lane], bi = a.bias2[n_lane];
+    int aoff[5];
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch) {
+      const int t = min(2 * ch + (q4 >> 1), 8);  // the padded tenth tap re-reads the ninth (its weights are zero)
+      aoff[ch] = ((t / 3) * SF_CB + (t % 3)) * 32 + (q4 & 1) * 16;
+    }
+    __syncthreads();  // base tile complete; the image patch is dead
+    const int r00 = 2 * oh0 - 1, c00 = 2 * ow0 - 1;
+    for (int g = wave; g < SF_G0; g += SF_WAVES) {
+      const int p = min(g * 16 + n_lane, SF_N0 - 1);
+      const int r = p / SF_C0, c = p - r * SF_C0;
+      const unsigned char* base = regB + (r * SF_CB + c) * 32;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 5; ++ch)
+        acc = sf_mfma3(*reinterpret_cast<const f16x8*>(base + aoff[ch]), *reinterpret_cast<const f16x8*>(base + SF_B_PLANE + aoff[ch]), w[ch][0], w[ch][1], acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int po = g * 16 + q4 * 4 + e;
+        const int pr = po / SF_C0, pc = po - pr * SF_C0;
+        const bool inside = (unsigned)(r00 + pr) < (unsigned)a.Hp && (unsigned)(c00 + pc) < (unsigned)a.Wp;
+        const float v = inside ? fmaxf(acc[e] * sc + bi, 0.f) : 0.f;
+        _Float16 h, l;
+        ovf |= sf_split(v, pscale, h, l);
+        *reinterpret_cast<_Float16*>(regA + po * 32 + n_lane * 2) = h;
+        *reinterpret_cast<_Float16*>(regA + SF_0_PLANE + po * 32 + n_lane * 2) = l;
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ stage 3: level1 3x3 stride 2 (16 -> 32)
+  {
+    f16x8 w[5][2][2];
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(a.w3);
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) w[ch][pl][nt] = *reinterpret_cast<const f16x8*>(wp + ((ch * 2 + pl) * 32 + nt * 16 + n_lane) * 64 + q4 * 16);
+    float sc[2], bi[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) sc[nt] = a.scale3[nt * 16 + n_lane], bi[nt] = a.bias3[nt * 16 + n_lane];
+    int aoff[5];
+#pragma unroll
+    for (int ch = 0; ch < 5; ++ch) {
+      const int t = min(2 * ch + (q4 >> 1), 8);
+      aoff[ch] = ((t / 3) * SF_C0 + (t % 3)) * 32 + (q4 & 1) * 16;
+    }
+    __syncthreads();  // level0 tile complete; the base tile is dead
+    float* stage = reinterpret_cast<float*>(regB);  // [256 pixels][32 channels] f32
+    for (int g = wave; g < SF_G1; g += SF_WAVES) {
+      const int p = g * 16 + n_lane;
+      const int r = p / SF_TW, c = p - r * SF_TW;
+      const unsigned char* base = regA + (2 * r * SF_C0 + 2 * c) * 32;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ch = 0; ch < 5; ++ch) {
+        const f16x8 ahi = *reinterpret_cast<const f16x8*>(base + aoff[ch]), alo = *reinterpret_cast<const f16x8*>(base + SF_0_PLANE + aoff[ch]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = sf_mfma3(ahi, alo, w[ch][0][nt], w[ch][1][nt], acc[nt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stage[(g * 16 + q4 * 4 + e) * 32 + nt * 16 + n_lane] = fmaxf(acc[nt][e] * sc[nt] + bi[nt], 0.f);
+    }
+    __syncthreads();
+    // coalesced write-out: thread -> (pixel, 4 channels): 16 bytes of the f32 row, 8 bytes of each plane row
+    for (int i = tid; i < SF_N1 * 8; i += 64 * SF_WAVES) {
+      const int p = i >> 3, c4 = (i & 7) * 4;
+      const int r = p / SF_TW, c = p - r * SF_TW;
+      const int oh = oh0 + r, ow = ow0 + c;
+      if (oh >= Ho || ow >= Wo) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stage + p * 32 + c4);
+      const long m = ((long)b * Ho + oh) * Wo + ow;
+      if (a.out) *reinterpret_cast<f32x4*>(a.out + m * a.out_pitch + c4) = v;
+      if (a.out_planes) {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 h, l;
+          ovf |= sf_split(v[e], pscale, h, l);
+          hi[e] = h, lo[e] = l;
+        }
+        unsigned char* dst = reinterpret_cast<unsigned char*>(a.out_planes) + m * 128 + c4 * 2;  // [pixel][plane][32] halves, one chunk
+        *reinterpret_cast<f16x4*>(dst) = hi;
+        *reinterpret_cast<f16x4*>(dst + 64) = lo;
+      }
+    }
+  }
+  if (ovf && a.status) atomicOr(a.status, DD3D_STATUS_F16_OVERFLOW);
+}
+
+}  // namespace dd3d
+
+extern "C" int dd3d_stem_fused_f16x2(const dd3d_stem_args* a, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(a && a->src && a->sizes && a->w1 && a->w2 && a->w3 && a->scale1 && a->bias1 && a->scale2 && a->bias2 && a->scale3 && a->bias3,
+               "dd3d_stem_fused_f16x2: null pointer");
+  DD3D_REQUIRE(a->out || a->out_planes, "dd3d_stem_fused_f16x2: no output");
+  DD3D_REQUIRE(a->B > 0 && a->Hp > 0 && a->Wp > 0 && (a->Hp % 2) == 0 && (a->Wp % 2) == 0, "dd3d_stem_fused_f16x2: canvas %dx%d (x%d) must be even", a->Hp,
+               a->Wp, a->B);
+  DD3D_REQUIRE(!a->out || (a->out_pitch >= 32 && a->out_pitch % 4 == 0), "dd3d_stem_fused_f16x2: out_pitch=%d", a->out_pitch);
+  DD3D_REQUIRE(a->plane_scale > 0.f, "dd3d_stem_fused_f16x2: plane_scale=%g", (double)a->plane_scale);
+  static unsigned long long attr_done[4];
+  if (lds_opt_in_needed(attr_done)) {
+    if (lds_opt_in(reinterpret_cast<const void*>(stem_fused_f16x2_kernel), (size_t)SF_LDS, "stem_fused_f16x2_kernel") != DD3D_OK) return DD3D_E_LAUNCH;
+  }
+  StemFusedK P;
+  P.a = *a;
+  const int Ho = a->Hp / 2, Wo = a->Wp / 2;
+  hipLaunchKernelGGL(stem_fused_f16x2_kernel, dim3(ceil_div(Wo, SF_TW), ceil_div(Ho, SF_TH), a->B), dim3(64 * SF_WAVES), SF_LDS, reinterpret_cast<hipStream_t>(stream), P);
+  return check_launch("stem_fused_f16x2_kernel");
+}

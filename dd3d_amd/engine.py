@@ -220,6 +220,68 @@ def pack_smallc_bf16x3(weights, cin_p):
     return planes.permute(1, 2, 0, 3).contiguous()
 
 
+def pack_smallc_f16x2(weights, cin_p):
+    """OIHW filter (Cin <= cin_p in {4, 16}) -> ([chunk][plane hi, lo][Npad16][32] IEEE-half bit patterns, row scales s[Npad16]) in the k
+    order of the patch kernels (pack_smallc_bf16x3 / include/dd3d_hip.h::dd3d_stem_args); the terms are those of w[n] * s[n], split as
+    split_f16x2_host splits every other filter of the two-half-term arithmetic."""
+    w = weights.detach().float().cpu()
+    N, Cin, KH, KW = w.shape
+    n16 = (N + 15) // 16 * 16
+    if cin_p == 4:
+        k = torch.zeros((n16, KH, 8, 4))
+        k[:N, :, :KW, :Cin] = w.permute(0, 2, 3, 1)
+        k = k.reshape(n16, KH * 32)  # chunk = filter row
+    else:
+        T = KH * KW
+        k = torch.zeros((n16, (T + 1) // 2 * 2, 16))
+        k[:N, :T, :Cin] = w.permute(0, 2, 3, 1).reshape(N, T, Cin)
+        k = k.reshape(n16, (T + 1) // 2 * 32)  # chunk = two taps
+    planes, s = split_f16x2_host(k)  # [n16][chunks][2][32]
+    return planes.permute(1, 2, 0, 3).contiguous(), s
+
+
+class FusedStemOp:
+    """One dd3d_stem_fused_f16x2 launch: uint8 image -> normalise -> base_layer -> level0 -> level1 (DLA, dla.py:271-280,327-344), the
+    intermediate maps kept in LDS.  Replaces preprocess + three convolutions + the plane split of level1's output."""
+    def __init__(self, plan, model, convs, vout, name="stem"):
+        from dd3d_amd.layers import fold_norm
+        assert plan.math == hip.MATH_F16X2
+        self.name, self.macs = name, 0
+        B, Hp, Wp = plan.B, plan.Hp, plan.Wp
+        a = hip.StemArgs()
+        self.keep = []
+        descs = []
+        for i, (conv, cin_p) in enumerate(zip(convs, (4, 16, 16)), 1):
+            planes, row_scale = pack_smallc_f16x2(conv.weight, cin_p)
+            scale, shift = fold_norm(conv, None)
+            n = conv.out_channels
+            # acc = (S x) . (s[n] w): both power-of-two scales leave through the epilogue scale, exactly
+            sc = (scale.detach().float().cpu() / (row_scale[:n] * float(plan.act_scale))).to(plan.device)
+            bi, wdev = plan._vec(shift), planes.to(plan.device)
+            setattr(a, f"w{i}", wdev.data_ptr())
+            setattr(a, f"scale{i}", sc.data_ptr())
+            setattr(a, f"bias{i}", bi.data_ptr())
+            self.keep += [wdev, sc, bi]
+            descs.append(dict(weight=conv.weight, stride=conv.stride, pad=conv.padding, scale=plan._vec(scale), bias=bi))
+            Ho, Wo = (Hp, Wp) if i < 3 else (Hp // 2, Wp // 2)
+            self.macs += B * Ho * Wo * n * conv.weight.shape[1] * conv.weight.shape[2] * conv.weight.shape[3]
+        a.src, a.sizes = plan.in_u8.data_ptr(), plan.in_sizes.data_ptr()
+        for c in range(3):
+            a.mean[c], a.stdv[c] = float(model.pixel_mean.flatten()[c]), float(model.pixel_std.flatten()[c])
+        a.out = vout.ptr if vout.has_f32 else None
+        a.out_planes = vout.pptr if vout.np else None
+        a.B, a.Hp, a.Wp, a.out_pitch = B, Hp, Wp, vout.pitch
+        a.plane_scale = float(plan.act_scale)
+        a.status = plan.status.data_ptr()
+        self.a = a
+        self.desc = dict(kind="fused_stem", convs=descs, vout=vout, mean=[float(v) for v in model.pixel_mean.flatten()],
+                         std=[float(v) for v in model.pixel_std.flatten()], planes=bool(vout.np))
+        self.info = dict(name=name, M=B * (Hp // 2) * (Wp // 2), N=32, K=0, tile="fused", splitk=1, math=hip.MATH_F16X2, blocks=0, nsegs=1)
+
+    def __call__(self, lib, stream):
+        hip.check(lib.dd3d_stem_fused_f16x2(C.byref(self.a), stream), "fused stem " + self.name)
+
+
 class SmallcConvOp:
     """One dd3d_conv2d_smallc_bf16x3 launch: a stem convolution fed from an LDS patch (no im2col loop)."""
     def __init__(self, plan, conv_weight, cin_p, stride, pad, vin, vout, scale, bias, relu, name=""):
@@ -823,27 +885,34 @@ class ForwardPlan(PlanBase):
         self.in_outsize = torch.zeros((B, 4), dtype=torch.float32, device=dev)
         self.inv_K = torch.zeros((B, 9), dtype=torch.float32, device=dev)
 
-        # ---- preprocess
-        img = self.buf("img4", B, Hp, Wp, 4)
-        mean = (C.c_float * 3)(*[float(v) for v in model.pixel_mean.flatten().tolist()])
-        std = (C.c_float * 3)(*[float(v) for v in model.pixel_std.flatten().tolist()])
-
-        def _pre(lib, st, img=img, mean=mean, std=std):
-            hip.check(
-                lib.dd3d_preprocess_u8_nhwc4(self.in_u8.data_ptr(), self.in_sizes.data_ptr(), img.t.data_ptr(), B, Hp, Wp, mean, std, st),
-                "preprocess"
-            )
-            hip.check(lib.dd3d_invert_intrinsics(self.in_K.data_ptr(), self.inv_K.data_ptr(), B, st), "invert_intrinsics")
-
-        self.ops.append(CallOp(_pre, "preprocess", dict(kind="preprocess", img=img, mean=list(mean), std=list(std))))
-
-        # ---- backbone + FPN
+        # ---- preprocess.  With the fused stem (DLA, two-half-term arithmetic: FusedStemOp) the normalised image exists only inside
+        # that kernel's LDS tiles; `normalized_image()` produces it on demand (tests).
         from dd3d_amd.modeling.dla import DLA
         bb = model.backbone
+        self.fused_stem = self._can_fuse_stem(bb.bottom_up) if isinstance(bb.bottom_up, DLA) else False
+        self._norm = ((C.c_float * 3)(*[float(v) for v in model.pixel_mean.flatten().tolist()]),
+                      (C.c_float * 3)(*[float(v) for v in model.pixel_std.flatten().tolist()]))
+        img = self.buf("img4", B, Hp, Wp, 4) if (not self.fused_stem or self.dry_run) else None
+
+        def _pre(lib, st, img=img):
+            if img is not None:
+                hip.check(
+                    lib.dd3d_preprocess_u8_nhwc4(self.in_u8.data_ptr(), self.in_sizes.data_ptr(), img.t.data_ptr(), B, Hp, Wp, self._norm[0], self._norm[1], st),
+                    "preprocess"
+                )
+            hip.check(lib.dd3d_invert_intrinsics(self.in_K.data_ptr(), self.inv_K.data_ptr(), B, st), "invert_intrinsics")
+
+        self.ops.append(CallOp(_pre, "preprocess", dict(kind="preprocess", img=img, mean=list(self._norm[0]), std=list(self._norm[1]))))
+        if img is None:
+            img = View.__new__(View)  # geometry only: the DLA lowering reads B / H / W of the input view
+            img.buf, img.c0, img.C = type("Geom", (), dict(B=B, H=Hp, W=Wp, pitch=4, has_f32=False, np=0, t=None, p=None, name="img4"))(), 0, 4
+
+        # ---- backbone + FPN
+        img_view = img.view() if isinstance(img, Buf) else img
         if isinstance(bb.bottom_up, DLA):
-            feats = self._dla(bb.bottom_up, img.view())
+            feats = self._dla(bb.bottom_up, img_view)
         else:
-            feats = self._vovnet(bb.bottom_up, img.view())
+            feats = self._vovnet(bb.bottom_up, img_view)
         self.bottom_up = feats
         outs = self._fpn(bb, feats)  # name -> view, finest first
         # the heads see DD3D.IN_FEATURES (core.py:32-34,84): all FPN outputs in every reference config, a subset is allowed
@@ -851,6 +920,16 @@ class ForwardPlan(PlanBase):
         if self.fpn_tail_join is not None:
             self.join(self.fpn_tail_join)  # P6 / P7 (side branch) feed the towers
         self.strides = [s.stride for s in model.backbone_output_shape]
+
+    def normalized_image(self):
+        """The padded, normalised input canvas (B, 3, Hp, Wp) as the preprocess kernel writes it -- from the plan's buffer when the plan
+        has one, else (fused stem) by running that kernel into a scratch buffer on the current stream."""
+        if "img4" in self.bufs:
+            return self.bufs["img4"].nchw(0, 3)
+        t = torch.zeros((self.B, self.Hp, self.Wp, 4), dtype=torch.float32, device=self.device)
+        hip.check(self.lib.dd3d_preprocess_u8_nhwc4(self.in_u8.data_ptr(), self.in_sizes.data_ptr(), t.data_ptr(), self.B, self.Hp, self.Wp,
+                                                    self._norm[0], self._norm[1], hip.current_stream()), "preprocess")
+        return t[..., :3].permute(0, 3, 1, 2)
 
     # ------------------------------------------------------------------ DLA-34 (dla.py:170-355)
     def _block(self, m, x, residual, out, name, join=None, out_f32=True):
@@ -972,20 +1051,42 @@ class ForwardPlan(PlanBase):
         self._tree_generic(m.tree1, x, name + ".tree1", dst=t1)  # a chain of its own
         return self._tree_generic(m.tree2, t1, name + ".tree2", dst=dst, cat=cat, off=off + oc)
 
+    def _can_fuse_stem(self, dla):
+        """The one-launch stem (csrc/stem_fused.hip) covers the DLA-34 family's stem exactly: 7x7 3->16, ONE 3x3 16->16, ONE 3x3 stride-2
+        16->32, all bias-free + norm + ReLU, in the two-half-term arithmetic, on an even canvas.  DD3D_FUSED_STEM=0 keeps the launch-by-
+        launch lowering (A/B measurements; it is also what every other arithmetic mode uses)."""
+        import os
+        if self.math != hip.MATH_F16X2 or os.environ.get("DD3D_FUSED_STEM", "1") == "0" or self.Hp % 2 or self.Wp % 2:
+            return False
+        convs = [dla.base_layer] + list(dla.level0) + list(dla.level1)
+        want = [(16, 3, 7, 1, 3), (16, 16, 3, 1, 1), (32, 16, 3, 2, 1)]
+        if len(convs) != 3:
+            return False
+        for cv, (n, c, k, st, pd) in zip(convs, want):
+            if (tuple(cv.weight.shape) != (n, c, k, k) or cv.stride != st or cv.padding != pd or getattr(cv, "groups", 1) != 1
+                    or cv.bias is not None or cv.norm is None):
+                return False
+        return True
+
     def _dla(self, dla, img):
         B, H, W = img.B, img.H, img.W
         ch = dla.channels
-        base = self.buf("base", B, H, W, ch[0])
-        self.conv_module(dla.base_layer, img, base.view(), relu=True, name="base_layer")
-        x = base.view()
-        for i, conv in enumerate(dla.level0):
-            y = self.buf(f"level0.{i}", B, H, W, ch[0])
-            self.conv_module(conv, x, y.view(), relu=True, name=f"level0.{i}")
+        if self.fused_stem:
+            y = self.buf("level1.0", B, H // 2, W // 2, ch[1], kind="both")  # level2: conv input (planes) + max-pool input (f32)
+            self.ops.append(FusedStemOp(self, self.model, [dla.base_layer, dla.level0[0], dla.level1[0]], y.view(), name="stem"))
             x = y.view()
-        for i, conv in enumerate(dla.level1):
-            y = self.buf(f"level1.{i}", B, x.H // conv.stride, x.W // conv.stride, ch[1], kind="both")  # level2: conv input + max-pool input
-            self.conv_module(conv, x, y.view(), relu=True, name=f"level1.{i}")
-            x = y.view()
+        else:
+            base = self.buf("base", B, H, W, ch[0])
+            self.conv_module(dla.base_layer, img, base.view(), relu=True, name="base_layer")
+            x = base.view()
+            for i, conv in enumerate(dla.level0):
+                y = self.buf(f"level0.{i}", B, H, W, ch[0])
+                self.conv_module(conv, x, y.view(), relu=True, name=f"level0.{i}")
+                x = y.view()
+            for i, conv in enumerate(dla.level1):
+                y = self.buf(f"level1.{i}", B, x.H // conv.stride, x.W // conv.stride, ch[1], kind="both")  # level2: conv input + max-pool input
+                self.conv_module(conv, x, y.view(), relu=True, name=f"level1.{i}")
+                x = y.view()
         outs = {"level0": None, "level1": x}
         from dd3d_amd.modeling.dla import BasicBlock
         plain34 = dla.block is BasicBlock and max(dla.levels) <= 2 and not dla.residual_root  # DLA-34: the measured lowering

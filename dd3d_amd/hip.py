@@ -63,6 +63,16 @@ class SmallcArgs(C.Structure):
     ]
 
 
+class StemArgs(C.Structure):
+    """`dd3d_stem_args`."""
+    _fields_ = [
+        ("src", C.c_void_p), ("sizes", C.c_void_p), ("mean", C.c_float * 3), ("stdv", C.c_float * 3), ("w1", C.c_void_p), ("scale1", C.c_void_p),
+        ("bias1", C.c_void_p), ("w2", C.c_void_p), ("scale2", C.c_void_p), ("bias2", C.c_void_p), ("w3", C.c_void_p), ("scale3", C.c_void_p),
+        ("bias3", C.c_void_p), ("out", C.c_void_p), ("out_planes", C.c_void_p), ("B", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32),
+        ("out_pitch", C.c_int32), ("plane_scale", C.c_float), ("status", C.c_void_p)
+    ]
+
+
 class ResizeArgs(C.Structure):
     """`dd3d_resize_args`."""
     _fields_ = [
@@ -116,7 +126,7 @@ EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
     "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8",
-    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_upsample2x_add_planes", "dd3d_ese_fused"
+    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_upsample2x_add_planes", "dd3d_ese_fused", "dd3d_stem_fused_f16x2"
 ]
 
 
@@ -158,6 +168,7 @@ def lib():
     L.dd3d_bev_nms_aggregate.argtypes = [C.POINTER(BevArgs), C.c_void_p]
     L.dd3d_conv2d_smallc_supported.argtypes = [C.c_int32] * 6
     L.dd3d_conv2d_smallc_bf16x3.argtypes = [C.POINTER(SmallcArgs), C.c_void_p]
+    L.dd3d_stem_fused_f16x2.argtypes = [C.POINTER(StemArgs), C.c_void_p]
     L.dd3d_rotate_iou_eval.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p]
     L.dd3d_d3_box_overlap.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p]
     L.dd3d_image_box_overlap.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p]

@@ -198,6 +198,39 @@ typedef struct dd3d_smallc_args {  /* host memory */
   int32_t relu;
 } dd3d_smallc_args;
 int dd3d_conv2d_smallc_supported(int32_t Cin, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t N);
+
+/* ------------------------------------------------------------------------------------------------
+ * The DLA stem in one launch (ABI 3): uint8 image -> (x - mean) / std (core.py:61-66, zero outside the real image as
+ * ImageList.from_tensors pads, image_list.py:120-142) -> base_layer 7x7 3->16 -> level0 3x3 16->16 -> level1 3x3 stride 2 16->32,
+ * each + folded norm + ReLU (dla.py:271-280,327-344), DD3D_MATH_F16X2 arithmetic.  Intermediate maps never leave the LDS.
+ *   src    uint8 [B][3][Hp][Wp] planar; sizes int32 [B][2] = real (h, w) of each image; mean / stdv per input channel
+ *   wK     halves [chunk][plane hi, lo][Npad16][32] of filter K in the k order of dd3d_conv2d_smallc_bf16x3 (w1: Cin 4, 7 chunks,
+ *          16 rows; w2: Cin 16, 5 chunks, 16 rows; w3: Cin 16, 5 chunks, 32 rows), every row n scaled by a power of two s_K[n]
+ *   scaleK / biasK  per output channel: out = relu(acc * scaleK + biasK); the caller folds 1 / (s_K[n] * plane_scale) into scaleK
+ *   out    f32 NHWC [B][Hp/2][Wp/2] rows of out_pitch floats, channels [0, 32) (may be NULL)
+ *   out_planes  [pixel][plane][32] halves of value * plane_scale: the one 32-channel chunk image of the split-plane form (may be NULL)
+ *   status: the word dd3d_conv_launch.status names -- DD3D_STATUS_F16_OVERFLOW is set when an intermediate or output value leaves the half range)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct dd3d_stem_args {  /* host memory; all pointers device */
+  const uint8_t* src;
+  const int32_t* sizes;
+  float mean[3], stdv[3];
+  const void* w1;
+  const float* scale1;
+  const float* bias1;
+  const void* w2;
+  const float* scale2;
+  const float* bias2;
+  const void* w3;
+  const float* scale3;
+  const float* bias3;
+  float* out;
+  void* out_planes;
+  int32_t B, Hp, Wp, out_pitch;
+  float plane_scale;
+  int32_t* status;
+} dd3d_stem_args;
+int dd3d_stem_fused_f16x2(const dd3d_stem_args* args, void* stream);
 int dd3d_conv2d_smallc_bf16x3(const dd3d_smallc_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ def main():
         report[name] = {"max_abs": e, "rel": r, "ref_absmax": float(b.abs().max())}
         print(f"{name:28s} max_abs={e:.3e} rel={r:.3e} (|ref|max={float(b.abs().max()):.3e})", flush=True)
 
-    line("images", plan.bufs["img4"].nchw(0, 3), st["images"])
+    line("images", plan.normalized_image(), st["images"])
     for k, v in st["bottom_up"].items():
         line("bottom_up." + k, plan.bottom_up[k].nchw(), v)
     for l, f in enumerate(st["features"]):

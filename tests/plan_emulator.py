@@ -44,6 +44,17 @@ def _smallc(d):
     _store(d["vout"], F.relu(y) if d["relu"] else y, n)
 
 
+def _fused_stem(plan, d):
+    """csrc/stem_fused.hip: the normalised canvas (the preprocess op's buffer) through base_layer -> level0 -> level1, each + folded
+    norm + ReLU."""
+    x = plan.bufs["img4"].nchw(0, 3)
+    for cv in d["convs"]:
+        w = cv["weight"].detach().float()
+        n = w.shape[0]
+        x = F.relu(F.conv2d(x, w, None, stride=cv["stride"], padding=cv["pad"]) * cv["scale"][:n].view(1, -1, 1, 1) + cv["bias"][:n].view(1, -1, 1, 1))
+    _store(d["vout"], x, x.shape[1])
+
+
 def _preprocess(plan, d):
     img = d["img"].t
     img.zero_()
@@ -92,6 +103,10 @@ def _track(forms, name, d):
         forms.wrote(d["vout"], "f32", d["weight"].shape[0])
     elif k == "preprocess":
         forms.wrote(d["img"].view(), "f32")
+    elif k == "fused_stem":
+        forms.wrote(d["vout"], "f32")
+        if d["planes"]:
+            forms.wrote(d["vout"], "planes")
     elif k == "split_planes":
         forms.reads(d["src"], "f32", name)
         forms.wrote(d["dst"], "planes")
@@ -133,6 +148,8 @@ def emulate(plan, stop_before=("select_decode", )):
             _smallc(d)
         elif k == "preprocess":
             _preprocess(plan, d)
+        elif k == "fused_stem":
+            _fused_stem(plan, d)
         elif k == "split_planes":
             if d["dst"] is not d["src"]:
                 x = d["src"].nchw()

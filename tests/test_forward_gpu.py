@@ -81,7 +81,7 @@ def test_forward_matches_oracle(hiplib, kitti_dla34, H, W, B, math):
     plan.run()
     torch.cuda.synchronize()
     C = cfg.DD3D.NUM_CLASSES
-    assert torch.equal(plan.bufs["img4"].nchw(0, 3).cpu(), st["images"])  # normalise + pad is bit-exact
+    assert torch.equal(plan.normalized_image().cpu(), st["images"])  # normalise + pad is bit-exact
     _check_head_maps(plan, st, C)
     out = model.collect(plan, inputs, image_sizes)
     # end-to-end: a candidate only one side selected must sit ON a cut (oracle score within MARGIN_EPS of PRE_NMS_THRESH / of the
@@ -205,7 +205,7 @@ def test_hip_matches_reference_golden(hiplib, name):
     plan.run()
     torch.cuda.synchronize()
     C = cfg.DD3D.NUM_CLASSES
-    assert torch.equal(plan.bufs["img4"].nchw(0, 3).cpu(), t("images"))
+    assert torch.equal(plan.normalized_image().cpu(), t("images"))
     keys = ("logits", "box2d_reg", "centerness", "quat", "ctr", "depth", "size", "conf") + (("attr", "speed") if nusc else ())
     st = {k: [t(f"{k}{l}") for l in range(5)] for k in keys}
     for l in range(5):

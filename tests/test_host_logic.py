@@ -67,7 +67,12 @@ def test_plan_construction_dry_run(kitti_dla34, hiplib):
     plan = ForwardPlan(model, 1, 384, 1280, device="cpu", dry_run=True)
     convs = [op for op in plan.ops if isinstance(op, ConvOp)]
     gmac = plan.conv_macs / 1e9
-    assert abs(gmac - (110.384 + 0.3853)) < 0.01, gmac  # + the Cin 3 -> 4 padding of the 7x7 stem; p7 rectifies p6 on the fly (no second p6 conv)
+    assert plan.fused_stem and plan.ops[1].name == "stem"  # default arithmetic: the one-launch stem (counts the algorithmic 3-channel MACs)
+    assert abs(gmac - 110.384) < 0.01, gmac  # BASELINE.md's count; p7 rectifies p6 on the fly (no second p6 conv)
+    model.math = "bf16x3"  # launch-by-launch stem: + the Cin 3 -> 4 padding of the 7x7 conv
+    unfused = ForwardPlan(model, 1, 384, 1280, device="cpu", dry_run=True)
+    model.math = None
+    assert not unfused.fused_stem and abs(unfused.conv_macs / 1e9 - (110.384 + 0.3853)) < 0.01
     assert [f.H * f.W for f in plan.features] == [7680, 1920, 480, 120, 30]
     towers = [c for c in convs if c.name.startswith("towers.")]
     assert len(towers) == 4 and all(c.info["nsegs"] == 15 for c in towers)
@@ -242,7 +247,7 @@ def test_header_is_plain_c_and_matches_the_ctypes_mirrors(tmp_path):
     import subprocess
     from dd3d_amd import hip
     mirrors = {"dd3d_conv_launch": hip.ConvLaunch, "dd3d_smallc_args": hip.SmallcArgs, "dd3d_resize_args": hip.ResizeArgs,
-               "dd3d_select_args": hip.SelectArgs, "dd3d_nms_args": hip.NmsArgs, "dd3d_bev_args": hip.BevArgs}
+               "dd3d_select_args": hip.SelectArgs, "dd3d_nms_args": hip.NmsArgs, "dd3d_bev_args": hip.BevArgs, "dd3d_stem_args": hip.StemArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dd3d_hip.h"', 'int main(void) {',
              '  printf("dd3d_conv_seg %zu\\n", sizeof(dd3d_conv_seg));']
     for cname, cls in mirrors.items():
