@@ -35,6 +35,7 @@ struct ConvKArgs {
   int in_relu;  // bf16x3 kernel with f32 input: rectify the input while it is split (conv(relu(x)) without a rectified copy of x)
   float out_plane_scale;  // F16X2: split-plane outputs hold value * this (power of two)
   int* status;            // OR-ed with DD3D_STATUS_* bits, or null
+  float* amax;            // F16X2: atomic max of |stored plane value| (scaled), or null
   dd3d_conv_seg seg0;
 };
 
@@ -219,6 +220,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
     const int odd = lane & 1;
     const float pscale = a.out_plane_scale;
     int ovf = 0;
+    float amx = 0.f;  // F16X2: largest |scaled value| this lane stores as planes
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nb = n0 + (wn * TN + j) * 32;  // wave-uniform: first channel of this column block
@@ -264,6 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
             if constexpr (Planes<MODE>::F16) {
               e0 *= pscale, e1 *= pscale;
               ovf |= !(fabsf(e0) <= 65504.f) | !(fabsf(e1) <= 65504.f);
+              if (m < s.M) amx = fmaxf(amx, fmaxf(fabsf(e0), fabsf(e1)));
             }
             split_pack<MODE>(e0, e1, w);
             if (m < s.M) {
@@ -277,6 +280,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
     }
     if constexpr (Planes<MODE>::F16) {
       if (ovf && a.status) atomicOr(a.status, DD3D_STATUS_F16_OVERFLOW);  // (NaN / inf inputs trip it as well)
+      if (a.amax) {  // one atomic per wave: non-negative floats order like their bit patterns
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) amx = fmaxf(amx, __shfl_xor(amx, d, 64));
+        if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.amax), __float_as_uint(amx));
+      }
     }
   }
 }

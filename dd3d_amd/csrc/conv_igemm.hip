@@ -886,6 +886,7 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   DD3D_REQUIRE(L->math_mode >= DD3D_MATH_F32 && L->math_mode <= DD3D_MATH_F16X2, "dd3d_conv2d_igemm_f32: unknown math mode %d", L->math_mode);
   ka.out_plane_scale = L->out_plane_scale > 0.f ? L->out_plane_scale : 1.f;
   ka.status = L->status;
+  ka.amax = L->amax;
   if (L->in_planes) {
     DD3D_REQUIRE(L->math_mode != DD3D_MATH_F32 && !smallc && L->zero_page && !L->in_relu,
                  "dd3d_conv2d_igemm_f32: split-plane input needs a split-operand math mode, Cin %% 32 == 0, a zero page and no in_relu");

@@ -530,6 +530,8 @@ class ConvOp:
         L.in_planes = int(in_planes)
         L.out_plane_scale = float(plan.act_scale)
         L.status = plan.status.data_ptr() if plan.status is not None else None
+        # underflow side of the f16x2 range guard: only launches that hand planes to a following convolution are watched
+        L.amax = plan.amax_slot(name) if (math == hip.MATH_F16X2 and any(wp for _, wp in self.out_forms) and not plan.dry_run) else None
         self.L = L
         # algorithmic MACs: every segment counts the channels it stores
         self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs)) * meta["KH"] * meta["KW"] * meta["Cin"]
@@ -595,6 +597,10 @@ class PlanBase:
         self.act_scale = float(os.environ.get("DD3D_F16_ACT_SCALE", "16"))
         assert self.act_scale > 0 and _math.log2(self.act_scale).is_integer(), "DD3D_F16_ACT_SCALE must be a power of two"
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)  # DD3D_STATUS_* bits OR-ed in by the kernels
+        # DD3D_MATH_F16X2, the other side of the range guard: one float per convolution launch that writes split planes, holding the
+        # largest |value * plane scale| it stored (dd3d_conv_launch.amax); zeroed at the start of a forward, read by check_status()
+        self.amax = torch.zeros(512, dtype=torch.float32, device=self.device)
+        self.amax_names = []
 
     @property
     def use_planes(self):
@@ -606,14 +612,34 @@ class PlanBase:
             return False
         return self.math != hip.MATH_BF16X3 or os.environ.get("DD3D_PLANES", "1") != "0"
 
+    AMAX_FLOOR = 2.0**-5  # largest scaled entry of a tensor below this: > 4 of its 24 bits are under the half pair's absolute floor 2^-25
+
+    def amax_slot(self, name):
+        """Device address of a fresh per-launch maximum (DD3D_MATH_F16X2 range guard, underflow side)."""
+        assert len(self.amax_names) < self.amax.numel()
+        self.amax_names.append(name)
+        return self.amax.data_ptr() + 4 * (len(self.amax_names) - 1)
+
     def check_status(self):
-        """Raise if a kernel flagged a numeric fault (reads one int32 from the device; call after the forward has been waited for)."""
+        """Raise if a kernel flagged a numeric fault (reads one int32 and the per-launch maxima from the device; call after the forward
+        has been waited for).  DD3D_MATH_F16X2 keeps activations as two IEEE halves of value * plane scale: exact to 2^-24 relative
+        between 2^-1 and 65504, with an ABSOLUTE floor of 2^-25 below.  Overflow is flagged per element (status bit); underflow per
+        tensor: a convolution whose LARGEST output, scaled, stayed below 2^-5 has lost more than four of its 24 bits."""
         st = int(self.status.cpu())
         if st & hip.STATUS_F16_OVERFLOW:
             self.status.zero_()
             raise FloatingPointError(
                 f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}, or a "
                 "NaN / inf): lower DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
+        if self.amax_names:
+            mx = self.amax[:len(self.amax_names)].cpu()
+            low = [(n, float(v)) for n, v in zip(self.amax_names, mx.tolist()) if 0.0 < v < self.AMAX_FLOOR]
+            if low:
+                n, v = min(low, key=lambda t: t[1])
+                raise FloatingPointError(
+                    f"the outputs of {len(low)} convolution(s) sit below the half range's useful part (smallest: {n}, max |x| = "
+                    f"{v / self.act_scale:.3g} at plane scale {self.act_scale:g}; the pair (hi, lo) has an absolute floor of {2.0**-25 / self.act_scale:.2g}): "
+                    "raise DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
 
     def adopt_weight_store(self, model):
         """Use the model's weight store (created on first use; dropped by DD3D.invalidate_plans when the weights change)."""
@@ -895,6 +921,7 @@ class ForwardPlan(PlanBase):
         img = self.buf("img4", B, Hp, Wp, 4) if (not self.fused_stem or self.dry_run) else None
 
         def _pre(lib, st, img=img):
+            self.amax.zero_()  # (captured with the rest of the forward: the maxima are per forward)
             if img is not None:
                 hip.check(
                     lib.dd3d_preprocess_u8_nhwc4(self.in_u8.data_ptr(), self.in_sizes.data_ptr(), img.t.data_ptr(), B, Hp, Wp, self._norm[0], self._norm[1], st),

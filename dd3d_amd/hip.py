@@ -49,7 +49,7 @@ class ConvLaunch(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("Cin", C.c_int32), ("N", C.c_int32),
         ("Kpad", C.c_int32), ("Npad", C.c_int32), ("relu", C.c_int32), ("splitk", C.c_int32), ("math_mode", C.c_int32),
         ("tile_cfg", C.c_int32), ("zero_page", C.c_void_p), ("tile_counters", C.c_void_p), ("seg0_host", C.c_void_p), ("in_relu", C.c_int32),
-        ("in_planes", C.c_int32), ("out_plane_scale", C.c_float), ("status", C.c_void_p)
+        ("in_planes", C.c_int32), ("out_plane_scale", C.c_float), ("status", C.c_void_p), ("amax", C.c_void_p)
     ]
 
 

@@ -90,7 +90,8 @@ def _camera_worker(rank, world, port, ret):
     bad = []
     single = build_model(cfg)
     single.load_state_dict(sd)
-    close = lambda x, y: x.shape == y.shape and bool(torch.allclose(x, y, rtol=1e-5, atol=1e-6))
+    # (absolute tolerance relative to the tensor's largest entry: pixel coordinates are O(100), a clipped one may be exactly 0)
+    close = lambda x, y: x.shape == y.shape and (x.numel() == 0 or float((x - y).abs().max()) <= 1e-5 * max(1.0, float(y.abs().max())))
     for use_graph in (False, True):
         runner = DistributedForward(model, B, H + (-H) % 128, W + (-W) % 128, use_graph=use_graph, camera_sharded=True)
         for step in range(2):  # two different samples through the same plan

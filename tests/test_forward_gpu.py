@@ -309,6 +309,33 @@ def test_nuscenes_two_samples_match_oracle(hiplib, bev_nms, cap):
         assert torch.equal(x["instances"].scores_3d, y["instances"].scores_3d) and torch.equal(x["instances"].pred_boxes.tensor, y["instances"].pred_boxes.tensor)
 
 
+def test_bev_capacity_counts_boxes_not_slots(hiplib):
+    """Six nuScenes samples (36 images) on one rank: 36 x 256 detection SLOTS exceed the 8192 entries of the BEV sorter (round 2 refused
+    to build this plan), the few hundred actual detections do not.  Against the oracle on identical head maps."""
+    from oracle import nuscenes_oracle as N
+    from dd3d_amd.synthetic import make_inputs
+    from tests.util import bundle
+    cfg, sd = bundle("dd3d_nusc_dla34", "dla34_nusc", {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.02}}}})
+    model = gpu_model(cfg, sd, use_graph=False)
+    B = 36
+    inputs = make_inputs(B, 128, 160, dataset="nusc")
+    with torch.no_grad():
+        ref, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
+    plan, image_sizes = model.stage_inputs(inputs)
+    assert plan.B * plan.det_cap > 8192
+    plan.run()
+    torch.cuda.synchronize()
+    C = cfg.DD3D.NUM_CLASSES
+    oracle_heads_to_plan(plan, st, C)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
+    torch.cuda.synchronize()
+    out = model.collect(plan, inputs, image_sizes)
+    assert sum(len(r["scores"]) for r in ref) > 100
+    for i in range(B):
+        _check_final(out[i], ref[i])
+        _nusc_check(out[i]["instances"], ref[i], True)
+
+
 def test_kitti_bev_nms_matches_oracle(hiplib, kitti_dla34):
     """DD3D.INFERENCE.DO_BEV_NMS on the KITTI model (core.py:135-150): per-image BEV rotated NMS between the 2D NMS and the
     resize, poses taken from 'extrinsics' when there is no 'pose'."""

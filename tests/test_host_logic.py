@@ -130,7 +130,7 @@ def test_cabi_exports_match_header(hiplib):
     for cfg_id, shape in hip.TILE_SHAPES.items():
         assert hiplib.dd3d_conv_tile_shape(cfg_id, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == shape
     assert hiplib.dd3d_conv_tile_shape(99, C.byref(bm), C.byref(bn)) < 0 and b"tile_cfg" in hiplib.dd3d_last_error()
-    assert C.sizeof(hip.ConvLaunch) == 128 and hip.CONV_SEG_DTYPE.itemsize == 120
+    assert C.sizeof(hip.ConvLaunch) == 136 and hip.CONV_SEG_DTYPE.itemsize == 120
 
 
 def test_config_surface():
@@ -385,3 +385,16 @@ def test_plan_cache_is_bounded_lru(kitti_dla34, monkeypatch):
     assert [p.key for p in model._plans.values()] == [(1, 256, 256), (1, 128, 256), (2, 128, 256)]
     model.get_plan(1, 128, 384)
     assert built[-1] == (1, 128, 384) and len(built) == 5 and len(model._plans) == 3
+
+
+def test_collect_reports_a_bev_sorter_overflow(kitti_dla34):
+    """dd3d_bev_nms_aggregate writes count_out = -1 everywhere when more than 8192 boxes meet in one problem; the host must not read
+    detections then (round 2 silently relied on a build-time capacity check instead)."""
+    import torch
+    cfg, model, sd = kitti_dla34
+    fake = type("P", (), dict(det_count=torch.tensor([-1, -1], dtype=torch.int32), det_cap=256, check_status=lambda self: None))()
+    with pytest.raises(RuntimeError, match="8192 detections"):
+        model._counts(fake)
+    ok = type("P", (), dict(det_count=torch.tensor([3, 7], dtype=torch.int32), det_cap=256, check_status=lambda self: None))()
+    counts, n_max = model._counts(ok)
+    assert counts.tolist() == [3, 7] and n_max == 7
