@@ -241,9 +241,9 @@ def main():
         traffic, traffic_src = None, None
         if os.path.exists(args.traffic_json):
             try:
-                rec = json.load(open(args.traffic_json)).get(kname)
                 # (a record is for one launch geometry: the same instantiation on another number of images per launch moves other bytes)
-                if rec is not None and int(rec.get("images_per_launch", 1)) == plan.B:
+                rec = json.load(open(args.traffic_json)).get(f"{kname} @ {plan.B} images per launch")
+                if rec is not None:
                     traffic, traffic_src = rec["hbm_bytes_per_launch"], f"{os.path.relpath(args.traffic_json, ROOT)} ({rec.get('collected', '')})"
             except Exception:
                 traffic = None

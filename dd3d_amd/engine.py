@@ -531,7 +531,8 @@ class ConvOp:
         L.out_plane_scale = float(plan.act_scale)
         L.status = plan.status.data_ptr() if plan.status is not None else None
         # underflow side of the f16x2 range guard: only launches that hand planes to a following convolution are watched
-        L.amax = plan.amax_slot(name) if (math == hip.MATH_F16X2 and any(wp for _, wp in self.out_forms) and not plan.dry_run) else None
+        L.amax = plan.amax_slot(name) if (math == hip.MATH_F16X2 and any(wp for _, wp in self.out_forms) and not plan.dry_run
+                                          and os.environ.get("DD3D_AMAX", "1") != "0") else None  # DD3D_AMAX=0: A/B measurements only
         self.L = L
         # algorithmic MACs: every segment counts the channels it stores
         self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs)) * meta["KH"] * meta["KW"] * meta["Cin"]
@@ -599,7 +600,7 @@ class PlanBase:
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)  # DD3D_STATUS_* bits OR-ed in by the kernels
         # DD3D_MATH_F16X2, the other side of the range guard: one float per convolution launch that writes split planes, holding the
         # largest |value * plane scale| it stored (dd3d_conv_launch.amax); zeroed at the start of a forward, read by check_status()
-        self.amax = torch.zeros(512, dtype=torch.float32, device=self.device)
+        self.amax = torch.zeros((512, 16, 32), dtype=torch.float32, device=self.device)  # [launch][sub-maximum][128-byte line]
         self.amax_names = []
 
     @property
@@ -616,9 +617,13 @@ class PlanBase:
 
     def amax_slot(self, name):
         """Device address of a fresh per-launch maximum (DD3D_MATH_F16X2 range guard, underflow side)."""
-        assert len(self.amax_names) < self.amax.numel()
+        assert len(self.amax_names) < self.amax.shape[0]
         self.amax_names.append(name)
-        return self.amax.data_ptr() + 4 * (len(self.amax_names) - 1)
+        return self.amax[len(self.amax_names) - 1].data_ptr()
+
+    def amax_values(self):
+        """Largest sampled |value * plane scale| of every watched launch of the last forward (CPU tensor, order of `amax_names`)."""
+        return self.amax[:len(self.amax_names), :, 0].amax(1).cpu()
 
     def check_status(self):
         """Raise if a kernel flagged a numeric fault (reads one int32 and the per-launch maxima from the device; call after the forward
@@ -632,7 +637,7 @@ class PlanBase:
                 f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}, or a "
                 "NaN / inf): lower DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
         if self.amax_names:
-            mx = self.amax[:len(self.amax_names)].cpu()
+            mx = self.amax_values()
             low = [(n, float(v)) for n, v in zip(self.amax_names, mx.tolist()) if 0.0 < v < self.AMAX_FLOOR]
             if low:
                 n, v = min(low, key=lambda t: t[1])

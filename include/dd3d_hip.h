@@ -108,10 +108,11 @@ typedef struct dd3d_conv_launch {  /* host memory */
                         split-operand math mode */
   float out_plane_scale; /* DD3D_MATH_F16X2: the split-plane outputs hold value * out_plane_scale (a power of two; 0 = 1) */
   int32_t* status;       /* device int32 OR-ed with DD3D_STATUS_* bits by the kernels, or NULL */
-  float* amax;           /* DD3D_MATH_F16X2, split-plane outputs: device float that receives max(*amax, max |value * out_plane_scale|) over
-                            the stored outputs of this launch (atomic; compare as unsigned), or NULL.  The caller zeroes it before a
-                            forward and reads it afterwards: a tensor whose LARGEST scaled entry is below 2^-5 has lost more than four of
-                            its 24 bits to the absolute floor 2^-25 of the half pair (the "underflow" side of the range guard). */
+  float* amax;           /* DD3D_MATH_F16X2, split-plane outputs: 16 device floats, 32 floats apart (amax[32 * j], j < 16), or NULL.  The
+                            launch folds max |value * out_plane_scale| over a sample of its stored outputs (one wave tile per block) into
+                            them (atomic max; non-negative floats compare like their bit patterns).  The caller zeroes them before a forward
+                            and reads their maximum afterwards: a tensor whose LARGEST scaled entry is below 2^-5 has lost more than four
+                            of its 24 bits to the absolute floor 2^-25 of the half pair (the "underflow" side of the range guard). */
 } dd3d_conv_launch;
 
 /* Arithmetic of the implicit GEMM (results agree to f32 rounding level; both accumulate in f32):

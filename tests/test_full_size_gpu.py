@@ -233,7 +233,7 @@ def _scaled_between(sd, bn_a, bn_b, factor):
 def test_half_range_guard_with_realistic_statistics(hiplib, kitti_dla34, monkeypatch):
     """Round-2 verdict: the range of the default f16x2 arithmetic exercised by a NETWORK whose statistics move, not by an absurd plane
     scale.  One mid-network activation (DLA level3, between the two norms of a BasicBlock) is scaled so that its largest entry is
-      ~3000   (inside the range, 4094 at plane scale 16)  -> no flag, parity with the oracle on the same weights;
+      ~2000+  (inside the range, 4094 at plane scale 16)  -> no flag, parity with the oracle on the same weights;
       ~6000   (outside)                                   -> the overflow bit: explicit f16x2 raises BEFORE results are returned, the
                                                             default arithmetic falls back to bf16x3 and agrees with the oracle;
       ~1e-6   (far below the pair's absolute floor's useful range) -> the per-tensor maximum trips the underflow side of the guard:
@@ -249,8 +249,8 @@ def test_half_range_guard_with_realistic_statistics(hiplib, kitti_dla34, monkeyp
     base(inputs)
     plan = next(iter(base._plans.values()))
     slot = plan.amax_names.index("level3.tree1.tree1.conv1")
-    a0 = float(plan.amax[slot].cpu()) / plan.act_scale  # largest activation between the two norms
-    every = plan.amax[:len(plan.amax_names)].cpu() / plan.act_scale
+    a0 = float(plan.amax_values()[slot]) / plan.act_scale  # largest (sampled) activation between the two norms
+    every = plan.amax_values() / plan.act_scale
     print(f"[range] max |activation| per plane-writing conv: min {float(every.min()):.3g} max {float(every.max()):.3g}; level3.tree1.tree1.conv1 {a0:.3g}")
     assert a0 > 0 and float(every.min()) > plan.AMAX_FLOOR / plan.act_scale  # the synthetic network itself sits inside the range
     C = cfg.DD3D.NUM_CLASSES
@@ -262,12 +262,12 @@ def test_half_range_guard_with_realistic_statistics(hiplib, kitti_dla34, monkeyp
         _check_head_maps(p, st, C)
         assert len(out[0]["instances"]) == len(ref[0]["scores"]) > 0
 
-    # ~3000: inside
-    sd_in = _scaled_between(sd, bn_a, bn_b, 3000.0 / a0)
+    # ~2000 on the guard's sample of the outputs (a lower bound of the true maximum, which must stay below 4094): inside
+    sd_in = _scaled_between(sd, bn_a, bn_b, 2000.0 / a0)
     m = gpu_model(cfg, sd_in, use_graph=False, math="f16x2")
     check(m, sd_in)
     p = next(iter(m._plans.values()))
-    assert 2500.0 < float(p.amax[slot].cpu()) / p.act_scale < 3500.0
+    assert 1800.0 < float(p.amax_values()[slot]) / p.act_scale < 2200.0
     # ~6000: overflow, and ~1e-6: underflow -- explicit mode raises, default mode falls back
     for factor, what in ((6000.0 / a0, "half range"), (1e-6 / a0, "useful part")):
         sd_x = _scaled_between(sd, bn_a, bn_b, factor)
