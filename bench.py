@@ -58,12 +58,12 @@ def parse_args():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-graph", action="store_true", help="launch kernel by kernel instead of replaying the hipGraph")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DD3D_BENCH_PIPELINE", "4")),
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DD3D_BENCH_PIPELINE", "5")),
                     help="plan slots of dd3d_amd.parallel.PipelinedForward (exchange + NMS of step i overlap the trunk of step i+1); "
                          "0 = one step at a time")
-    ap.add_argument("--compute-streams", type=int, default=int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "4")),
+    ap.add_argument("--compute-streams", type=int, default=int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "5")),
                     help="PipelinedForward: streams the slots' trunks are issued on (> 1 lets consecutive steps share the chip)")
-    ap.add_argument("--microbatch", type=int, default=int(os.environ.get("DD3D_BENCH_MICROBATCH", "5")),
+    ap.add_argument("--microbatch", type=int, default=int(os.environ.get("DD3D_BENCH_MICROBATCH", "4")),
                     help="PipelinedForward: queued requests (steps) one slot's launch plan covers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=200, help="upper bound; the CPU leg stops after ~12 s of work")

@@ -926,7 +926,7 @@ class ForwardPlan(PlanBase):
         img = self.buf("img4", B, Hp, Wp, 4) if (not self.fused_stem or self.dry_run) else None
 
         def _pre(lib, st, img=img):
-            self.amax.zero_()  # (captured with the rest of the forward: the maxima are per forward)
+            self.amax[:max(1, len(self.amax_names))].zero_()  # (captured with the rest of the forward: the maxima are per forward)
             if img is not None:
                 hip.check(
                     lib.dd3d_preprocess_u8_nhwc4(self.in_u8.data_ptr(), self.in_sizes.data_ptr(), img.t.data_ptr(), B, Hp, Wp, self._norm[0], self._norm[1], st),
