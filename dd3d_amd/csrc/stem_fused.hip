@@ -65,6 +65,33 @@ __device__ __forceinline__ f32x4 sf_mfma3(f16x8 ahi, f16x8 alo, f16x8 whi, f16x8
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi, acc, 0, 0, 0);
 }
 
+// One 16-pixel x 16-channel accumulator block -> the (hi, lo) half planes of a tile in LDS, rows of 16 channels (32 bytes) per pixel.
+// C/D map of the 16x16 MFMA: column (channel) = lane & 15, row (pixel of the group) = (lane >> 4) * 4 + e.  Lanes n and n ^ 1 swap one value
+// per pixel pair (DPP quad_perm [1, 0, 3, 2]) so that every lane stores a (channel n & ~1, n | 1) dword for two of its four pixels: four
+// 4-byte LDS stores per lane instead of eight 2-byte ones.  `zero(po)`: the pixel lies outside the canvas (the next filter's zero padding).
+template <class Z>
+__device__ __forceinline__ int sf_store_tile(unsigned char* plane_hi, int plane_bytes, int g, int lane, f32x4 acc, float sc, float bi, float pscale, Z&& zero) {
+  const int q4 = lane >> 4, n_lane = lane & 15, odd = lane & 1;
+  int ovf = 0;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = zero(g * 16 + q4 * 4 + e) ? 0.f : fmaxf(acc[e] * sc + bi, 0.f);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float send = odd ? v[2 * t] : v[2 * t + 1];
+    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));
+    const float own = odd ? v[2 * t + 1] : v[2 * t];
+    const int po = g * 16 + q4 * 4 + 2 * t + odd;           // the pixel this lane stores
+    const float e0 = odd ? recv : own, e1 = odd ? own : recv;  // channels n & ~1, n | 1
+    _Float16 h0, l0, h1, l1;
+    ovf |= sf_split(e0, pscale, h0, l0) | sf_split(e1, pscale, h1, l1);
+    unsigned char* dst = plane_hi + po * 32 + (n_lane & ~1) * 2;
+    *reinterpret_cast<f16x2*>(dst) = f16x2{h0, h1};
+    *reinterpret_cast<f16x2*>(dst + plane_bytes) = f16x2{l0, l1};
+  }
+  return ovf;
+}
+
 __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const StemFusedK P) {
   const dd3d_stem_args& a = P.a;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -114,31 +141,43 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
     const float sc = a.scale1[n_lane], bi = a.bias1[n_lane];
     __syncthreads();
     const int rb0 = 2 * oh0 - 2, cb0 = 2 * ow0 - 2;  // canvas position of the base tile's origin
-    for (int g = wave; g < SF_GB; g += SF_WAVES) {
-      const int p = min(g * 16 + n_lane, SF_NB - 1);
-      const int r = p / SF_CB, c = p - r * SF_CB;
-      const unsigned char* base = regA + (r * SF_CI + c + 2 * q4) * 8;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const auto outside = [&](int po) {
+      const int pr = po / SF_CB, pc = po - pr * SF_CB;
+      return !((unsigned)(rb0 + pr) < (unsigned)a.Hp && (unsigned)(cb0 + pc) < (unsigned)a.Wp);  // level0's zero padding
+    };
+    // two row groups per iteration: two independent accumulation chains keep the matrix pipe fed (one chain of 21 dependent MFMAs per
+    // group left it idle most of the time: 40 us per image at batch 8)
+    for (int g0 = wave; g0 < SF_GB; g0 += 2 * SF_WAVES) {
+      const int g1 = g0 + SF_WAVES;
+      const bool has1 = g1 < SF_GB;
+      const unsigned char* base[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = min((u ? (has1 ? g1 : g0) : g0) * 16 + n_lane, SF_NB - 1);
+        const int r = p / SF_CB, c = p - r * SF_CB;
+        base[u] = regA + (r * SF_CI + c + 2 * q4) * 8;
+      }
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ch = 0; ch < 7; ++ch) {
-        const unsigned char* src = base + ch * SF_CI * 8;  // filter row ch: pixels (r + ch, c + 2 q4), (.., + 1): 16 bytes, 8-byte aligned
-        const u32x2 h0 = *reinterpret_cast<const u32x2*>(src), h1 = *reinterpret_cast<const u32x2*>(src + 8);
-        const u32x2 l0 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE), l1 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE + 8);
-        acc = sf_mfma3(__builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]}), __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]}),
-                       w[ch][0], w[ch][1], acc);
-      }
-      // C/D map of the 16x16 MFMA: column (channel) = lane & 15, row (pixel of the group) = (lane >> 4) * 4 + e
+        f16x8 ahi[2], alo[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int po = g * 16 + q4 * 4 + e;
-        const int pr = po / SF_CB, pc = po - pr * SF_CB;
-        const bool inside = (unsigned)(rb0 + pr) < (unsigned)a.Hp && (unsigned)(cb0 + pc) < (unsigned)a.Wp;  // else: level0's zero padding
-        const float v = inside ? fmaxf(acc[e] * sc + bi, 0.f) : 0.f;
-        _Float16 h, l;
-        ovf |= sf_split(v, pscale, h, l);
-        *reinterpret_cast<_Float16*>(regB + po * 32 + n_lane * 2) = h;  // (po < SF_GB * 16: the padded tail of the plane absorbs it)
-        *reinterpret_cast<_Float16*>(regB + SF_B_PLANE + po * 32 + n_lane * 2) = l;
+        for (int u = 0; u < 2; ++u) {
+          const unsigned char* src = base[u] + ch * SF_CI * 8;  // filter row ch: pixels (r + ch, c + 2 q4), (.., + 1): 16 bytes, 8-byte aligned
+          const u32x2 h0 = *reinterpret_cast<const u32x2*>(src), h1 = *reinterpret_cast<const u32x2*>(src + 8);
+          const u32x2 l0 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE), l1 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE + 8);
+          ahi[u] = __builtin_bit_cast(f16x8, u32x4{h0[0], h0[1], h1[0], h1[1]});
+          alo[u] = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[u], w[ch][0], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][1], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][0], acc[u], 0, 0, 0);
       }
+      ovf |= sf_store_tile(regB, SF_B_PLANE, g0, lane, acc[0], sc, bi, pscale, outside);  // (po < SF_GB * 16: the padded tail of the plane absorbs it)
+      if (has1) ovf |= sf_store_tile(regB, SF_B_PLANE, g1, lane, acc[1], sc, bi, pscale, outside);
     }
   }
 
@@ -159,25 +198,38 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
     }
     __syncthreads();  // base tile complete; the image patch is dead
     const int r00 = 2 * oh0 - 1, c00 = 2 * ow0 - 1;
-    for (int g = wave; g < SF_G0; g += SF_WAVES) {
-      const int p = min(g * 16 + n_lane, SF_N0 - 1);
-      const int r = p / SF_C0, c = p - r * SF_C0;
-      const unsigned char* base = regB + (r * SF_CB + c) * 32;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const auto outside = [&](int po) {
+      const int pr = po / SF_C0, pc = po - pr * SF_C0;
+      return !((unsigned)(r00 + pr) < (unsigned)a.Hp && (unsigned)(c00 + pc) < (unsigned)a.Wp);
+    };
+    for (int g0 = wave; g0 < SF_G0; g0 += 2 * SF_WAVES) {
+      const int g1 = g0 + SF_WAVES;
+      const bool has1 = g1 < SF_G0;
+      const unsigned char* base[2];
 #pragma unroll
-      for (int ch = 0; ch < 5; ++ch)
-        acc = sf_mfma3(*reinterpret_cast<const f16x8*>(base + aoff[ch]), *reinterpret_cast<const f16x8*>(base + SF_B_PLANE + aoff[ch]), w[ch][0], w[ch][1], acc);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int po = g * 16 + q4 * 4 + e;
-        const int pr = po / SF_C0, pc = po - pr * SF_C0;
-        const bool inside = (unsigned)(r00 + pr) < (unsigned)a.Hp && (unsigned)(c00 + pc) < (unsigned)a.Wp;
-        const float v = inside ? fmaxf(acc[e] * sc + bi, 0.f) : 0.f;
-        _Float16 h, l;
-        ovf |= sf_split(v, pscale, h, l);
-        *reinterpret_cast<_Float16*>(regA + po * 32 + n_lane * 2) = h;
-        *reinterpret_cast<_Float16*>(regA + SF_0_PLANE + po * 32 + n_lane * 2) = l;
+      for (int u = 0; u < 2; ++u) {
+        const int p = min((u ? (has1 ? g1 : g0) : g0) * 16 + n_lane, SF_N0 - 1);
+        const int r = p / SF_C0, c = p - r * SF_C0;
+        base[u] = regB + (r * SF_CB + c) * 32;
       }
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ch = 0; ch < 5; ++ch) {
+        f16x8 ahi[2], alo[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ahi[u] = *reinterpret_cast<const f16x8*>(base[u] + aoff[ch]);
+          alo[u] = *reinterpret_cast<const f16x8*>(base[u] + SF_B_PLANE + aoff[ch]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[u], w[ch][0], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][1], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][0], acc[u], 0, 0, 0);
+      }
+      ovf |= sf_store_tile(regA, SF_0_PLANE, g0, lane, acc[0], sc, bi, pscale, outside);
+      if (has1) ovf |= sf_store_tile(regA, SF_0_PLANE, g1, lane, acc[1], sc, bi, pscale, outside);
     }
   }
 
