@@ -20,7 +20,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NSET = 4;  // operand sets a wave rotates through (register resident)
 
-template <int WAVES>
+// ORDER 0: product-major (the conv kernels' order: lo*hi for all four blocks, then hi*lo, then hi*hi; the A operand changes every 2 MFMAs,
+//          the B operand every MFMA);  1: A-operand-major (A hi of row i meets B hi 0, B hi 1, B lo 0, B lo 1 back to back, then A lo of row i
+//          meets B hi 0, B hi 1: one operand port holds still for 4 / 2 instructions);  2: B-operand-major (the mirror image)
+template <int WAVES, int ORDER>
 __global__ __launch_bounds__(64 * WAVES) void mfma_loop(const f16x8* __restrict__ ops, int iters, float* sink) {
   // per lane: NSET x (A hi0, A hi1, A lo0, A lo1, B hi0, B hi1, B lo0, B lo1)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,6 +47,30 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_loop(const f16x8* __restrict_
     for (int s = 0; s < NSET; ++s) {
       // one "16-k chunk" of the f16x2 tower loop: 3 products x (2 x 2) accumulator blocks = 12 MFMAs
       // planes: a[s][0..1] = hi of rows 0/1, a[s][2..3] = lo;  b likewise
+      if constexpr (ORDER == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][i], b[s][2 + j], acc[i][j], 0, 0, 0);  // hi * lo
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);  // hi * hi
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][2 + i], b[s][j], acc[i][j], 0, 0, 0);  // lo * hi
+        }
+        continue;
+      }
+      if constexpr (ORDER == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][2 + i], b[s][j], acc[i][j], 0, 0, 0);  // lo * hi
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);  // hi * hi
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][i], b[s][2 + j], acc[i][j], 0, 0, 0);  // hi * lo
+        }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -84,7 +111,7 @@ static float gauss() {
   return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
 }
 
-template <int WAVES>
+template <int WAVES, int ORDER = 0>
 static void run(const char* name, unsigned short* host, long n_half, unsigned short* dev, int blocks, int iters, float* sink) {
   hipMemcpy(dev, host, n_half * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1;
@@ -93,7 +120,7 @@ static void run(const char* name, unsigned short* host, long n_half, unsigned sh
   float best = 1e30f, worst = 0.f;
   for (int rep = 0; rep < 6; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL(mfma_loop<WAVES>, dim3(blocks), dim3(64 * WAVES), 0, 0, (const f16x8*)dev, iters, sink);
+    hipLaunchKernelGGL((mfma_loop<WAVES, ORDER>), dim3(blocks), dim3(64 * WAVES), 0, 0, (const f16x8*)dev, iters, sink);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -156,5 +183,10 @@ int main(int argc, char** argv) {
       for (int e = 0; e < 8; ++e)
         if (!(q & 2) && (rand() & 1)) host[(t * 8 + q) * 8 + e] = 0, host[(t * 8 + q + 2) * 8 + e] = 0;
   go("f16x2 planes, 50% of the activations zero");
+  if (waves == 8) {  // instruction order: does holding one operand port still between consecutive MFMAs change the power-limited rate?
+    run<8, 1>("  same data, A-operand-major order", host, n_half, dev, blocks, iters, sink);
+    run<8, 2>("  same data, B-operand-major order", host, n_half, dev, blocks, iters, sink);
+    run<8, 0>("  same data, product-major order (again)", host, n_half, dev, blocks, iters, sink);
+  }
   return 0;
 }
