@@ -55,6 +55,8 @@ def main():
         print(f"{exp:18s} math={os.environ.get('DD3D_MATH', 'f16x2'):7s} B={B} {H}x{W}: {ms:8.3f} ms/forward = {B / ms * 1e3:7.1f} img/s, {2 * gmac / ms:7.1f} TFLOP/s, dets {[len(o['instances']) for o in out]}, "
               f"plan build {t_build:.1f} s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB, ops {len(plan.ops)}", flush=True)
         del model, plan, out
+        import gc
+        gc.collect()  # (plans and their ops reference each other: without a collection the previous case's buffers inflate the next peak)
         torch.cuda.empty_cache()
 
 
