@@ -111,7 +111,7 @@ def main():
     for _ in range(20):
         slot = runner.step()
     torch.cuda.synchronize()
-    slot.inputs, slot.image_sizes = stream[0], [(H, W)] * B
+    slot.requests[0] = (stream[0], [(H, W)] * B)  # (step() runs on resident inputs: name them for collect())
     last = runner.result(slot)
     ok &= all(torch.equal(o["instances"].scores_3d, q["instances"].scores_3d) for o, q in zip(last, ref[0]))
     print(f"pipeline check ({'nccl exchange' if use_nccl else 'single rank'}, {depth} slots / {streams} compute streams): ok={bool(ok)} detections={n_det}")
