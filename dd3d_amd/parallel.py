@@ -186,10 +186,11 @@ class PipelinedForward:
 
     Every slot's graphs are replayed once at construction, so the first timed step of a caller does not pay a first-launch cost.
 
-    Numeric guard: `result()` raises FloatingPointError when the default f16x2 arithmetic met an activation outside the half range
-    (dd3d_amd.engine.PlanBase.check_status); unlike `DD3D.forward` the runner does not rebuild itself on the three-term arithmetic --
-    steps of several slots (and, with several ranks, a collective per step) are in flight.  Serve a model whose activation range has
-    not been validated with `model.math = "bf16x3"`; with several ranks every rank must treat the error as fatal for the run."""
+    Numeric guard (dd3d_amd.engine.PlanBase.check_status): when the default f16x2 arithmetic meets an activation outside the half pair's
+    range, `result()` -- with ONE rank and a model on the default arithmetic -- drains the pipeline, rebuilds every slot on the three-term
+    bf16 split, re-runs the requests in flight and returns (what `DD3D.forward` does for a single forward).  With several ranks every step
+    holds a collective and a rank cannot change course alone: the FloatingPointError propagates and is fatal for the run on every rank;
+    serve a model whose activation range has not been validated with `model.math = "bf16x3"`."""
     def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1, microbatch=1):
         from dd3d_amd.engine import ForwardPlan
         assert depth >= 1 and compute_streams >= 1 and microbatch >= 1
@@ -203,8 +204,26 @@ class PipelinedForward:
         self.compute_streams = [torch.cuda.Stream() for _ in range(compute_streams)]
         self.post_stream = torch.cuda.Stream()
         self.slots = []
-        for _ in range(depth):
-            p = ForwardPlan(model, B * self.microbatch, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
+        for i in range(depth):
+            slot = type("Slot", (), {})()
+            slot.pre_done, slot.post_done, slot.released = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            slot.post_done.record()
+            slot.released.record()
+            slot.requests = [None] * self.microbatch  # (inputs, image_sizes) of the requests staged into the slot
+            slot.fill, slot.enqueued, slot.generation = 0, True, 0
+            slot.compute_stream = self.compute_streams[i % compute_streams]
+            self.slots.append(slot)
+        self._geometry = (Hp, Wp)
+        self._build_plans()
+        self._next = 0
+        self._filling = None  # the slot requests are being staged into
+
+    def _build_plans(self):
+        """(Re)build every slot's launch plan and pair of graph halves for the model's current arithmetic, and replay them once."""
+        from dd3d_amd.engine import ForwardPlan
+        Hp, Wp = self._geometry
+        for slot in self.slots:
+            p = ForwardPlan(self.model, self.B * self.microbatch, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
             p.launch()  # warm-up outside capture
             torch.cuda.synchronize()
             pre, post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -212,15 +231,7 @@ class PipelinedForward:
                 p.launch(0, p.num_pre_nms_ops)
             with torch.cuda.graph(post):
                 p.launch(p.num_pre_nms_ops)
-            slot = type("Slot", (), {})()
             slot.plan, slot.pre_graph, slot.post_graph = p, pre, post
-            slot.pre_done, slot.post_done, slot.released = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-            slot.post_done.record()
-            slot.released.record()
-            slot.requests = [None] * self.microbatch  # (inputs, image_sizes) of the requests staged into the slot
-            slot.fill, slot.enqueued, slot.generation = 0, True, 0
-            slot.compute_stream = self.compute_streams[len(self.slots) % compute_streams]
-            self.slots.append(slot)
         torch.cuda.synchronize()
         # first replay of every slot's graphs (a hipGraph's first launch uploads it: ~10x a steady replay), on the streams they will use;
         # a collective is NOT issued here (the ranks would have to agree on it) -- the post half runs on the zeroed record
@@ -236,8 +247,32 @@ class PipelinedForward:
         for slot in self.slots:
             slot.plan.status.zero_()
         self.plan = self.slots[0].plan
-        self._next = 0
-        self._filling = None  # the slot requests are being staged into
+
+    def _fall_back(self, err):
+        """The range guard of the default f16x2 arithmetic fired on a request (DD3D.forward's behaviour, for the runner): with ONE rank and
+        a model on the default arithmetic, drain the pipeline, rebuild every slot on the three-term bf16 split and re-run the requests that
+        were in flight (their inputs are still referenced by their slots).  Several ranks: every step holds a collective, a rank cannot
+        change course alone -- the error propagates (serve such a model with math='bf16x3')."""
+        from dd3d_amd import hip
+        if self.world > 1 or self.model.math is not None or self.plan.math != hip.MATH_F16X2:
+            raise err
+        import warnings
+        warnings.warn(f"dd3d_amd: {err}; switching this model and its pipeline to math='bf16x3'")
+        for cs in self.compute_streams:
+            cs.synchronize()
+        self.post_stream.synchronize()
+        self.model.math = "bf16x3"
+        self.model._plans.clear()
+        self._build_plans()
+        for slot in self.slots:
+            staged = [(j, r) for j, r in enumerate(slot.requests[:slot.fill]) if r is not None]
+            if slot.generation == 0 or not staged:
+                continue
+            with torch.cuda.stream(slot.compute_stream):
+                for j, (inputs, _) in staged:
+                    self.model.stage_inputs(inputs, plan=slot.plan, first=j * self.B, partial=True)
+            if slot.enqueued:
+                self._enqueue(slot)
 
     def _enqueue(self, slot):
         cs, ps = slot.compute_stream, self.post_stream
@@ -316,7 +351,12 @@ class PipelinedForward:
             self.flush()
         slot.post_done.synchronize()
         inputs, image_sizes = slot.requests[j]
-        out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
+        try:
+            out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
+        except FloatingPointError as e:
+            self._fall_back(e)  # (raises unless this is one rank on the default arithmetic)
+            slot.post_done.synchronize()
+            out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
         slot.released.record()  # the copies out of the detection buffer are enqueued: later steps of this slot order after them
         return out
 

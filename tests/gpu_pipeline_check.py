@@ -63,10 +63,50 @@ def microbatch_main():
     assert ok
 
 
+def fallback_main():
+    """The range guard inside the pipeline: with an absurd plane scale every activation of the default f16x2 arithmetic overflows; a
+    single-rank runner on the default arithmetic must drain, rebuild its slots on bf16x3, re-run the requests in flight (here: one full
+    slot and one partly filled slot) and return what a bf16x3 model returns."""
+    import warnings
+    import torch
+    os.environ["DD3D_F16_ACT_SCALE"] = str(2**22)
+    os.environ.pop("DD3D_MATH", None)
+    from dd3d_amd import build_model, get_cfg
+    from dd3d_amd.parallel import PipelinedForward
+    from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
+    torch.cuda.set_device(0)
+    cfg = get_cfg("dd3d_kitti_dla34")
+    model = build_model(cfg)
+    model.load_state_dict(make_state_dict(model, calib=load_calib("dla34_kitti")))
+    H, W, M = 128, 256, 2
+    stream = [make_inputs(1, H, W, seed=40 + 3 * i) for i in range(3)]
+    ref_model = build_model(cfg)
+    ref_model.load_state_dict(model.state_dict())
+    ref_model.math = "bf16x3"
+    ref = [ref_model(x * M)[:1] for x in stream]
+    runner = PipelinedForward(model, 1, H, W, depth=2, compute_streams=2, microbatch=M)
+    handles = [runner.submit(x) for x in stream]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        outs = [runner.result(h) for h in handles]
+    ok = any("bf16x3" in str(x.message) for x in w) and model.math == "bf16x3"
+    for out, r in zip(outs, ref):
+        a, b = out[0]["instances"], r[0]["instances"]
+        ok &= len(a) == len(b) and len(a) > 0 and torch.equal(a.pred_classes, b.pred_classes)
+        ok &= torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores_3d, b.scores_3d)
+    # ... and the rebuilt pipeline keeps serving
+    more = runner.result(runner.submit(stream[0]))
+    ok &= torch.equal(more[0]["instances"].scores_3d, ref[0][0]["instances"].scores_3d)
+    print(f"pipeline check (range guard -> bf16x3 fallback inside the runner): ok={bool(ok)}")
+    assert ok
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else ""
     if mode == "microbatch":
         return microbatch_main()
+    if mode == "fallback":
+        return fallback_main()
     use_nccl = mode == "nccl"
     depth, streams = (4, 4) if mode == "streams" else (2, 1)  # "streams": the bench default, consecutive steps share the chip
     from dd3d_amd import build_model, get_cfg

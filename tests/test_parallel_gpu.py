@@ -33,7 +33,7 @@ def test_rccl_transport_single_rank(hiplib):
     assert "rccl check: ok=True" in r.stdout
 
 
-@pytest.mark.parametrize("mode", ["", "nccl", "streams", "microbatch"])
+@pytest.mark.parametrize("mode", ["", "nccl", "streams", "microbatch", "fallback"])
 def test_pipelined_forward_equals_stepwise(hiplib, mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "tests", "gpu_pipeline_check.py")] + ([mode] if mode else [])
