@@ -358,6 +358,19 @@ def test_cabi_argument_validation_without_a_gpu(hiplib):
     assert L.dd3d_ese_nhwc(None, None, None, None, None, None, None, 1, 4, 64, 64, 0, 64, 1, None) != 0 and "bad arguments" in err()
     with pytest.raises(RuntimeError, match="null pointer"):
         hip.check(L.dd3d_format_boxes3d(None, None, None, None, 5, None), "format_boxes3d")
+    # round 3 entry points and arguments
+    st = hip.StemArgs()
+    assert L.dd3d_stem_fused_f16x2(C.byref(st), None) != 0 and "dd3d_stem_fused_f16x2: null pointer" in err()
+    assert L.dd3d_mfma_probe(None, 256, 10, None, None) != 0 and "dd3d_mfma_probe: bad arguments" in err()
+    keep = [C.create_string_buffer(64) for _ in range(10)]  # (never dereferenced: the argument checks come first)
+    n = hip.NmsArgs()
+    n.G, n.num_levels, n.topk, n.det_cap = 1, 5, 100, 256
+    for f, b in zip(("cand", "counts", "out_size", "sort_idx", "sbox", "scls", "mask", "nvalid", "det", "det_count"), keep):
+        setattr(n, f, C.addressof(b))
+    n.img_per_rec, n.rec_stride = 3, 0  # records without a stride
+    assert L.dd3d_nms_finalize(C.byref(n), None) != 0 and "record addressing" in err()
+    n.img_per_rec, n.rec_stride, n.img_first = 3, 1000, -1
+    assert L.dd3d_nms_finalize(C.byref(n), None) != 0 and "record addressing" in err()
 
 
 def test_plan_cache_is_bounded_lru(kitti_dla34, monkeypatch):
