@@ -333,6 +333,35 @@ extern "C" int dd3d_ese_nhwc(const float* x, const float* identity, float* out, 
   return check_launch("scale_add_nhwc_kernel");
 }
 
+namespace dd3d {
+// The two halves of the f16x2 range guard folded into two words of a rank's exchange record, so that after the all_gather every rank
+// sees every rank's verdict and all of them act on the same step:  out[0] = *status (DD3D_STATUS_* bits),  out[1] = 1 when some watched
+// launch stored a nonzero sampled maximum below `floor` (maxima: amax[launch][16 sub-maxima, 32 floats apart]).
+__global__ __launch_bounds__(256) void fold_range_flags_kernel(const int32_t* status, const float* amax, int n, float floor, int32_t* out) {
+  __shared__ int low;
+  if (threadIdx.x == 0) low = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, amax[((long)i * 16 + j) * 32]);
+    if (m > 0.f && m < floor) low = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = status ? *status : 0;
+    out[1] = low;
+  }
+}
+}  // namespace dd3d
+
+extern "C" int dd3d_fold_range_flags(const int32_t* status, const float* amax, int32_t n_launches, float floor, int32_t* out, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(out && n_launches >= 0 && (n_launches == 0 || amax), "dd3d_fold_range_flags: bad arguments");
+  hipLaunchKernelGGL(fold_range_flags_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), status, amax, n_launches, floor, out);
+  return check_launch("fold_range_flags_kernel");
+}
+
 extern "C" int dd3d_invert_intrinsics(const float* K, float* inv_K, int32_t B, void* stream) {
   using namespace dd3d;
   DD3D_REQUIRE(K && inv_K && B > 0, "dd3d_invert_intrinsics: bad arguments");

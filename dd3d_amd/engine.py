@@ -1458,7 +1458,8 @@ class ForwardPlan(PlanBase):
         n_c, n_k, n_o, n_i, n_p = pad4(B * hip.CAND_FIELDS * NS), pad4(B * L), pad4(B * 4), pad4(B * 9), pad4(B * 7)
         self.record_fields = dict(cand=(0, hip.CAND_FIELDS * NS), counts=(n_c, L), outsize=(n_c + n_k, 4), inv_K=(n_c + n_k + n_o, 9),
                                   pose=(n_c + n_k + n_o + n_i, 7))  # name -> (word offset in a record, words per image)
-        self.record_len = n_c + n_k + n_o + n_i + n_p
+        self.flags_off = n_c + n_k + n_o + n_i + n_p  # 4 words per RECORD (not per image): the rank's range-guard verdict (below)
+        self.record_len = self.flags_off + 4
 
         def views(rec):
             f = self.record_fields
@@ -1479,6 +1480,16 @@ class ForwardPlan(PlanBase):
         a.cand, a.counts, a.npass = self.cand.data_ptr(), self.counts.data_ptr(), self.npass.data_ptr()
         self.select_args = a
         self.ops.append(CallOp(lambda lib, st: hip.check(lib.dd3d_fcos_select_decode(C.byref(a), st), "select_decode"), "select_decode"))
+        if self.exchange and self.math == hip.MATH_F16X2 and not self.dry_run:
+            # the rank's range-guard verdict (status bits, underflow flag) rides in its record: after the all_gather every rank sees every
+            # rank's and all of them raise / fall back on the SAME step (a rank that raised alone would leave its peers in the next collective)
+            flags = self.record[self.flags_off:self.flags_off + 4]
+
+            def _flags(lib, st, flags=flags):
+                hip.check(lib.dd3d_fold_range_flags(self.status.data_ptr(), self.amax.data_ptr(), len(self.amax_names), float(self.AMAX_FLOOR),
+                                                    flags.data_ptr(), st), "fold_range_flags")
+
+            self.ops.append(CallOp(_flags, "range_flags", dict(kind="range_flags")))
         self.num_pre_nms_ops = len(self.ops)
 
         # The exchange (dd3d_amd.parallel): every rank's record is all-gathered into `gathered` [W x record]; each rank then finalises
@@ -1595,6 +1606,21 @@ class ForwardPlan(PlanBase):
             if bev_sample:
                 stage(self.in_group, int(model.max_num_dets_per_sample), True, False, "nusc_sample_aggregate")
                 self.has_global_boxes = True
+
+    def check_status(self):
+        """With the exchange, the verdict is the OR over all ranks' records (delivered by the step's all_gather), so that every rank raises on
+        the same step; the local words are cleared as well."""
+        if not (self.exchange and self.math == hip.MATH_F16X2 and self.gathered is not None and not self.dry_run):
+            return super().check_status()
+        fl = self.gathered.view(self.world_size, self.record_len)[:, self.flags_off:self.flags_off + 2].view(torch.int32).cpu()
+        over = [r for r in range(self.world_size) if int(fl[r, 0]) & hip.STATUS_F16_OVERFLOW]
+        under = [r for r in range(self.world_size) if int(fl[r, 1])]
+        if over or under:
+            self.status.zero_()
+            what = (f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}) on "
+                    f"rank(s) {over}" if over else
+                    f"convolution outputs sit below the half range's useful part on rank(s) {under} (absolute floor {2.0**-25 / self.act_scale:.2g})")
+            raise FloatingPointError(f"{what}: run this model with math='bf16x3' (every rank sees this verdict on the same step)")
 
     def gather_pairs(self):
         """(local record, gathered buffer [W x record]): the ONE tensor pair the multi-GPU step all-gathers between select/decode and

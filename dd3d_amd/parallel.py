@@ -116,11 +116,15 @@ class DistributedForward:
         # one rank: the whole forward is one hipGraph, unless `force_exchange` keeps the two-phase step (RCCL check on one GPU);
         # force_exchange=False with several ranks drops the collective (per-image results only; never with camera_sharded)
         self.exchange = (self.world > 1 and force_exchange is not False) or bool(force_exchange) or self.camera_sharded
-        model.use_graph = use_graph
-        self.plan = p = model.get_plan(B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange, camera_sharded=camera_sharded)
-        self.B = B
+        self.B, self._geometry, self.use_graph = B, (Hp, Wp), use_graph
+        self._build()
+
+    def _build(self):
+        model, (Hp, Wp) = self.model, self._geometry
+        model.use_graph = self.use_graph
+        self.plan = p = model.get_plan(self.B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange, camera_sharded=self.camera_sharded)
         self.pre_graph = self.post_graph = None
-        if use_graph and self.exchange:
+        if self.use_graph and self.exchange:
             # the collective sits between two captured halves
             p.launch()
             torch.cuda.synchronize()
@@ -150,15 +154,36 @@ class DistributedForward:
         `padded_inference_shard`.  A batch shorter than the plan's (the last batch of a shard, or none at all) is completed with the
         images the plan's buffers already hold -- the step still runs in full -- and only the given images are returned; `valid`
         (list of bool, from padded_inference_shard) drops padding images from the result as well."""
+        try:
+            return self._forward(batched_inputs, valid)
+        except FloatingPointError as e:
+            # The range guard of the default f16x2 arithmetic.  With the exchange every rank read the SAME verdict out of the gathered records
+            # (engine.ForwardPlan.check_status), so all ranks arrive here on the same step and repeat it together on the three-term split.
+            from dd3d_amd import hip
+            if self.model.math is not None or self.plan.math != hip.MATH_F16X2 or (self.world > 1 and not self.exchange):
+                raise
+            import warnings
+            warnings.warn(f"dd3d_amd: {e}; switching this model to math='bf16x3'")
+            torch.cuda.synchronize()
+            self.model.math = "bf16x3"
+            self.model._plans.clear()
+            self._build()
+            return self._forward(batched_inputs, valid)
+
+    def _forward(self, batched_inputs, valid):
         image_sizes = []
         if len(batched_inputs):
             _, image_sizes = self.model.stage_inputs(batched_inputs, plan=self.plan, partial=len(batched_inputs) < self.plan.B)
         self.step()
         if self.camera_sharded:
             # results belong to the OWNER of a sample, not to the rank that decoded a camera: [(global image index, {"instances"})]
+            if self.plan.G == 0:
+                torch.cuda.current_stream().synchronize()
+                self.plan.check_status()  # (a rank that owns no sample still takes part in the verdict)
             return self.model.collect_owned(self.plan)
         if not len(batched_inputs):
             torch.cuda.current_stream().synchronize()
+            self.plan.check_status()
             return []
         out = self.model.collect(self.plan, batched_inputs, image_sizes)
         if valid is not None:
@@ -187,10 +212,9 @@ class PipelinedForward:
     Every slot's graphs are replayed once at construction, so the first timed step of a caller does not pay a first-launch cost.
 
     Numeric guard (dd3d_amd.engine.PlanBase.check_status): when the default f16x2 arithmetic meets an activation outside the half pair's
-    range, `result()` -- with ONE rank and a model on the default arithmetic -- drains the pipeline, rebuilds every slot on the three-term
-    bf16 split, re-runs the requests in flight and returns (what `DD3D.forward` does for a single forward).  With several ranks every step
-    holds a collective and a rank cannot change course alone: the FloatingPointError propagates and is fatal for the run on every rank;
-    serve a model whose activation range has not been validated with `model.math = "bf16x3"`."""
+    range, `result()` -- on a model on the default arithmetic -- drains the pipeline, rebuilds every slot on the three-term bf16 split,
+    re-runs the requests in flight and returns (what `DD3D.forward` does for a single forward).  With several ranks the verdict of every
+    rank travels in the exchanged records, so all ranks take this path for the same slot run."""
     def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1, microbatch=1):
         from dd3d_amd.engine import ForwardPlan
         assert depth >= 1 and compute_streams >= 1 and microbatch >= 1
@@ -249,12 +273,13 @@ class PipelinedForward:
         self.plan = self.slots[0].plan
 
     def _fall_back(self, err):
-        """The range guard of the default f16x2 arithmetic fired on a request (DD3D.forward's behaviour, for the runner): with ONE rank and
-        a model on the default arithmetic, drain the pipeline, rebuild every slot on the three-term bf16 split and re-run the requests that
-        were in flight (their inputs are still referenced by their slots).  Several ranks: every step holds a collective, a rank cannot
-        change course alone -- the error propagates (serve such a model with math='bf16x3')."""
+        """The range guard of the default f16x2 arithmetic fired on a request (DD3D.forward's behaviour, for the runner): on a model on the
+        default arithmetic, drain the pipeline, rebuild every slot on the three-term bf16 split and re-run the requests that were in flight
+        (their inputs are still referenced by their slots).  Several ranks: the verdict travels in the exchanged records
+        (engine.ForwardPlan.check_status), so every rank raises for the same slot run and all of them rebuild and re-run together, issuing
+        the same collectives in the same order -- provided every rank collects its results in the same order, as a data-parallel loop does."""
         from dd3d_amd import hip
-        if self.world > 1 or self.model.math is not None or self.plan.math != hip.MATH_F16X2:
+        if self.model.math is not None or self.plan.math != hip.MATH_F16X2:
             raise err
         import warnings
         warnings.warn(f"dd3d_amd: {err}; switching this model and its pipeline to math='bf16x3'")

@@ -128,7 +128,77 @@ def _camera_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _guard_worker(rank, world, port, ret):
+    """The f16x2 range guard across ranks: rank 1's weights push one activation past the half range (same network function: the
+    neighbouring norms absorb the factor), rank 0's do not.  The verdict travels in the exchanged records, so BOTH ranks must fall back to
+    bf16x3 on the same step -- in the step-by-step runner and in the pipelined one -- and return what a bf16x3 model returns."""
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.pop("DD3D_MATH", None)
+    from dd3d_amd import build_model, get_cfg
+    from dd3d_amd.parallel import DistributedForward, PipelinedForward, init_distributed
+    from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
+    init_distributed(backend="gloo")
+    cfg = get_cfg("dd3d_kitti_dla34")
+    sd = make_state_dict(build_model(cfg), calib=load_calib("dla34_kitti"))
+    if rank == 1:
+        a, b, f = "backbone.bottom_up.level3.tree1.tree1.conv1.norm", "backbone.bottom_up.level3.tree1.tree1.conv2.norm", 1.0e4
+        sd = {k: v.clone() for k, v in sd.items()}
+        sd[a + ".weight"] *= f
+        sd[a + ".bias"] *= f
+        sd[b + ".running_mean"] *= f
+        sd[b + ".running_var"] *= f * f
+    B, H, W = 2, 128, 256
+    ref_model = build_model(cfg)
+    ref_model.load_state_dict(sd)
+    ref_model.math = "bf16x3"
+    bad = []
+
+    def same(out, ref, tag):
+        for o, r in zip(out, ref):
+            x, y = o["instances"], r["instances"]
+            if not (len(x) == len(y) > 0 and torch.equal(x.pred_classes, y.pred_classes) and torch.equal(x.pred_boxes.tensor, y.pred_boxes.tensor)
+                    and torch.equal(x.scores_3d, y.scores_3d)):
+                bad.append(f"{tag}: results differ from the bf16x3 model ({len(x)} vs {len(y)} detections)")
+
+    for kind in ("step", "pipelined"):
+        model = build_model(cfg)
+        model.load_state_dict(sd)
+        inputs = [make_inputs(B, H, W, seed=70 + 10 * i + rank * B) for i in range(2)]
+        refs = [ref_model(x) for x in inputs]
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            if kind == "step":
+                runner = DistributedForward(model, B, H, W, use_graph=True)
+                outs = [runner.forward(x) for x in inputs]
+            else:
+                runner = PipelinedForward(model, B, H, W, depth=2)
+                handles = [runner.submit(x) for x in inputs]
+                outs = [runner.result(h) for h in handles]
+        if not (any("bf16x3" in str(x.message) for x in w) and model.math == "bf16x3"):
+            bad.append(f"{kind}: rank {rank} did not fall back (math={model.math}, warnings={[str(x.message)[:60] for x in w]})")
+        for i, (o, r) in enumerate(zip(outs, refs)):
+            same(o, r, f"{kind} step {i}")
+        dist.barrier()
+    if bad:
+        print(f"[rank {rank}]", *bad[:8], sep="\n  ", flush=True)
+    ret[rank] = not bad
+    dist.destroy_process_group()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "guard":
+        import __graft_entry__ as g
+        g.build()
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ret = mp.Manager().dict()
+        mp.spawn(_guard_worker, args=(2, port, ret), nprocs=2, join=True)
+        print("range-guard consensus check:", dict(ret))
+        assert all(ret.get(r) for r in range(2)), dict(ret)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cameras":
         import __graft_entry__ as g
         g.build()

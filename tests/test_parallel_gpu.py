@@ -26,6 +26,15 @@ def test_camera_sharded_sample_on_two_ranks_matches_single_rank(hiplib):
     assert "camera-sharded check: {" in r.stdout and "False" not in r.stdout.split("camera-sharded check:")[-1]
 
 
+def test_range_guard_verdict_is_shared_by_all_ranks(hiplib):
+    """Only rank 1's activations leave the half range; both ranks must fall back to bf16x3 on the same step (the verdict rides in the
+    exchanged records), in DistributedForward and in PipelinedForward, and return the bf16x3 model's detections."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_dist_check.py"), "guard"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    assert "range-guard consensus check: {" in r.stdout and "False" not in r.stdout.split("range-guard consensus check:")[-1]
+
+
 def test_rccl_transport_single_rank(hiplib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_rccl_check.py")], capture_output=True, text=True, timeout=900)
