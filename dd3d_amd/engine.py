@@ -1610,7 +1610,8 @@ class ForwardPlan(PlanBase):
     def check_status(self):
         """With the exchange, the verdict is the OR over all ranks' records (delivered by the step's all_gather), so that every rank raises on
         the same step; the local words are cleared as well."""
-        if not (self.exchange and self.math == hip.MATH_F16X2 and self.gathered is not None and not self.dry_run):
+        # (DenseDepthPlan shares this class without the post-processing half: no exchange, no gathered buffer)
+        if not (getattr(self, "exchange", False) and self.math == hip.MATH_F16X2 and getattr(self, "gathered", None) is not None and not self.dry_run):
             return super().check_status()
         fl = self.gathered.view(self.world_size, self.record_len)[:, self.flags_off:self.flags_off + 2].view(torch.int32).cpu()
         over = [r for r in range(self.world_size) if int(fl[r, 0]) & hip.STATUS_F16_OVERFLOW]
