@@ -178,7 +178,8 @@ __device__ __forceinline__ void split_pack(float x0, float x1, unsigned (&w)[Pla
 }
 
 // MODE == DD3D_MATH_F32: f32 NHWC store only (the kernel's math mode has no planes).
-template <int TM, int TN, int MODE = DD3D_MATH_F32>
+// WM x WN: the block's wave grid (only the range-guard sample needs it; 1 x 1 = every wave is "the" wave of its block).
+template <int TM, int TN, int MODE = DD3D_MATH_F32, int WM = 1, int WN = 1>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0,
                                               int wm, int wn, int lane) {
   const gcfp g_res = as_g(s.res);
@@ -221,8 +222,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
     const float pscale = a.out_plane_scale;
     int ovf = 0;
     float amx = 0.f;  // F16X2: largest |scaled value| this lane stores as planes (tracked by the block's reporting wave only, see below)
-    const int bidl = blockIdx.x + blockIdx.y * gridDim.x;
-    const bool report = Planes<MODE>::F16 && a.amax != nullptr && (int)(threadIdx.x >> 6) == bidl % (int)(blockDim.x >> 6);  // wave-uniform
+    // The reporting wave of the block: chosen from the TILE's coordinates (not the block index: with split-K the block that finishes a tile
+    // is whichever slice arrives last), rotating over the wave grid, and moved to wave row / column 0 when the chosen one holds only rows
+    // >= M or columns >= N (row m0 and column n0 of a tile are always real) -- wave-uniform.
+    const int seed = m0 / (TM * 32 * WM) + n0 / (TN * 32 * WN);
+    int wm_sel = seed % WM, wn_sel = (seed / WM) % WN;
+    if (m0 + wm_sel * TM * 32 >= s.M) wm_sel = 0;
+    if (n0 + wn_sel * TN * 32 >= nlim) wn_sel = 0;
+    const bool report = Planes<MODE>::F16 && a.amax != nullptr && wm == wm_sel && wn == wn_sel;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nb = n0 + (wn * TN + j) * 32;  // wave-uniform: first channel of this column block
@@ -282,15 +289,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
     }
     if constexpr (Planes<MODE>::F16) {
       if (ovf && a.status) atomicOr(a.status, DD3D_STATUS_F16_OVERFLOW);  // (NaN / inf inputs trip it as well)
-      // Underflow side of the range guard: a SAMPLE of the stored outputs -- one wave tile per block, the wave rotating with the block
-      // index so that every (row, column) sub-tile position is covered -- is folded into one of 16 per-launch maxima (128 B apart:
+      // Underflow side of the range guard: a SAMPLE of the stored outputs -- one wave tile per block, the wave rotating with the tile's
+      // coordinates so that every (row, column) sub-tile position is covered -- is folded into one of 16 per-launch maxima (128 B apart:
       // different L2 lines).  Every wave of every block reporting into ONE address cost 16 % of the whole forward (2016 same-address
       // atomics at the end of a 100 us launch, measured: profiles/r03g_amax_ab.txt); the sample is a lower bound of the true maximum,
       // so a tensor that passes the guard on it passes on all of its entries.
       if (report) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) amx = fmaxf(amx, __shfl_xor(amx, d, 64));
-        if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.amax + (bidl & 15) * 32), __float_as_uint(amx));
+        if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.amax + (seed & 15) * 32), __float_as_uint(amx));
       }
     }
   }

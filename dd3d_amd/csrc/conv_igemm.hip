@@ -739,7 +739,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
   if constexpr (SK) {
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
-  conv_epilogue<TM, TN, DD3D_MATH_BF16X3>(a, s, acc, m0, n0, wm, wn, lane);  // f32 NHWC and / or split planes for the next conv
+  conv_epilogue<TM, TN, DD3D_MATH_BF16X3, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);  // f32 NHWC and / or split planes for the next conv
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if constexpr (SK) {
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
-  conv_epilogue<TM, TN, MODE>(a, s, acc, m0, n0, wm, wn, lane);
+  conv_epilogue<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
