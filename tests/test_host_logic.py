@@ -411,3 +411,33 @@ def test_collect_reports_a_bev_sorter_overflow(kitti_dla34):
     ok = type("P", (), dict(det_count=torch.tensor([3, 7], dtype=torch.int32), det_cap=256, check_status=lambda self: None))()
     counts, n_max = model._counts(ok)
     assert counts.tolist() == [3, 7] and n_max == 7
+
+
+@pytest.mark.parametrize("cin,cin_p,k,n", [(3, 4, 7, 16), (16, 16, 3, 16), (16, 16, 3, 32)])
+def test_pack_smallc_f16x2_k_order_and_split(cin, cin_p, k, n):
+    """Filters of the one-launch stem (include/dd3d_hip.h::dd3d_stem_args): [chunk][plane hi, lo][Npad16][32] halves of w[n] * s[n] in the
+    k order of the patch kernels -- Cin 4: k = (dh * 8 + dw) * 4 + c (one chunk per filter row, tap slots >= KW and channel 3 zero);
+    Cin 16: k = (dh * KW + dw) * 16 + c (two taps per chunk, the odd tenth tap zero) -- hi + lo carrying 22 bits, s[n] a power of two."""
+    import torch
+    from dd3d_amd.engine import pack_smallc_f16x2
+    g = torch.Generator().manual_seed(k * 100 + n)
+    w = torch.randn(n, cin, k, k, generator=g) * 0.2
+    planes, s = pack_smallc_f16x2(w, cin_p)
+    nch = k if cin_p == 4 else (k * k + 1) // 2
+    assert planes.shape == (nch, 2, n, 32) and planes.dtype == torch.int16 and s.shape == (n, )
+    assert torch.all(torch.log2(s) == torch.log2(s).round())  # powers of two
+    val = planes.view(torch.float16).float()  # [chunk][plane][n][32]
+    dec = (val[:, 0] + val[:, 1]) / s.view(1, -1, 1)  # [chunk][n][32]
+    want = torch.zeros(nch, n, 32)
+    for dh in range(k):
+        for dw in range(k):
+            for c in range(cin):
+                if cin_p == 4:
+                    want[dh, :, dw * 4 + c] = w[:, c, dh, dw]
+                else:
+                    t = dh * k + dw
+                    want[t // 2, :, (t % 2) * 16 + c] = w[:, c, dh, dw]
+    assert float((dec - want).abs().max()) <= 2.0**-21 * float(w.abs().max())
+    assert torch.all(dec[want == 0] == 0)  # padding taps / channels carry exact zeros
+    hi = val[:, 0] / s.view(1, -1, 1)
+    assert float((hi - want).abs().max()) <= 2.0**-10 * float(w.abs().max())  # the hi plane alone is the half rounding of the filter
