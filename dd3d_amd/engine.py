@@ -935,12 +935,9 @@ class ForwardPlan(PlanBase):
             hip.check(lib.dd3d_invert_intrinsics(self.in_K.data_ptr(), self.inv_K.data_ptr(), B, st), "invert_intrinsics")
 
         self.ops.append(CallOp(_pre, "preprocess", dict(kind="preprocess", img=img, mean=list(self._norm[0]), std=list(self._norm[1]))))
-        if img is None:
-            img = View.__new__(View)  # geometry only: the DLA lowering reads B / H / W of the input view
-            img.buf, img.c0, img.C = type("Geom", (), dict(B=B, H=Hp, W=Wp, pitch=4, has_f32=False, np=0, t=None, p=None, name="img4"))(), 0, 4
 
         # ---- backbone + FPN
-        img_view = img.view() if isinstance(img, Buf) else img
+        img_view = img.view() if img is not None else None  # (None: the fused stem reads the uint8 input itself)
         if isinstance(bb.bottom_up, DLA):
             feats = self._dla(bb.bottom_up, img_view)
         else:
@@ -1101,7 +1098,7 @@ class ForwardPlan(PlanBase):
         return True
 
     def _dla(self, dla, img):
-        B, H, W = img.B, img.H, img.W
+        B, H, W = self.B, self.Hp, self.Wp
         ch = dla.channels
         if self.fused_stem:
             y = self.buf("level1.0", B, H // 2, W // 2, ch[1], kind="both")  # level2: conv input (planes) + max-pool input (f32)
