@@ -180,3 +180,25 @@ def test_inference_shard_follows_the_reference_group_sampler():
         assert all(len(sh) % group == 0 and (len(sh) == 0 or sh[0] % group == 0) for sh in shards)  # whole groups only
     with pytest.raises(AssertionError, match="divisible by group size"):
         inference_shard(13, 6, 0, 2)
+
+
+def test_range_guard_verdict_is_the_or_over_all_ranks_records():
+    """engine.ForwardPlan.check_status with the exchange: the two flag words every rank folds into its record (dd3d_fold_range_flags)
+    are read out of the GATHERED buffer, so a fault on any rank raises on every rank (they all hold the same gathered bytes)."""
+    import torch
+    from dd3d_amd import hip
+    from dd3d_amd.engine import ForwardPlan
+    W, rec, off = 3, 40, 36
+    fake = type("P", (), {})()
+    fake.exchange, fake.math, fake.dry_run, fake.world_size, fake.record_len, fake.flags_off, fake.act_scale = True, hip.MATH_F16X2, False, W, rec, off, 16.0
+    fake.status = torch.zeros(1, dtype=torch.int32)
+    fake.gathered = torch.zeros(W * rec, dtype=torch.float32)
+    flags = fake.gathered.view(W, rec)[:, off:off + 2].view(torch.int32)
+    ForwardPlan.check_status(fake)  # nothing flagged anywhere: no error
+    flags[2, 0] = hip.STATUS_F16_OVERFLOW  # rank 2 overflowed
+    with pytest.raises(FloatingPointError, match=r"half range.*rank\(s\) \[2\]"):
+        ForwardPlan.check_status(fake)
+    flags[2, 0] = 0
+    flags[1, 1] = 1  # rank 1's outputs sit below the useful range
+    with pytest.raises(FloatingPointError, match=r"useful part on rank\(s\) \[1\]"):
+        ForwardPlan.check_status(fake)
