@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Throughput benchmark of the DD3D-DLA34 forward path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one forward pass of the hot path (uint8 image already resident in HBM -> final detections in HBM) over one
@@ -15,9 +15,10 @@ the next slots' trunks).  `--pipeline 0` issues one step at a time and that figu
 timed steps does all of its work and is complete before the closing synchronize (a partly filled slot is flushed and runs in full).
 Every slot's graphs are replayed once at construction and the untimed warm-up covers every slot at least twice, whatever --warmup says.
 
-Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch,
-conv_igemm_planes_kernel<2,2,4,2,...> of csrc/conv_planes.hip): algorithmic FLOPs of one launch / its mean duration measured here with
-HIP events on the launch stream, against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
+Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch of the slot's plan:
+conv_igemm_planes_row_kernel<4,2,2,4,2,4,false> of csrc/conv_planes_row.hip at the default four images per launch): algorithmic FLOPs of
+one launch / its mean duration measured here with HIP events on the launch stream (``traffic``: the PMC-derived HBM bytes of that launch
+geometry, profiles/r03_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: dd3d_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
 matrix products spent per f32 product (``--math``: f16x2 3, bf16x3 6, bf16x2 3, bf16 1; the f32-input MFMA peak 157.3 TFLOP/s for f32).
 ``blocks`` repeats the timed block a few times so that a reader can tell box / clock variance from a regression.  ``cpu_baseline`` is
 the CPU oracle (a restatement "port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
