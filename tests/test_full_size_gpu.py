@@ -51,7 +51,7 @@ def test_v99_kitti_bs16_full_size_matches_oracle(hiplib):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name", ["dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets"])
+@pytest.mark.parametrize("name", ["dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets"])
 def test_full_size_detections_match_the_reference_itself(hiplib, name):
     """BASELINE configs[1] / [2] geometry (384x1280) against detections produced by the reference's own tridet DD3D.forward
     (tests/golden/make_golden.py, run in the build container), end to end from the uint8 image: same detections -- classes, levels,
@@ -63,14 +63,20 @@ def test_full_size_detections_match_the_reference_itself(hiplib, name):
     from tests.golden.make_golden import CASES, case_inputs
     from tests.test_forward_gpu import _key
     exp, tag, B, H, W, ragged = CASES[name]
+    nusc = "nusc" in exp  # configs[4] geometry: one 6-camera sample, attributes / speeds / global boxes after the sample-level aggregation
     cfg, sd = bundle(exp, tag)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     t = lambda k: torch.from_numpy(g[k])
-    inputs = case_inputs(B, H, W, ragged, "kitti")
+    inputs = case_inputs(B, H, W, ragged, "nusc" if nusc else "kitti")
     model = gpu_model(cfg, sd, use_graph=True)
     out = model(inputs)
     plan, _ = model.stage_inputs(inputs)
-    _, st = _oracle(cfg, sd, inputs)
+    if nusc:
+        from oracle import nuscenes_oracle as N
+        with torch.no_grad():
+            _, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
+    else:
+        _, st = _oracle(cfg, sd, inputs)
     for i in range(B):
         _, _, margins = candidate_margins(plan, st, cfg, i)
         assert all(m <= MARGIN_EPS for m in margins), margins
@@ -92,7 +98,13 @@ def test_full_size_detections_match_the_reference_itself(hiplib, name):
         gq = t(f"det{i}_quat")[ir]
         assert float(torch.minimum((b3.quat[io].cpu() - gq).abs().amax(1), (b3.quat[io].cpu() + gq).abs().amax(1)).max()) < REL_TOL
         assert max_abs(b3.tvec[io], t(f"det{i}_tvec")[ir]) < REL_TOL * float(t(f"det{i}_tvec").abs().max())
-        print(f"[golden] {name}: {len(kr)} reference detections, {len(common)} shared, {len(margins)} on-the-cut flips")
+        if nusc:
+            assert torch.equal(o.pred_attributes.cpu()[io], t(f"det{i}_attributes")[ir])
+            assert rel_err(o.pred_speeds[io], t(f"det{i}_speeds")[ir]) < REL_TOL
+            gl, gg = o.pred_boxes3d_global.vectorize().cpu()[io], t(f"det{i}_global")[ir]
+            assert max_abs(gl[:, 4:], gg[:, 4:]) < REL_TOL * float(gg[:, 4:].abs().max())  # global tvec (~1e3 m) and size
+            assert float(torch.minimum((gl[:, :4] - gg[:, :4]).abs().amax(1), (gl[:, :4] + gg[:, :4]).abs().amax(1)).max()) < REL_TOL
+        print(f"[golden] {name}: image {i}: {len(kr)} reference detections, {len(common)} shared, {len(margins)} on-the-cut flips")
 
 
 @pytest.mark.timeout(900)
