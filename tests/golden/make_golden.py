@@ -47,6 +47,8 @@ CASES = {
     # attributes, speeds and the sample-level BEV aggregation -- the reference's own classes; the HIP path is tied to the oracle at this size
     # on the GPU (test_full_size_gpu.py), this fixture ties the oracle to the reference
     "dla34_nusc_896x1600_b6_dets": ("dd3d_nusc_dla34", "dla34_nusc", 6, 896, 1600, False),
+    # BASELINE.json configs[3] per GPU: NuscenesDD3D on V2-99, one 6-camera sample at 896x1600
+    "v99_nusc_896x1600_b6_dets": ("dd3d_nusc_v99", "v99_nusc", 6, 896, 1600, False),
 }
 # the 128x224 images yield few candidates at the default threshold; lower it so that the BEV stages have work to do.  The
 # second case also trips the per-sample cap (nuscenes_dd3d.py:333, postprocessing.py:93-94).
@@ -56,8 +58,8 @@ EXTRA_OVERRIDES = {
     "dla34_nusc_128x224_b6_bevnms": {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.01}}, "INFERENCE": {"DO_BEV_NMS": True},
                                               "NUSC": {"INFERENCE": {"MAX_NUM_DETS_PER_SAMPLE": 60}}}},
 }
-DETECTIONS_ONLY = {"dla34_nusc_128x224_b6_bevnms", "dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets"}  # no head maps
-NO_IMAGES = {"dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets"}  # (the padded canvases are MBs; the small cases pin them)
+DETECTIONS_ONLY = {"dla34_nusc_128x224_b6_bevnms", "dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets", "v99_nusc_896x1600_b6_dets"}  # no head maps
+NO_IMAGES = {"dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets", "v99_nusc_896x1600_b6_dets"}  # (the padded canvases are MBs; the small cases pin them)
 NO_FEATURES = {"v99_nusc_64x128_b6"}  # the V2-99 features are covered by the KITTI case; keeps the fixture small
 
 

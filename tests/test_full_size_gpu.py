@@ -51,7 +51,8 @@ def test_v99_kitti_bs16_full_size_matches_oracle(hiplib):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name", ["dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets"])
+@pytest.mark.parametrize("name", ["dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets",
+                                  "v99_nusc_896x1600_b6_dets"])
 def test_full_size_detections_match_the_reference_itself(hiplib, name):
     """BASELINE configs[1] / [2] geometry (384x1280) against detections produced by the reference's own tridet DD3D.forward
     (tests/golden/make_golden.py, run in the build container), end to end from the uint8 image: same detections -- classes, levels,
@@ -71,18 +72,25 @@ def test_full_size_detections_match_the_reference_itself(hiplib, name):
     model = gpu_model(cfg, sd, use_graph=True)
     out = model(inputs)
     plan, _ = model.stage_inputs(inputs)
-    if nusc:
-        from oracle import nuscenes_oracle as N
-        with torch.no_grad():
-            _, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
-    else:
-        _, st = _oracle(cfg, sd, inputs)
+    keys = []
     for i in range(B):
-        _, _, margins = candidate_margins(plan, st, cfg, i)
-        assert all(m <= MARGIN_EPS for m in margins), margins
         o = out[i]["instances"]
-        ko = _key(o.fpn_levels.cpu(), o.locations.cpu(), o.pred_classes.cpu())
-        kr = _key(t(f"det{i}_levels"), t(f"det{i}_locations"), t(f"det{i}_classes"))
+        keys.append((_key(o.fpn_levels.cpu(), o.locations.cpu(), o.pred_classes.cpu()), _key(t(f"det{i}_levels"), t(f"det{i}_locations"), t(f"det{i}_classes"))))
+    st = None
+    if any(ko != kr for ko, kr in keys):  # the oracle is only needed to show that a differing candidate sits ON a cut
+        if nusc:
+            from oracle import nuscenes_oracle as N
+            with torch.no_grad():
+                _, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
+        else:
+            _, st = _oracle(cfg, sd, inputs)
+    for i in range(B):
+        margins = []
+        if st is not None:
+            _, _, margins = candidate_margins(plan, st, cfg, i)
+            assert all(m <= MARGIN_EPS for m in margins), margins
+        o = out[i]["instances"]
+        ko, kr = keys[i]
         assert len(kr) > 20
         if not margins:
             assert ko == kr, (len(ko), len(kr))  # same detections in the same (score_3d) order
