@@ -8,8 +8,29 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256 logical CPUs to a
+    container that is allowed a fraction of them; the oracle on 256 torch threads over a 16-CPU quota thrashes).  Same rule as bench.py."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(_usable_cores())  # the CPU oracle is the checker of most tests: do not oversubscribe the host
 
 
 def pytest_collection_modifyitems(config, items):
