@@ -291,8 +291,8 @@ def main():
         # with half of the activations zero -- the chip's power management, not the kernel.
         try:
             measured_mfma_ceiling_tflops = round(mfma_ceiling_tflops(), 1)
-        except Exception:  # (a stale library without the probe: the figure of profiles/r03_mfma_power_bench.txt)
-            measured_mfma_ceiling_tflops = 1480.0
+        except Exception:  # (a library without the probe: nothing was measured in this run, and nothing is reported as if it had been)
+            measured_mfma_ceiling_tflops = None
         out["roofline"] = {
             "kernel": kname + " (head towers, 15 segments / launch)", "bound": "mfma",
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -301,7 +301,8 @@ def main():
                            "For reference the f32-input MFMA peak is 157.3"),
             "executed_16bit_mfma_tflops": None if math_name == "f32" else round(achieved * PRODUCTS[math_name], 1),
             "measured_mfma_ceiling_on_real_operands_tflops": None if math_name == "f32" else measured_mfma_ceiling_tflops,
-            "frac_of_measured_ceiling": None if math_name == "f32" else round(achieved * PRODUCTS[math_name] / measured_mfma_ceiling_tflops, 4),
+            "frac_of_measured_ceiling": (None if math_name == "f32" or not measured_mfma_ceiling_tflops else
+                                         round(achieved * PRODUCTS[math_name] / measured_mfma_ceiling_tflops, 4)),
             "ceiling_note": "`frac` is against the nominal dense peak as the contract asks; a register-resident loop of the same MFMA instruction "
                             "(dd3d_mfma_probe, timed in this run) reaches 0.98 of that peak on zero operands and 0.58-0.71 on realistic ones, "
                             "depending on the chip and its thermal state (profiles/r03_mfma_power_bench.txt, r03l_mfma_power_bench_orders.txt)",

@@ -21,13 +21,22 @@ inline int check_launch(const char* what) {
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of a kernel ON ONE DEVICE: a process that drives several GPUs must opt
-// in on each of them.  `done` = one bit per device ordinal (static storage at the call site); a refusal is reported, not ignored.
-inline bool lds_opt_in_needed(unsigned long long (&done)[4]) {
+// in on each of them.  `done` = one bit per device ordinal (static storage at the call site).  lds_opt_in_needed() only ASKS; the call
+// site marks the device with lds_opt_in_done() after EVERY opt-in of the site has succeeded, so a refusal is retried by the next launch
+// instead of leaving later launches to fail with an opaque launch error (round-3 advisor).  The bit set is updated atomically: two host
+// threads may drive different GPUs.
+inline int lds_current_device() {
   int d = 0;
-  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 256) return true;
-  if ((done[d >> 6] >> (d & 63)) & 1ull) return false;
-  done[d >> 6] |= 1ull << (d & 63);
-  return true;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 256) ? d : -1;
+}
+inline bool lds_opt_in_needed(unsigned long long (&done)[4]) {
+  const int d = lds_current_device();
+  if (d < 0) return true;
+  return !((__atomic_load_n(&done[d >> 6], __ATOMIC_ACQUIRE) >> (d & 63)) & 1ull);
+}
+inline void lds_opt_in_done(unsigned long long (&done)[4]) {
+  const int d = lds_current_device();
+  if (d >= 0) __atomic_fetch_or(&done[d >> 6], 1ull << (d & 63), __ATOMIC_RELEASE);
 }
 inline int lds_opt_in(const void* kernel, size_t bytes, const char* what) {
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

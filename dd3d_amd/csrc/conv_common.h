@@ -303,6 +303,236 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
   }
 }
 
+// ---- Epilogue of the split-plane kernels: TRANSPOSED accumulators.
+// The split-plane kernels issue their MFMAs with the FILTER fragment as the first operand (D = W . A^T): a lane of a 32x32 accumulator
+// block then owns ONE output pixel (column = lane & 31) and 16 output channels (rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  The filter
+// rows of every 32-row block are laid into LDS in the order chan_of_row() -- the LDS-DMA's per-lane source address, nothing else -- so
+// that those 16 channels are CONSECUTIVE: half-wave h = lane >> 5 owns channels 16 h .. 16 h + 15 of the block, register r = channel
+// 16 h + r.  Every memory instruction of the epilogue is then 16 bytes per lane on consecutive channels of one pixel:
+//   f32 NHWC store 4 x dwordx4 per block (the pixel-per-register form: 16 x dword), split-plane store 2 x dwordx4 per plane (16 x dword
+//   + 8 DPP swaps for two planes), residual 4 x dwordx4 (16 x dword).
+// The epilogue of a short-K convolution is bound by the NUMBER of memory instructions its CU must issue (~70-80 cycles each whatever
+// their width, MI355X_MICROARCH.md "store-ISSUE-bound"): DLA level 2 (K = 576) spent 96 of them per wave against a 5.8 us K loop.
+// The per-channel vectors (scale, bias, lower clamp with the ReLU folded in) of the block's BN columns are staged in LDS by the
+// kernel's prologue (epi_stage_vectors: global loads issued before the first LDS-DMA, written to LDS after the prologue's barrier), so
+// the epilogue reads them with ds_read_b128 -- no vector-memory load sits between the stores of consecutive blocks.
+// Residual sources (dd3d_conv_seg.res_mode): 1 f32 NHWC same pixel; 2 split planes, same pixel; 3 split planes of the map at HALF the
+// resolution (nearest-neighbour x2 upsampling fused into the add: the FPN top-down path).
+__device__ __forceinline__ int chan_of_row(int rho) { return ((rho >> 2) & 1) * 16 + (rho >> 3) * 4 + (rho & 3); }
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(1))) * gcu4p;
+typedef u32x4 __attribute__((address_space(1))) * gu4p;
+typedef f32x4 __attribute__((address_space(1))) * gf4p;
+
+// Prologue half 1: this thread's share of [scale | bias | lo] for columns n0 .. n0 + BN - 1 (clamped to the last real channel).
+template <int BN, int NTHR>
+struct EpiVec {
+  static constexpr int CNT = (3 * BN + NTHR - 1) / NTHR;
+  float v[CNT];
+};
+template <int BN, int NTHR>
+__device__ __forceinline__ void epi_load_vectors(const ConvKArgs& a, const dd3d_conv_seg& s, int n0, int tid, EpiVec<BN, NTHR>& e) {
+  const int nlim = s.n_limit > 0 ? s.n_limit : a.N;
+#pragma unroll
+  for (int k = 0; k < EpiVec<BN, NTHR>::CNT; ++k) {
+    const int idx = tid + k * NTHR;
+    const int which = idx / BN, c = idx - which * BN;
+    const int n = min(n0 + c, nlim - 1);
+    float x = 0.f;
+    if (which == 0) x = as_g(s.scale)[n];
+    else if (which == 1) x = as_g(s.bias)[n];
+    else if (which == 2) {
+      x = s.lo ? as_g(s.lo)[n] : -INFINITY;
+      if (a.relu) x = fmaxf(x, 0.f);
+    }
+    e.v[k] = x;
+  }
+}
+// Prologue half 2 (after the first barrier; any later barrier publishes the values): LDS [3][BN] floats at `dst`.
+template <int BN, int NTHR>
+__device__ __forceinline__ void epi_store_vectors(unsigned char* dst, int tid, const EpiVec<BN, NTHR>& e) {
+#pragma unroll
+  for (int k = 0; k < EpiVec<BN, NTHR>::CNT; ++k) {
+    const int idx = tid + k * NTHR;
+    if (idx < 3 * BN) reinterpret_cast<float*>(dst)[idx] = e.v[k];
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void unpack_terms(const u32x4 (&w)[Planes<MODE>::NP][2], float (&x)[16]) {
+  constexpr int NP = Planes<MODE>::NP;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo_e = 0.f, hi_e = 0.f;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {  // largest term first: (hi + mid) + lo
+        const unsigned d = w[p][q][e];
+        if constexpr (Planes<MODE>::F16) {
+          const f16x2 hh = __builtin_bit_cast(f16x2, d);
+          lo_e += (float)hh[0], hi_e += (float)hh[1];
+        } else {
+          lo_e += __uint_as_float(d << 16), hi_e += __uint_as_float(d & 0xffff0000u);
+        }
+      }
+      x[8 * q + 2 * e] = lo_e, x[8 * q + 2 * e + 1] = hi_e;
+    }
+}
+
+// The 8-wave tile whose waves hold 8 accumulator blocks (256 x 256) has 256 registers per lane: no room for a residual in flight.
+template <int TM, int TN, int WM, int WN>
+constexpr bool epi_residual_ok() { return !(TM * TN >= 8 && WM * WN >= 8); }
+
+template <int TM, int TN, int MODE, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                                int wn, int lane, const unsigned char* evec) {
+  constexpr int NP = Planes<MODE>::NP;
+  constexpr int BN = TN * 32 * WN;
+  constexpr bool RES = epi_residual_ok<TM, TN, WM, WN>();
+  constexpr int IG = (TM * TN >= 8 || TM < 2) ? 1 : 2;  // accumulator blocks whose residuals are in flight together
+  constexpr int NRAW = 2 * NP > 4 ? 2 * NP : 4;          // 16-byte pieces of one block's residual (f32: 4, planes: 2 per plane)
+  const int nlim = s.n_limit > 0 ? s.n_limit : a.N;
+  const bool w32 = s.out != nullptr, wpl = s.out_planes != nullptr;
+  const int h = lane >> 5, px = lane & 31;
+  const long cstride = (long)s.M * (NP * 64);  // bytes per 32-channel chunk image of the output
+  const float pscale = a.out_plane_scale, inv_pscale = 1.f / pscale;
+  const int rmode = RES ? s.res_mode : 0;
+  const long res_cstride = rmode == 3 ? (long)s.B * (s.Ho >> 1) * (s.Wo >> 1) * (NP * 64) : cstride;
+  int ovf = 0;
+  float amx = 0.f;
+  // the reporting wave of the block (range-guard sample): see conv_epilogue
+  const int seed = m0 / (TM * 32 * WM) + n0 / (TN * 32 * WN);
+  int wm_sel = seed % WM, wn_sel = (seed / WM) % WN;
+  if (m0 + wm_sel * TM * 32 >= s.M) wm_sel = 0;
+  if (n0 + wn_sel * TN * 32 >= nlim) wn_sel = 0;
+  const bool report = Planes<MODE>::F16 && a.amax != nullptr && wm == wm_sel && wn == wn_sel;
+  const int mbase = m0 + wm * TM * 32 + px;  // this lane's pixel of accumulator row block 0
+  auto res_pixel = [&](int m) -> long {      // pixel of the residual map that output pixel m adds
+    if (rmode != 3) return m;
+    const int howo = s.Ho * s.Wo;
+    const int b = m / howo;
+    const int rr = m - b * howo;
+    const int ho = rr / s.Wo;
+    const int wo = rr - ho * s.Wo;
+    return ((long)b * (s.Ho >> 1) + (ho >> 1)) * (s.Wo >> 1) + (wo >> 1);
+  };
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cb = (wn * TN + j) * 32;   // first column of this block inside the tile
+    const int nb = n0 + cb;              // wave-uniform: first channel of this column block
+    if (nb >= nlim) continue;
+    const int nh = nb + 16 * h;          // this lane's first channel
+    const bool partial = nb + 32 > nlim; // wave-uniform: the block holds channels past the last one stored
+    const f32x4* ev = reinterpret_cast<const f32x4*>(evec) + (cb + 16 * h) / 4;
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += IG) {
+      // ---- residuals of IG blocks, all loads in flight together
+      u32x4 raw[IG][NRAW];
+      if constexpr (RES) {
+        if (rmode == 1) {
+#pragma unroll
+          for (int ii = 0; ii < IG; ++ii) {
+            const int m = mbase + (i0 + ii) * 32;
+            const gcu4p p = (gcu4p)(as_g(s.res) + (long)m * s.res_pitch + nh);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) raw[ii][q] = (m < s.M && nh + 4 * q < nlim) ? p[q] : u32x4{0u, 0u, 0u, 0u};
+          }
+        } else if (rmode >= 2) {
+#pragma unroll
+          for (int ii = 0; ii < IG; ++ii) {
+            const int m = mbase + (i0 + ii) * 32;
+            const bool mv = m < s.M;
+            const gcbp p = (gcbp)s.res + (long)(nb >> 5) * res_cstride + (mv ? res_pixel(m) : 0) * (NP * 64) + h * 32;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) raw[ii][2 * pl + q] = mv ? *(gcu4p)(p + pl * 64 + q * 16) : u32x4{0u, 0u, 0u, 0u};
+          }
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < IG; ++ii) {
+        const int i = i0 + ii;
+        const int m = mbase + i * 32;
+        const bool mv = m < s.M;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        if constexpr (RES) {
+          if (rmode == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = __uint_as_float(raw[ii][r >> 2][r & 3]);
+          } else if (rmode >= 2) {
+            u32x4 wv[NP][2];
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) wv[pl][0] = raw[ii][2 * pl], wv[pl][1] = raw[ii][2 * pl + 1];
+            unpack_terms<MODE>(wv, v);
+            if constexpr (Planes<MODE>::F16) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] *= inv_pscale;
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 sc = ev[q], bi = ev[BN / 4 + q], lo = ev[2 * (BN / 4) + q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = fmaxf(acc[i][j][4 * q + e] * sc[e] + bi[e] + v[4 * q + e], lo[e]);
+        }
+        if (partial) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = nh + r < nlim ? v[r] : 0.f;  // channels past N inside the last chunk are zero planes
+        }
+        if (w32 && mv) {
+          const gf4p o = (gf4p)(as_g(s.out) + (long)m * s.out_pitch + nh);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!partial || nh + 4 * q + 4 <= nlim) {
+              o[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            } else {  // the group that straddles the last stored channel: nothing past it is written (a neighbouring slice may own it)
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                if (nh + 4 * q + e < nlim) as_g(s.out)[(long)m * s.out_pitch + nh + 4 * q + e] = v[4 * q + e];
+            }
+          }
+        }
+        if (wpl) {
+          unsigned w[8][NP];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            float e0 = v[2 * t], e1 = v[2 * t + 1];
+            if constexpr (Planes<MODE>::F16) {
+              e0 *= pscale, e1 *= pscale;
+              ovf |= !(fabsf(e0) <= 65504.f) | !(fabsf(e1) <= 65504.f);
+              if (report && mv) amx = fmaxf(amx, fmaxf(fabsf(e0), fabsf(e1)));
+            }
+            split_pack<MODE>(e0, e1, w[t]);
+          }
+          if (mv) {
+            const gbp dst = (gbp)s.out_planes + (long)(nb >> 5) * cstride + (long)m * (NP * 64) + h * 32;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              *(gu4p)(dst + p * 64) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
+              *(gu4p)(dst + p * 64 + 16) = u32x4{w[4][p], w[5][p], w[6][p], w[7][p]};
+            }
+          }
+        }
+        if constexpr (TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);  // (keeps the blocks of the 8-block wave tiles from being interleaved: registers)
+      }
+    }
+  }
+  if constexpr (Planes<MODE>::F16) {
+    if (ovf && a.status) atomicOr(a.status, DD3D_STATUS_F16_OVERFLOW);  // (NaN / inf inputs trip it as well)
+    if (report) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) amx = fmaxf(amx, __shfl_xor(amx, d, 64));
+      if (lane == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.amax + (seed & 15) * 32), __float_as_uint(amx));
+    }
+  }
+}
+
 // ---- instruction-scheduling pattern of one phase of a K step (sched_group_barrier: 0x008 MFMA, 0x010 VMEM, 0x100 DS read)
 // NMFMA matrix instructions with NDMA LDS-DMA issues and NDS fragment reads spread EVENLY among them (the DMAs evenly among those): all
 // eight waves of a block leave the barrier together, and eight back-to-back bursts of LDS-DMA issues queue up in the CU's one

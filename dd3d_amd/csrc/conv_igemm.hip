@@ -755,7 +755,7 @@ static void launch_reg_sk(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   auto k = conv_igemm_f32_kernel<TM, TN, WM, WN, SMALLC, PIPE, SK>;
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
-    (void)lds_opt_in(reinterpret_cast<const void*>(k), lds, "conv_igemm_f32 kernel");  // (a refusal surfaces as the launch error below)
+    if (lds_opt_in(reinterpret_cast<const void*>(k), lds, "conv_igemm_f32 kernel") == DD3D_OK) lds_opt_in_done(attr_done);  // (a refusal is retried by the next launch; this one fails with the launch error below)
   }
   hipLaunchKernelGGL(k, grid, dim3(256, 1, 1), lds, st, ka);
 }
@@ -773,7 +773,7 @@ static void launch_dma_sk(const ConvKArgs& ka, dim3 grid, hipStream_t st) {
   auto k = conv_igemm_f32_dma_kernel<TM, TN, WM, WN, NS, U, WK, SK>;
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
-    (void)lds_opt_in(reinterpret_cast<const void*>(k), lds, "conv_igemm_f32 kernel");  // (a refusal surfaces as the launch error below)
+    if (lds_opt_in(reinterpret_cast<const void*>(k), lds, "conv_igemm_f32 kernel") == DD3D_OK) lds_opt_in_done(attr_done);  // (a refusal is retried by the next launch; this one fails with the launch error below)
   }
   hipLaunchKernelGGL(k, grid, dim3(256 * WK, 1, 1), lds, st, ka);
 }
@@ -793,6 +793,7 @@ static int launch_x3(const ConvKArgs& ka, hipStream_t st) {
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, false>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
     if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, true>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   if (ka.splitk > 1) hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, true>), grid, dim3(NTHR), lds, st, ka);
   else hipLaunchKernelGGL((conv_igemm_bf16x3_kernel<TM, TN, WM, WN, NSA, NSB, KT, false>), grid, dim3(NTHR), lds, st, ka);
@@ -887,6 +888,15 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.out_plane_scale = L->out_plane_scale > 0.f ? L->out_plane_scale : 1.f;
   ka.status = L->status;
   ka.amax = L->amax;
+  if (ka.single) {  // (only a single-segment launch hands its descriptor over on the host; the caller vouches for device-side ones)
+    const dd3d_conv_seg& s0 = ka.seg0;
+    DD3D_REQUIRE(s0.res_mode >= 0 && s0.res_mode <= 3 && (s0.res_mode == 0 || s0.res), "dd3d_conv2d_igemm_f32: res_mode=%d / null residual", s0.res_mode);
+    DD3D_REQUIRE(s0.res_mode <= 1 || L->in_planes, "dd3d_conv2d_igemm_f32: a split-plane residual (res_mode %d) needs the split-plane-input kernels",
+                 s0.res_mode);
+    DD3D_REQUIRE(s0.res_mode != 3 || ((s0.Ho % 2) == 0 && (s0.Wo % 2) == 0), "dd3d_conv2d_igemm_f32: res_mode 3 needs even Ho, Wo (%d x %d)", s0.Ho,
+                 s0.Wo);
+    DD3D_REQUIRE(s0.res_mode == 0 || !L->in_planes || L->tile_cfg != DD3D_TILE_256x256_W8, "dd3d_conv2d_igemm_f32: DD3D_TILE_256x256_W8 carries no residual");
+  }
   if (L->in_planes) {
     DD3D_REQUIRE(L->math_mode != DD3D_MATH_F32 && !smallc && L->zero_page && !L->in_relu,
                  "dd3d_conv2d_igemm_f32: split-plane input needs a split-operand math mode, Cin %% 32 == 0, a zero page and no in_relu");

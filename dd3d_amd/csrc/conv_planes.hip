@@ -53,6 +53,9 @@ __device__ __forceinline__ void sched_interleave() {
 #ifndef DD3D_LDS_KIB_4W
 #define DD3D_LDS_KIB_4W 72
 #endif
+#ifndef DD3D_EPI_T
+#define DD3D_EPI_T 1  // 1: transposed accumulators + the 16-bytes-per-lane epilogue (conv_common.h::conv_epilogue_t); 0: round-3 form (A/B)
+#endif
 #ifndef DD3D_SCHED_VARIANT
 #define DD3D_SCHED_VARIANT 1  // 0: DMA burst right after the barrier; 1: evenly spread over the phase; 2: spread over both phases of a step (NS >= 3)
 #endif
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
   constexpr int RA = BM / 16, RB = BN / 16;        // 16-row blocks (one 1-KiB DMA piece per plane)
   constexpr int QN = (RA + RB + NL - 1) / NL;      // row blocks per loading wave (the surplus re-fetches the last block)
   constexpr int P = QN * NP;                       // DMA instructions per wave and K-tile
-  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS ring");
+  constexpr int EV_OFF = NS * STAGE;  // [scale | bias | lo][BN] floats of the epilogue (conv_epilogue_t)
+  static_assert(NS >= 2 && EV_OFF + 12 * BN <= 160 * 1024, "LDS ring");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
@@ -136,7 +140,12 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
       const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
       const long a_off = (((long)b * s.H + hi0) * s.W + wi0) * (NP * 64) + slot16;
       // B geometry (rows past Npad feed columns >= N, which are never stored)
+#if DD3D_EPI_T  // LDS row R of the B rows holds filter row chan_of_row(R) of its 32-row block (conv_common.h::conv_epilogue_t)
+      const int brow = (r - RA) * 16 + (lane >> 2);
+      const int n = min(n0 + (brow & ~31) + chan_of_row(brow & 31), a.Npad - 1);
+#else
       const int n = min(n0 + (r - RA) * 16 + (lane >> 2), a.Npad - 1);
+#endif
       const long b_off = (long)n * nk * (NP * 64) + slot16;
       a_hi0[q] = r < RA ? (live ? hi0 : -(1 << 28)) : 0;  // dead A rows are never inside [0, H); B rows always are
       a_wi0[q] = r < RA ? wi0 : 0;
@@ -276,15 +285,31 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
+#if DD3D_EPI_T  // filter fragment first: the accumulator block is [channel][pixel] (conv_common.h::conv_epilogue_t)
+          if constexpr (Planes<MODE>::F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[c][j][PB_[t]]), __builtin_bit_cast(f16x8, fa[c][i][PA_[t]]),
+                                                               acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][j][PB_[t]], fa[c][i][PA_[t]], acc[i][j], 0, 0, 0);
+#else
           if constexpr (Planes<MODE>::F16)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[c][i][PA_[t]]), __builtin_bit_cast(f16x8, fb[c][j][PB_[t]]),
                                                                acc[i][j], 0, 0, 0);
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][i][PA_[t]], fb[c][j][PB_[t]], acc[i][j], 0, 0, 0);
+#endif
   };
   constexpr std::integral_constant<int, 0> C0{};
   constexpr std::integral_constant<int, 1> C1{};
 
+#if DD3D_EPI_T
+  static_assert(PW == 0, "the transposed epilogue stages its vectors in the unspecialised prologue");
+  EpiVec<BN, NTHR> evv;
+  if (ntile <= 0) {  // an empty K slice: the split-K exchange's barriers publish the vectors
+    epi_load_vectors<BN, NTHR>(a, s, n0, tid, evv);
+    epi_store_vectors<BN, NTHR>(lds + EV_OFF, tid, evv);
+  }
+#endif
   if constexpr (PW > 0) {
     if (ntile > 0) {
       if (loader) {
@@ -334,6 +359,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
     }
   } else
   if (ntile > 0) {
+#if DD3D_EPI_T
+    epi_load_vectors<BN, NTHR>(a, s, n0, tid, evv);  // (oldest vector-memory operations of the wave: landed by the prologue's counted wait)
+#endif
     // prologue: fill the ring (tiles 0 .. NS-1; variant 2 leaves the second part of tile NS-1 to the first step), wait for tile 0
 #pragma unroll
     for (int d = 0; d < NS; ++d) {
@@ -347,6 +375,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPLIT ? (NS - 2) * P + QH * NP : (NS - 1) * P) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#if DD3D_EPI_T
+    epi_store_vectors<BN, NTHR>(lds + EV_OFF, tid, evv);  // published by the first step's barrier
+#endif
     read_frags(0, C0);
     int stage = 0;        // ring stage of tile kt
     int fill = NS - 1;    // variant 2: stage whose tile is half issued
@@ -391,7 +422,11 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
   if constexpr (SK) {
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
+#if DD3D_EPI_T
+  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF);
+#else
   conv_epilogue<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
@@ -407,13 +442,14 @@ static int launch_planes_tile(const ConvKArgs& ka, hipStream_t st) {
   constexpr int BUDGET = ((WM * WN == 8 || STAGE > 32 * 1024) ? DD3D_LDS_KIB_8W : DD3D_LDS_KIB_4W) * 1024;  // (a big 4-wave tile owns its CU anyway)
   constexpr int NS0 = BUDGET / STAGE;
   constexpr int NS = NS0 > 4 ? 4 : (NS0 < 2 ? 2 : NS0);
-  const size_t lds = (size_t)NS * STAGE;
+  const size_t lds = (size_t)NS * STAGE + 12 * BN;  // rings + the epilogue vectors
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, false, PW>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
     if constexpr (ALLOW_SK)
       if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_kernel<TM, TN, WM, WN, NS, MODE, true, PW>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   if constexpr (!ALLOW_SK) DD3D_REQUIRE(ka.splitk == 1, "dd3d_conv2d_igemm_f32: this tile has no split-K form (its accumulators fill the register file)");
   if constexpr (ALLOW_SK) {
@@ -577,6 +613,64 @@ __global__ __launch_bounds__(256) void maxpool2x2_planes_kernel(const float* __r
       *reinterpret_cast<f32x4*>(q + 4) = o[1];
     }
     store_planes8<MODE>(out_planes, M, m, c8, o[0], o[1], pscale, status);
+  }
+}
+
+// 2x2 / stride 2 max-pool of a map that exists as split planes only (ABI 4: the DLA data flow keeps no f32 twin of its tensors).  One
+// thread per (output pixel, 8 channels): the four candidates' values are rebuilt from their terms (largest term first), and the TERMS of
+// the largest value are copied -- the pooled planes are exactly the planes of one of the four inputs, nothing is re-split.
+template <int MODE>
+__global__ __launch_bounds__(256) void maxpool2x2_planes_in_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, int B, int H, int W,
+                                                                   int C8) {
+  constexpr int NP = Planes<MODE>::NP;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long Mi = (long)B * H * W, Mo = (long)B * Ho * Wo, total = Mo * C8;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(t & 3);          // 16-byte slot of the 64-byte row: channels 8 q .. 8 q + 7 of the chunk
+    const long u = t >> 2;
+    const long m = u % Mo;
+    const int chunk = (int)(u / Mo);
+    const int wo = (int)(m % Wo);
+    const long r = m / Wo;
+    const int ho = (int)(r % Ho), b = (int)(r / Ho);
+    const long p00 = ((long)b * H + 2 * ho) * W + 2 * wo;
+    const long pix[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+    u32x4 w[4][NP];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) w[k][p] = *reinterpret_cast<const u32x4*>(in + ((long)chunk * Mi + pix[k]) * (NP * 64) + p * 64 + q * 16);
+    u32x4 o[NP];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned sel_lo[NP], sel_hi[NP];  // terms of the winners of the dword's two channels
+      float best_lo = 0.f, best_hi = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v_lo = 0.f, v_hi = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const unsigned d = w[k][p][e];
+          if constexpr (Planes<MODE>::F16) {
+            const f16x2 hh = __builtin_bit_cast(f16x2, d);
+            v_lo += (float)hh[0], v_hi += (float)hh[1];
+          } else {
+            v_lo += __uint_as_float(d << 16), v_hi += __uint_as_float(d & 0xffff0000u);
+          }
+        }
+        const bool tl = k == 0 || v_lo > best_lo, th = k == 0 || v_hi > best_hi;
+        best_lo = tl ? v_lo : best_lo, best_hi = th ? v_hi : best_hi;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          sel_lo[p] = tl ? (w[k][p][e] & 0xffffu) : sel_lo[p];
+          sel_hi[p] = th ? (w[k][p][e] & 0xffff0000u) : sel_hi[p];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) o[p][e] = sel_lo[p] | sel_hi[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(out + ((long)chunk * Mo + m) * (NP * 64) + p * 64 + q * 16) = o[p];
   }
 }
 
@@ -777,6 +871,20 @@ extern "C" int dd3d_maxpool2x2_planes(const float* in, float* out, void* out_pla
   unsigned char* o = reinterpret_cast<unsigned char*>(out_planes);
   DD3D_PLANE_MODE_SWITCH(maxpool2x2_planes_kernel, in, out, o, B, H, W, C / 8, in_pitch, out_pitch, ps, status)
   return check_launch("maxpool2x2_planes kernel");
+}
+
+extern "C" int dd3d_maxpool2x2_planes_in(const void* in_planes, void* out_planes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t math_mode,
+                                         void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(in_planes && out_planes && B > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0 && C > 0 && (C % 32) == 0,
+               "dd3d_maxpool2x2_planes_in: bad arguments (H=%d W=%d C=%d)", H, W, C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const unsigned char* i = reinterpret_cast<const unsigned char*>(in_planes);
+  unsigned char* o = reinterpret_cast<unsigned char*>(out_planes);
+  DD3D_PLANE_MODE_SWITCH(maxpool2x2_planes_in_kernel, i, o, B, H, W, C / 8)
+  return check_launch("maxpool2x2_planes_in kernel");
 }
 
 extern "C" int dd3d_upsample2x_add_planes(float* fine, const float* coarse, void* fine_planes, int32_t B, int32_t H, int32_t W, int32_t C,

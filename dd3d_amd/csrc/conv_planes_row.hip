@@ -25,6 +25,9 @@
 #ifndef DD3D_ROW_LDS_KIB_4W
 #define DD3D_ROW_LDS_KIB_4W 76
 #endif
+#ifndef DD3D_EPI_T
+#define DD3D_EPI_T 1  // 1: transposed accumulators + the 16-bytes-per-lane epilogue (conv_common.h::conv_epilogue_t); 0: round-3 form (A/B)
+#endif
 
 namespace dd3d {
 
@@ -41,7 +44,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   constexpr int B_BASE = 2 * A_STAGE;
   constexpr int NPA = (AROWS / 16) * NP, NPB = (BN / 16) * NP;  // 1-KiB pieces of an A stage / a B stage
   constexpr int PA = (NPA + NW - 1) / NW, PB = (NPB + NW - 1) / NW;  // per wave (the surplus re-fetches the last piece)
-  static_assert(NSB >= 2 && NSB <= 3 && B_BASE + NSB * B_STAGE + 64 <= 160 * 1024, "LDS rings");
+  constexpr int ZERO_OFF = B_BASE + NSB * B_STAGE;  // 16 zero bytes invalid taps read (64 reserved)
+  constexpr int EV_OFF = ZERO_OFF + 64;              // [scale | bias | lo][BN] floats of the epilogue (conv_epilogue_t)
+  static_assert(NSB >= 2 && NSB <= 3 && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
@@ -97,7 +102,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   for (int q = 0; q < PB; ++q) {
     const int piece = min(q * NW + wave, NPB - 1);
     const int rb = piece / NP, pl = piece - rb * NP;
+#if DD3D_EPI_T  // LDS row R of the B stage holds filter row chan_of_row(R) of its 32-row block (conv_common.h::conv_epilogue_t)
+    const int brow = rb * 16 + (lane >> 2);
+    const int n = min(n0 + (brow & ~31) + chan_of_row(brow & 31), a.Npad - 1);  // rows past Npad feed columns >= N, which are never stored
+#else
     const int n = min(n0 + rb * 16 + (lane >> 2), a.Npad - 1);  // rows past Npad feed columns >= N, which are never stored
+#endif
     b_dst[q] = B_BASE + pl * PLB + rb * 1024;
     b_src[q] = g_w + (long)n * nk * (NP * 64) + pl * 64 + slot16;
   }
@@ -176,7 +186,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   bf16x8 fa[2][TM][NP], fb[2][TN][NP];
   // An invalid (pixel, tap) reads 16 zero bytes kept behind the rings instead of its LDS row: one address select per fragment read,
   // computed before the read is issued (masking the loaded registers would make every MFMA phase wait for its own prefetch).
-  constexpr int ZERO_OFF = B_BASE + NSB * B_STAGE;
   auto read_frags = [&](int sa, int sb, int dw, int tap, auto c_c) {
     constexpr int c = decltype(c_c)::value;
     const int abase = sa * A_STAGE + fa_off[dw][c];
@@ -210,16 +219,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
+#if DD3D_EPI_T  // filter fragment first: the accumulator block is [channel][pixel] (conv_common.h::conv_epilogue_t)
+          if constexpr (Planes<MODE>::F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[c][j][PB_[t]]), __builtin_bit_cast(f16x8, fa[c][i][PA_[t]]),
+                                                               acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][j][PB_[t]], fa[c][i][PA_[t]], acc[i][j], 0, 0, 0);
+#else
           if constexpr (Planes<MODE>::F16)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[c][i][PA_[t]]), __builtin_bit_cast(f16x8, fb[c][j][PB_[t]]),
                                                                acc[i][j], 0, 0, 0);
           else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][i][PA_[t]], fb[c][j][PB_[t]], acc[i][j], 0, 0, 0);
+#endif
   };
   constexpr std::integral_constant<int, 0> C0{};
   constexpr std::integral_constant<int, 1> C1{};
 
   if (tid < 4) reinterpret_cast<int*>(lds + ZERO_OFF)[tid] = 0;  // (visible to every wave after the prologue's barrier)
+#if DD3D_EPI_T
+  EpiVec<BN, NTHR> evv;
+  epi_load_vectors<BN, NTHR>(a, s, n0, tid, evv);  // (oldest vector-memory operations of the wave: landed by the prologue's counted wait)
+  if (ngroup <= 0) epi_store_vectors<BN, NTHR>(lds + EV_OFF, tid, evv);  // (an empty K slice: the split-K exchange's barriers publish them)
+#endif
   if (ngroup > 0) {
     // prologue, in issue order: A(group 0) -> A stage 0 | B(tiles 0 .. NSB-1) | A(group 1) -> A stage 1.  Wait for A(0) and B(0).
     prepare_a();
@@ -231,6 +253,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 1) * PB + PA) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#if DD3D_EPI_T
+    epi_store_vectors<BN, NTHR>(lds + EV_OFF, tid, evv);  // published by the first step's barrier
+#endif
     read_frags(0, 0, 0, (g_begin % 3) * 3, C0);
     int sb = 0;
     // One step = one K-tile (filter row dh, column dw).  DMA issue order after the prologue: step s issues B(s + NSB) and, when dw == 2
@@ -279,7 +304,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if constexpr (SK) {
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
+#if DD3D_EPI_T
+  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF);
+#else
   conv_epilogue<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
@@ -291,14 +320,15 @@ static int launch_row_tile(const ConvKArgs& ka, hipStream_t st) {
   // (a 4-wave block whose two A stages alone exceed half a CU's LDS owns its CU anyway: it takes the 8-wave budget)
   constexpr int BUDGET = ((WM * WN == 8 || A2 > 64 * 1024) ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
   constexpr int NSB = (A2 + 3 * BST <= BUDGET) ? 3 : 2;
-  static_assert(A2 + NSB * BST + 64 <= 160 * 1024, "tile does not fit the LDS");
-  const size_t lds = (size_t)A2 + (size_t)NSB * BST + 64;  // + the zero bytes invalid taps read
+  static_assert(A2 + NSB * BST + 64 + 12 * BN <= 160 * 1024, "tile does not fit the LDS");
+  const size_t lds = (size_t)A2 + (size_t)NSB * BST + 64 + 12 * BN;  // + the zero bytes invalid taps read + the epilogue vectors
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
     if constexpr (ALLOW_SK)
       if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   if constexpr (!ALLOW_SK) DD3D_REQUIRE(ka.splitk == 1, "dd3d_conv2d_igemm_f32: this tile has no split-K form (its accumulators fill the register file)");
   if constexpr (ALLOW_SK) {

@@ -1228,6 +1228,7 @@ extern "C" int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream) {
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(nms_sort_kernel), (size_t)(NCAP_MAX * 8), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
     if (lds_opt_in(reinterpret_cast<const void*>(nms_finalize_kernel), (size_t)(FIN_LDS_BYTES), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(args->G, SORT_SPLIT), dim3(PT), lds_sort, st, P);
   int rc = check_launch("nms_sort_kernel");
@@ -1261,6 +1262,7 @@ extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(bev_prepare_kernel), (size_t)(NCAP_MAX * 8), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
     if (lds_opt_in(reinterpret_cast<const void*>(bev_finalize_kernel), (size_t)(NCAP_MAX / 64 * 8 + NCAP_MAX * 4), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   hipLaunchKernelGGL(bev_prepare_kernel, dim3(1), dim3(PT), lds_prep, st, P);
   int rc = check_launch("bev_prepare_kernel");

@@ -153,6 +153,7 @@ static int launch_stem(const dd3d_smallc_args* a, hipStream_t st) {
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(k), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   StemK P;
   P.a = *a;

@@ -311,6 +311,7 @@ extern "C" int dd3d_stem_fused_f16x2(const dd3d_stem_args* a, void* stream) {
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(stem_fused_f16x2_kernel), (size_t)SF_LDS, "stem_fused_f16x2_kernel") != DD3D_OK) return DD3D_E_LAUNCH;
+    lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   StemFusedK P;
   P.a = *a;

@@ -457,11 +457,14 @@ class ConvOp:
             cfg = tile
         if splitk is not None:
             sk = splitk
+        if cfg == hip.TILE_256x256_W8 and any(sg.get("res") is not None for sg in segs):
+            cfg = hip.TILE_256x128  # (the 8-wave 256 x 256 tile has no registers left for a residual in flight)
         bm, bn = hip.TILE_SHAPES[cfg]
         arr = np.zeros(len(segs), dtype=hip.CONV_SEG_DTYPE)
         tiles = []
         self.keep = []
         self.out_forms = []
+        self.res_forms = []
         for i, s in enumerate(segs):
             vin, vout = s["in"], s["out"]
             assert vin.C == meta["Cin"], (name, vin.C, meta["Cin"])
@@ -496,16 +499,34 @@ class ConvOp:
             a["in_pitch"], a["out_pitch"] = vin.pitch, vout.pitch
             a["M"] = m_list[i]
             res = s.get("res")
+            res_form = None
             if res is not None:
-                assert (res.B, res.H, res.W) == (vout.B, vout.H, vout.W) and res.C >= meta["N"]
-                assert res.has_f32, f"conv {name}: the residual is read as f32"
-                a["res"], a["res_pitch"], a["res_mode"] = res.ptr, res.pitch, 1
+                # residual source forms (include/dd3d_hip.h, dd3d_conv_seg.res_mode): the split planes when the launch runs on the
+                # split-plane kernels and the source has them (no f32 twin needed), else the f32 map; `res_up`: the source is the
+                # map at half the resolution (FPN top-down: nearest x2 + add fused into the lateral convolution), planes only
+                assert res.C >= meta["N"]
+                planes_ok = in_planes and res.np == hip.MATH_PLANES[math] and (math != hip.MATH_F16X2 or res.buf.plane_scale == float(plan.act_scale))
+                if s.get("res_up"):
+                    assert planes_ok, f"conv {name}: the upsampled residual is read from split planes"
+                    assert (res.B, 2 * res.H, 2 * res.W) == (vout.B, vout.H, vout.W), (name, res.H, res.W, vout.H, vout.W)
+                    a["res"], a["res_pitch"], a["res_mode"] = res.pptr, 0, 3
+                    res_form = "planes_up"
+                else:
+                    assert (res.B, res.H, res.W) == (vout.B, vout.H, vout.W)
+                    if planes_ok and not (res.has_f32 and os.environ.get("DD3D_RES_F32", "0") == "1"):
+                        a["res"], a["res_pitch"], a["res_mode"] = res.pptr, 0, 2
+                        res_form = "planes"
+                    else:
+                        assert res.has_f32, f"conv {name}: the residual source has no f32 storage and its planes do not fit this launch"
+                        a["res"], a["res_pitch"], a["res_mode"] = res.ptr, res.pitch, 1
+                        res_form = "f32"
+            self.res_forms.append(res_form)
             a["n_limit"] = int(s.get("n_limit", 0))
             assert a["n_limit"] <= meta["N"]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
             self.keep += [w, scale_vec, s["bias"], s.get("lo")]  # (what the launch reads; kept alive here)
         self.desc = dict(kind="conv", segs=segs, meta=meta, stride=stride, pad=pad, relu=bool(relu), in_relu=bool(in_relu),
-                         in_form="planes" if in_planes else "f32", out_forms=self.out_forms)
+                         in_form="planes" if in_planes else "f32", out_forms=self.out_forms, res_forms=self.res_forms)
         self.segs_host = arr  # kept alive: single-segment launches hand the descriptor over by value (seg0_host)
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
@@ -535,7 +556,8 @@ class ConvOp:
                                           and os.environ.get("DD3D_AMAX", "1") != "0") else None  # DD3D_AMAX=0: A/B measurements only
         self.L = L
         # algorithmic MACs: every segment counts the channels it stores
-        self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs)) * meta["KH"] * meta["KW"] * meta["Cin"]
+        # (a segment that repeats another's products -- relu(p6) beside p6 -- is marked `algorithmic=False` and not counted)
+        self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs) if sg.get("algorithmic", True)) * meta["KH"] * meta["KW"] * meta["Cin"]
         self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), tile_name=hip.TILE_NAMES[cfg], splitk=sk, math=math,
                          blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs), in_form="planes" if in_planes else "f32")
 
@@ -582,6 +604,10 @@ class PlanBase:
         # vs 1.783 ms with them -- the cross-stream edges cost more than the overlap of the short residual / lateral / P6-P7
         # chains returns (their neighbours already fill the CUs).  DD3D_BRANCHES=1 turns them on.
         self.use_branches = os.environ.get("DD3D_BRANCHES", "0") == "1"
+        # Round 4: tensors that only convolutions, residual adds, 2x2 pools and the FPN top-down sum read exist as split planes ONLY (those
+        # consumers read planes: dd3d_conv_seg.res_mode 2 / 3, dd3d_maxpool2x2_planes_in).  DD3D_PLANES_ONLY=0 keeps round 3's f32 twins
+        # and the separate top-down kernels (A/B measurements).
+        self.planes_only = os.environ.get("DD3D_PLANES_ONLY", "1") != "0"
         self.ops = OpList(self)
         self.bufs = {}
         self.graph = None
@@ -592,6 +618,9 @@ class PlanBase:
         # (ForwardPlan.__init__ -> adopt_weight_store): every plan / pipeline slot of the model then reads the SAME device copies, so steps
         # in flight on several slots hit the same L2 / MALL lines instead of streaming one private copy of the weights per slot.
         self._packed, self._split, self._descaled = {}, {}, {}
+        # filters built on the fly (pack(cache=False): grouped / re-laid filters whose storage the model does not own) keep their term planes
+        # in the PLAN, so that they die with it instead of accumulating in the model's store (round-3 advisor)
+        self._split_local = {}
         import math as _math
         # DD3D_MATH_F16X2: every split-plane activation holds value * act_scale (a power of two; |value| <= 65504 / act_scale or the
         # status word trips and the forward raises; terms below 2^-24 / act_scale are lost).  DD3D_F16_ACT_SCALE overrides.
@@ -656,7 +685,9 @@ class PlanBase:
         """pack_filter with the plan's store in front: one packed copy per filter (list of filters) and device.  `cache=False` for
         filters built on the fly (their storage is not owned by the model, so its address may be recycled)."""
         if not cache:
-            return pack_filter(weights, self.device)
+            wp, meta = pack_filter(weights, self.device)
+            self._split_local[wp.data_ptr()] = {"wp": wp}  # (keeps the tensor alive: its address is the key)
+            return wp, meta
         ws = list(weights) if isinstance(weights, (list, tuple)) else [weights]
         key = tuple((w.data_ptr(), tuple(w.shape), w._version) for w in ws)
         if key not in self._packed:
@@ -666,22 +697,28 @@ class PlanBase:
     def split_weight(self, wp, math=hip.MATH_BF16X3):
         """16-bit term planes of a packed filter, built once per filter and mode (the towers share theirs over 5 levels)."""
         key = (wp.data_ptr(), math)
-        if key not in self._split:
+        store = self._split_local[wp.data_ptr()] if wp.data_ptr() in self._split_local else self._split
+        if key not in store:
             if math == hip.MATH_F16X2:
                 planes, row_scale = split_f16x2_host(wp)
-                self._split[key] = (wp, planes.to(self.device), row_scale)
+                store[key] = (wp, planes.to(self.device), row_scale)
             else:
-                self._split[key] = (wp, split_planes_host(wp, math).to(self.device), None)
-        return self._split[key][1]
+                store[key] = (wp, split_planes_host(wp, math).to(self.device), None)
+        return store[key][1]
 
     def descaled(self, scale, wp, in_scale):
-        """Epilogue scale of a DD3D_MATH_F16X2 convolution: scale[n] / (in_scale * row_scale[n]), all powers of two (exact)."""
-        key = (scale.data_ptr(), wp.data_ptr(), float(in_scale))
-        if key not in self._descaled:
-            row_scale = self._split[(wp.data_ptr(), hip.MATH_F16X2)][2]
-            n = scale.numel()
-            self._descaled[key] = (scale, (scale.detach().float().cpu() / (row_scale[:n] * float(in_scale))).to(self.device))
-        return self._descaled[key][1]
+        """Epilogue scale of a DD3D_MATH_F16X2 convolution: scale[n] / (in_scale * row_scale[n]), all powers of two (exact).  Keyed by the
+        VALUES of `scale` (every plan makes fresh device copies of the folded norms: keyed by address, each plan build added entries that
+        were never freed -- round-3 advisor), so all plans / pipeline slots of a model share one vector per (norm, filter, input scale)."""
+        local = wp.data_ptr() in self._split_local
+        row_scale = (self._split_local[wp.data_ptr()] if local else self._split)[(wp.data_ptr(), hip.MATH_F16X2)][2]
+        host = scale.detach().float().cpu().contiguous()
+        key = (hash(host.numpy().tobytes()), host.numel(), wp.data_ptr(), float(in_scale))
+        store = self._split_local[wp.data_ptr()] if local else self._descaled
+        if key not in store:
+            n = host.numel()
+            store[key] = (host / (row_scale[:n] * float(in_scale))).to(self.device)
+        return store[key]
 
     # ------------------------------------------------------------------ helpers
     def buf(self, name, B, H, W, Cc, kind="f32"):
@@ -716,7 +753,8 @@ class PlanBase:
     def _vec(self, t):
         return t.detach().float().contiguous().to(self.device)
 
-    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name="", in_relu=False, weight=None, write_f32=True, write_planes=True):
+    def conv_module(self, conv, vin, vout, relu=False, res=None, norm=None, name="", in_relu=False, weight=None, write_f32=True, write_planes=True,
+                    res_up=False):
         """One Conv2d(+folded norm)(+residual)(+relu) as a single-segment launch.  `weight`: an OIHW filter to use instead of the
         module's (the same filter re-laid for a padded input layout, see `scatter_in_channels`).  `write_f32` / `write_planes`: drop
         one of the output buffer's storages for this producer (e.g. an f32 copy nobody reads)."""
@@ -734,7 +772,7 @@ class PlanBase:
             self.f32_written(vout, name)
             return op
         w, meta = self.pack(weight, cache=not explicit and getattr(conv, "groups", 1) == 1)
-        seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res,
+        seg = {"in": vin, "out": vout, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "res": res, "res_up": bool(res_up),
                "write_f32": write_f32, "write_planes": write_planes}
         op = ConvOp(self, meta, conv.stride, conv.padding, [seg], relu, name=name, in_relu=in_relu)
         self.ops.append(op)
@@ -744,6 +782,14 @@ class PlanBase:
 
     def maxpool(self, vin, vout, name="pool"):
         assert vin.C == vout.C and vout.H * 2 == vin.H and vout.W * 2 == vin.W
+        if not vin.has_f32:  # the map exists as split planes only: pool the planes (the winners' terms are copied)
+            assert vin.np and vout.np == vin.np and not vout.has_f32 and vin.C % 32 == 0, (name, vin.np, vout.np, vout.has_f32)
+
+            def _fq(lib, st, vin=vin, vout=vout):
+                hip.check(lib.dd3d_maxpool2x2_planes_in(vin.pptr, vout.pptr, vin.B, vin.H, vin.W, vin.C, self.math, st), name)
+
+            self.ops.append(CallOp(_fq, name, dict(kind="maxpool2x2", vin=vin, vout=vout, planes=True, in_form="planes")))
+            return
         if vout.np and vout.C % 32 == 0:  # pooled map + its split planes in one launch
 
             def _fp(lib, st, vin=vin, vout=vout):
@@ -970,6 +1016,12 @@ class ForwardPlan(PlanBase):
             self.join(join)
         self.conv_module(m.conv2, mid.view(), out, relu=True, res=residual, name=name + ".conv2", write_f32=out_f32)
 
+    @property
+    def _twin(self):
+        """Storage kind of a tensor that convolutions read AND a residual add / 2x2 pool / top-down sum reads: planes only when those
+        consumers read planes (planes_only), else both."""
+        return "planes" if self.planes_only else "both"
+
     def _tree(self, m, x, name, dst=None, cat=None, bottom=None, bottom_branch=None):
         """Tree.forward (dla.py:233-247) with the root's torch.cat realised by channel placement: the root reads
         one NHWC buffer [x2 | x1 | children...] whose slices are written in place by their producers."""
@@ -978,7 +1030,7 @@ class ForwardPlan(PlanBase):
         oc, ic = m.out_channels, m.in_channels
         if m.levels == 1:
             if cat is None:
-                cat = self.buf(name + ".cat", B, Ho, Wo, m.root_dim, kind="both")  # root input (planes); x1 / bottom also feed residual adds (f32)
+                cat = self.buf(name + ".cat", B, Ho, Wo, m.root_dim, kind=self._twin)  # root input (planes); x1 / bottom also feed residual adds
                 if m.level_root:
                     bottom = cat.view(2 * oc, ic)
                     if m.stride > 1:
@@ -992,14 +1044,14 @@ class ForwardPlan(PlanBase):
             side = bottom_branch
             if bottom is None:
                 if m.stride > 1:
-                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic, kind="both").view()
+                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic, kind=self._twin).view()
                     with self.branch(1):
                         self.maxpool(x, bottom, name + ".pool")
                     side = 1
                 else:
                     bottom = x
             if m.project is not None:
-                residual = self.buf(name + ".proj", B, Ho, Wo, oc).view()
+                residual = self.buf(name + ".proj", B, Ho, Wo, oc, kind="planes" if self.planes_only else "f32").view()
                 with self.branch(1):
                     self.conv_module(m.project, bottom, residual, name=name + ".project")
                 side = 1
@@ -1009,11 +1061,11 @@ class ForwardPlan(PlanBase):
             self._block(m.tree1, x, residual, x1, name + ".tree1", join=side)
             self._block(m.tree2, x1, x1, x2, name + ".tree2", out_f32=not x2.np)  # x2 only feeds the root (planes)
             if dst is None:
-                dst = self.buf(name + ".out", B, Ho, Wo, oc, kind="both").view()  # next level: conv input + max-pool input
+                dst = self.buf(name + ".out", B, Ho, Wo, oc, kind=self._twin).view()  # next level: conv input + max-pool input
             self.conv_module(m.root.conv, cat.view(), dst, relu=True, name=name + ".root")
             return dst
         assert m.levels == 2, "DLA-34 only nests trees two deep"
-        cat2 = self.buf(name + ".cat", B, Ho, Wo, m.tree2.root_dim, kind="both")
+        cat2 = self.buf(name + ".cat", B, Ho, Wo, m.tree2.root_dim, kind=self._twin)
         off = 2 * oc
         bottom = None
         bb = None
@@ -1050,7 +1102,7 @@ class ForwardPlan(PlanBase):
             inner = m
             while inner.levels > 1:
                 inner = inner.tree2
-            cat = self.buf(name + ".cat", B, Ho, Wo, inner.root_dim, kind="both")
+            cat = self.buf(name + ".cat", B, Ho, Wo, inner.root_dim, kind=self._twin)
             off = 2 * oc
             if m.level_root:
                 if m.stride == 1:
@@ -1061,19 +1113,19 @@ class ForwardPlan(PlanBase):
         if m.levels == 1:
             if bottom is None:
                 if m.stride > 1:
-                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic, kind="both").view()
+                    bottom = self.buf(name + ".bottom", B, Ho, Wo, ic, kind=self._twin).view()
                     self.maxpool(x, bottom, name + ".pool")
                 else:
                     bottom = x
             residual = bottom
             if m.project is not None:
-                residual = self.buf(name + ".proj", B, Ho, Wo, oc).view()
+                residual = self.buf(name + ".proj", B, Ho, Wo, oc, kind="planes" if self.planes_only else "f32").view()
                 self.conv_module(m.project, bottom, residual, name=name + ".project")
             x1, x2 = cat.view(oc, oc), cat.view(0, oc)
             self._block_any(m.tree1, x, residual, x1, name + ".tree1")
             self._block_any(m.tree2, x1, x1, x2, name + ".tree2")
             if dst is None:
-                dst = self.buf(name + ".out", B, Ho, Wo, oc, kind="both").view()
+                dst = self.buf(name + ".out", B, Ho, Wo, oc, kind=self._twin).view()
             self.conv_module(m.root.conv, cat.view(), dst, relu=True, res=x2 if m.root.residual else None, name=name + ".root")
             return dst
         t1 = cat.view(off, oc)
@@ -1101,7 +1153,7 @@ class ForwardPlan(PlanBase):
         B, H, W = self.B, self.Hp, self.Wp
         ch = dla.channels
         if self.fused_stem:
-            y = self.buf("level1.0", B, H // 2, W // 2, ch[1], kind="both")  # level2: conv input (planes) + max-pool input (f32)
+            y = self.buf("level1.0", B, H // 2, W // 2, ch[1], kind=self._twin)  # level2: conv input + max-pool input
             self.ops.append(FusedStemOp(self, self.model, [dla.base_layer, dla.level0[0], dla.level1[0]], y.view(), name="stem"))
             x = y.view()
         else:
@@ -1213,9 +1265,36 @@ class ForwardPlan(PlanBase):
         # pyramid outputs feed convolutions only (towers, P6); DD3D_KEEP_F32=1 keeps f32 copies too (debugging)
         import os
         p_kind = "both" if os.environ.get("DD3D_KEEP_F32", "0") == "1" else "planes"
+        assert fpn._fuse_type == "sum", "FUSE_TYPE avg is not used by any reference config"
+        fused = self.planes_only and self.use_planes  # top-down sum inside the lateral convolution's epilogue (res_mode 3)
+        lats = {}
+        if fused:
+            # [ext d2 FPN.forward]: prev = lateral(f) + interpolate(prev, x2, nearest); out = output_conv(prev) -- coarsest level first.  The
+            # lateral convolution of a finer level reads the coarser level's SUM out of its split planes (pixel (h/2, w/2)) and adds it in
+            # its epilogue: no f32 twin of the laterals, no fpn_topdown launches.
+            prev = None
+            for idx in range(len(names)):
+                f = feats[names[-idx - 1]]
+                st = fpn.stages[-idx - 1]
+                lat = self.buf(f"fpn_lateral{st}", f.B, f.H, f.W, fpn._out_feature_channels[f"p{st}"], kind="planes").view()
+                lats[st] = lat
+                up_ok = prev is not None and (2 * prev.H, 2 * prev.W) == (lat.H, lat.W)
+                assert prev is None or up_ok, "FPN levels whose sizes are not exact halves do not occur on a size-divisible canvas"
+                self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}", res=prev, res_up=prev is not None)
+                out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C, kind=p_kind).view()
+                if idx == 0:
+                    self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
+                    results[f"p{st}"] = out
+                    self._top_block(fpn, results, p_kind)
+                else:
+                    self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
+                    results[f"p{st}"] = out
+                prev = lat
+            self.fpn_tail_join = 3 if fpn.top_block is not None else None
+            return OrderedDict((n, results[n]) for n in fpn._out_features)
+        # ---- round-3 lowering (f32 math, DD3D_PLANES=0, DD3D_PLANES_ONLY=0): laterals as f32 (+ planes), separate top-down launches
         # The laterals of the finer levels only need backbone features: side branch 2, beside lateral/output of the coarsest
         # level; P6/P7 only need the coarsest output: side branch 3, beside the rest of the top-down path.
-        lats = {}
         for idx in list(range(1, len(names))) + [0]:  # side-branch ops first: a branch forks where its first op sits in the list
             f = feats[names[-idx - 1]]
             st = fpn.stages[-idx - 1]
@@ -1230,30 +1309,7 @@ class ForwardPlan(PlanBase):
             else:
                 with self.branch(2):  # (its planes are written after the top-down sum)
                     self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}", write_planes=False)
-        assert fpn._fuse_type == "sum", "FUSE_TYPE avg is not used by any reference config"
-        if fpn.top_block is not None:
-            st = fpn.stages[-1]
-            x = results[f"p{st}"]  # in_feature "p5" is an FPN output (dla.py:550-557)
-            p6 = self.buf(f"p{st + 1}", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C, kind="both").view()
-            with self.branch(3):
-                self.conv_module(fpn.top_block.p6, x, p6, name="top_block.p6")
-            results[f"p{st + 1}"] = p6
-            if fpn.top_block.num_levels == 2:
-                p7 = self.buf(f"p{st + 2}", p6.B, (p6.H + 1) // 2, (p6.W + 1) // 2, p6.C, kind=p_kind).view()
-                with self.branch(3):
-                    if p6.np:
-                        # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the planes of relu(p6), split from its f32 copy
-                        p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C, kind="planes").view()
-                        self.split(p6, relu=True, dst=p6r, name="top_block.p6.relu")
-                        self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
-                    elif self.math == hip.MATH_BF16X3:
-                        # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the conv rectifies its input while splitting it
-                        self.conv_module(fpn.top_block.p7, p6, p7, name="top_block.p7", in_relu=True)
-                    else:  # f32-MFMA mode: a rectified copy of p6 from a second run of its conv
-                        p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C).view()
-                        self.conv_module(fpn.top_block.p6, x, p6r, relu=True, name="top_block.p6.relu")
-                        self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
-                results[f"p{st + 2}"] = p7
+        self._top_block(fpn, results, p_kind)
         prev = lats[fpn.stages[-1]]
         for idx in range(1, len(names)):
             f = feats[names[-idx - 1]]
@@ -1268,6 +1324,53 @@ class ForwardPlan(PlanBase):
             results[f"p{st}"] = out
         self.fpn_tail_join = 3 if fpn.top_block is not None else None
         return OrderedDict((n, results[n]) for n in fpn._out_features)
+
+    def _top_block(self, fpn, results, p_kind):
+        """LastLevelP6P7 / LastLevelP6 [ext; built at dla.py:550-557]: p6 = conv(p5), p7 = conv(relu(p6)), on side branch 3."""
+        if fpn.top_block is None:
+            return
+        st = fpn.stages[-1]
+        x = results[f"p{st}"]  # in_feature "p5" is an FPN output (dla.py:550-557)
+        two = fpn.top_block.num_levels == 2
+        Ho, Wo = (x.H + 1) // 2, (x.W + 1) // 2
+        if two and self.planes_only and self.use_planes and x.np:
+            # ONE launch, two segments on the same input and filter: p6 (what the towers read) and relu(p6) (what the p7 convolution
+            # reads; per-channel lower clamp 0) -- both as planes, no f32 twin of p6 and no separate split launch
+            conv = fpn.top_block.p6
+            p6 = self.buf(f"p{st + 1}", x.B, Ho, Wo, x.C, kind=p_kind).view()
+            p6r = self.buf(f"p{st + 1}.relu", x.B, Ho, Wo, x.C, kind="planes").view()
+            scale, shift = fold_norm(conv, None)
+            w, meta = self.pack(dense_filter(conv))
+            segs = [{"in": x, "out": o, "w": w, "scale": self._vec(scale), "bias": self._vec(shift), "lo": lo, "algorithmic": lo is None}
+                    for o, lo in ((p6, None), (p6r, self._vec(torch.zeros(conv.out_channels))))]
+            with self.branch(3):
+                self.ops.append(ConvOp(self, meta, conv.stride, conv.padding, segs, relu=False, name="top_block.p6"))
+            results[f"p{st + 1}"] = p6
+            p7 = self.buf(f"p{st + 2}", x.B, (Ho + 1) // 2, (Wo + 1) // 2, x.C, kind=p_kind).view()
+            with self.branch(3):
+                self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
+            results[f"p{st + 2}"] = p7
+            return
+        p6 = self.buf(f"p{st + 1}", x.B, Ho, Wo, x.C, kind="both" if two else p_kind).view()
+        with self.branch(3):
+            self.conv_module(fpn.top_block.p6, x, p6, name="top_block.p6")
+        results[f"p{st + 1}"] = p6
+        if two:
+            p7 = self.buf(f"p{st + 2}", p6.B, (p6.H + 1) // 2, (p6.W + 1) // 2, p6.C, kind=p_kind).view()
+            with self.branch(3):
+                if p6.np:
+                    # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the planes of relu(p6), split from its f32 copy
+                    p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C, kind="planes").view()
+                    self.split(p6, relu=True, dst=p6r, name="top_block.p6.relu")
+                    self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
+                elif self.math == hip.MATH_BF16X3:
+                    # p7 = conv(relu(p6)) [ext LastLevelP6P7]: the conv rectifies its input while splitting it
+                    self.conv_module(fpn.top_block.p7, p6, p7, name="top_block.p7", in_relu=True)
+                else:  # f32-MFMA mode: a rectified copy of p6 from a second run of its conv
+                    p6r = self.buf(f"p{st + 1}.relu", p6.B, p6.H, p6.W, p6.C).view()
+                    self.conv_module(fpn.top_block.p6, x, p6r, relu=True, name="top_block.p6.relu")
+                    self.conv_module(fpn.top_block.p7, p6r, p7, name="top_block.p7")
+            results[f"p{st + 2}"] = p7
 
     # ------------------------------------------------------------------ heads (fcos2d.py:130-156, fcos3d.py:160-188)
     def _heads(self, model, feats):

@@ -73,21 +73,31 @@ def padded_inference_shard(total_size, group_size, rank, world_size, batch_size)
     The reference's sampler hands the tail ranks fewer items or none (KITTI val on 8 GPUs: 7 x 472 + 465), and its forward has no
     collective, so ranks may stop early.  Here every step of every rank takes part in one all_gather: a rank that stops early -- or the
     short final batch of a shard -- would leave the others waiting in RCCL until the watchdog fires.  This helper pads every rank's
-    shard to the SAME number of whole batches, steps = ceil(shard_size / batch_size) of the largest shard: padding entries repeat the
-    rank's last real index (rank with an empty shard: index 0, any valid image) and carry valid = False; the caller feeds them like
-    any other image and drops their outputs (`DistributedForward.forward(batch, valid=...)` does).  batch_size must be a multiple of
-    group_size so that a nuScenes sample never straddles two steps."""
+    shard to the SAME number of whole batches, steps = ceil(shard_size / batch_size) of the largest shard; padding entries carry
+    valid = False, the caller feeds them like any other image and drops their outputs (`DistributedForward.forward(batch, valid=...)`
+    does).  batch_size must be a multiple of group_size so that a nuScenes sample never straddles two steps.
+
+    **No batch ever holds a group twice** (round-3 advisor: repeating the rank's last group put one nuScenes sample twice into a padded
+    batch of two or more groups; NuscenesDD3D's sample grouping -- nuscenes_dd3d.py:77-87 get_group_idxs -- then sees 12 images under one
+    sample_token and raises on the tail rank only, while its peers wait in the step's collective).  Padding groups are whole dataset groups
+    that the batch does not hold yet: first the rank's own, from the start of its shard, then -- a shard with fewer groups than a batch --
+    the dataset's, in order."""
     assert batch_size > 0 and batch_size % group_size == 0, "a step's batch must hold whole groups"
     own = list(inference_shard(total_size, group_size, rank, world_size))
     largest = len(inference_shard(total_size, group_size, 0, world_size))  # rank 0 always holds a full shard
     steps = -(-largest // batch_size)
-    n = steps * batch_size
-    fill = own[-group_size:] if own else list(range(group_size))  # a whole group, so that padded nuScenes batches stay group-complete
-    idx, valid = list(own), [True] * len(own)
-    while len(idx) < n:
-        idx += fill
-        valid += [False] * len(fill)
-    return idx[:n], valid[:n]
+    per_batch, num_groups = batch_size // group_size, total_size // group_size
+    assert per_batch <= num_groups, f"a batch of {per_batch} groups cannot be filled with distinct groups of a dataset that has {num_groups}"
+    own_groups = [i // group_size for i in own[::group_size]]
+    pool = own_groups + [g for g in range(num_groups) if g not in set(own_groups)]  # candidates for padding, in order of preference
+    idx, valid = [], []
+    for st in range(steps):
+        real = own_groups[st * per_batch:(st + 1) * per_batch]
+        fill = [g for g in pool if g not in set(real)][:per_batch - len(real)]
+        for g, v in [(g, True) for g in real] + [(g, False) for g in fill]:
+            idx += list(range(g * group_size, (g + 1) * group_size))
+            valid += [v] * group_size
+    return idx, valid
 
 
 def gather_candidates(pairs, group=None):
@@ -235,6 +245,8 @@ class PipelinedForward:
             slot.released.record()
             slot.requests = [None] * self.microbatch  # (inputs, image_sizes) of the requests staged into the slot
             slot.fill, slot.enqueued, slot.generation = 0, True, 0
+            slot.seq = -1  # order of acquisition (submission order of the slot's requests)
+            slot.collected = [False] * self.microbatch  # requests whose result the caller already holds
             slot.compute_stream = self.compute_streams[i % compute_streams]
             self.slots.append(slot)
         self._geometry = (Hp, Wp)
@@ -289,9 +301,12 @@ class PipelinedForward:
         self.model.math = "bf16x3"
         self.model._plans.clear()
         self._build_plans()
-        for slot in self.slots:
+        # Only slots that still owe a result are re-run (a slot whose requests were all collected would only add a collective), and in
+        # SUBMISSION order -- the order in which their collectives were first issued, which every rank shares (round-3 advisor: slot-index
+        # order differs from it once the ring has wrapped).
+        for slot in sorted(self.slots, key=lambda sl: sl.seq):
             staged = [(j, r) for j, r in enumerate(slot.requests[:slot.fill]) if r is not None]
-            if slot.generation == 0 or not staged:
+            if slot.generation == 0 or not staged or all(slot.collected[j] for j, _ in staged):
                 continue
             with torch.cuda.stream(slot.compute_stream):
                 for j, (inputs, _) in staged:
@@ -323,6 +338,9 @@ class PipelinedForward:
         slot.compute_stream.wait_event(slot.released)
         slot.fill, slot.enqueued = 0, False
         slot.generation += 1
+        slot.seq = self._next
+        slot.requests = [None] * self.microbatch
+        slot.collected = [False] * self.microbatch
         return slot
 
     def _position(self):
@@ -382,6 +400,7 @@ class PipelinedForward:
             self._fall_back(e)  # (raises unless this is one rank on the default arithmetic)
             slot.post_done.synchronize()
             out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
+        slot.collected[j] = True
         slot.released.record()  # the copies out of the detection buffer are enqueued: later steps of this slot order after them
         return out
 

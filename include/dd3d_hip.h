@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DD3D_ABI_VERSION 3
+#define DD3D_ABI_VERSION 4
 
 #define DD3D_OK 0
 #define DD3D_E_INVALID (-1)  /* bad argument (shape / alignment / enum) */
@@ -69,13 +69,19 @@ typedef struct dd3d_conv_seg {  /* array lives in DEVICE memory */
   const float* scale;  /* [N] folded-norm / Scale multiplier                                     */
   const float* bias;   /* [N] folded-norm shift / conv bias / Offset                             */
   const float* lo;     /* [N] per-channel lower clamp (0 => ReLU on that channel, -inf => none), or NULL */
-  const float* res;    /* residual source (NHWC) or NULL                                         */
+  const float* res;    /* residual source or NULL: f32 NHWC (res_mode 1) or split planes (res_mode 2 / 3, ABI 4) */
   float* out;          /* NHWC output, already offset to the first output channel                */
   int32_t B, H, W;     /* input batch / height / width                                           */
   int32_t Ho, Wo;      /* output height / width                                                   */
   int32_t in_pitch, out_pitch, res_pitch; /* floats per pixel of the respective buffers          */
   int32_t M;           /* B*Ho*Wo                                                                */
-  int32_t res_mode;    /* 0 none, 1 add res[m, n] (same pixel) before the clamp                  */
+  int32_t res_mode;    /* 0 none; 1 add the f32 value res[m * res_pitch + n] (same pixel) before the clamp;
+                          ABI 4, split-plane-input kernels only: the residual is read from SPLIT PLANES of the launch's arithmetic mode,
+                          `res` = first chunk of the slice, [ceil(N/32)][pixels][NP][32] terms of value * out_plane_scale:
+                          2 same pixel (pixels = M) -- dla.py:59-60 without an f32 twin of the residual source;
+                          3 the map at HALF the resolution, pixel (b, ho/2, wo/2) of B x Ho/2 x Wo/2 (Ho, Wo even): the FPN top-down
+                            path's F.interpolate(scale 2, nearest) + add [ext d2 FPN.forward] fused into the lateral convolution.
+                          DD3D_TILE_256x256_W8 carries no residual (its waves have no registers left for one). */
   const void* in_planes; /* split-plane input [Cin/32][B*H*W][NP][32], first chunk of the slice; read instead of `in` when
                             dd3d_conv_launch.in_planes is set                                    */
   int32_t n_limit;     /* > 0: this segment stores only output channels < n_limit (<= launch N); 0: all N  */
@@ -182,6 +188,9 @@ int dd3d_split_planes(const float* in, void* out, int32_t M, int32_t C, int32_t 
  * C % 32 == 0.  dd3d_maxpool2x2_planes: `out` (f32) may be NULL.  plane_scale / status as in dd3d_split_planes. */
 int dd3d_maxpool2x2_planes(const float* in, float* out, void* out_planes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t in_pitch,
                            int32_t out_pitch, int32_t math_mode, float plane_scale, int32_t* status, void* stream);
+/* ABI 4: 2x2 / stride 2 max-pool (dla.py:228-231 Tree.downsample) of a map held as split planes ONLY: in_planes [C/32][B*H*W][NP][32] ->
+ * out_planes [C/32][B*(H/2)*(W/2)][NP][32]; per channel the terms of the largest of the four values are copied (no re-split). */
+int dd3d_maxpool2x2_planes_in(const void* in_planes, void* out_planes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t math_mode, void* stream);
 int dd3d_upsample2x_add_planes(float* fine, const float* coarse, void* fine_planes, int32_t B, int32_t H, int32_t W, int32_t C, int32_t fine_pitch,
                                int32_t coarse_pitch, int32_t math_mode, float plane_scale, int32_t* status, void* stream);
 

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# synthetic-weight calibrations of the backbone specs that only the CPU plan emulation exercises (not shipped in the package)
+os.environ.setdefault("DD3D_CALIB_DIR", os.path.join(ROOT, "tests", "data"))
 
 
 def _usable_cores():

@@ -4,7 +4,7 @@
 
 Runs the CPU oracle on synthetic image 0 at the benchmark resolution and records, for every norm layer, the
 (mean, std) of its input activation and, for every predictor conv, a (gain, bias) -- see
-dd3d_amd/synthetic.py.  Output: dd3d_amd/data/synth_calib_<tag>.json (a few KB).
+dd3d_amd/synthetic.py.  Output: dd3d_amd/data/synth_calib_<tag>.json (a few KB; the backbone specs the package does not ship: tests/data/).
 """
 import json
 import os
@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+os.environ.setdefault("DD3D_CALIB_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "data"))  # (specs outside the package: tests/data)
 import dd3d_amd.modeling  # noqa: E402,F401
 from dd3d_amd import META_ARCH_REGISTRY, get_cfg  # noqa: E402
 from dd3d_amd.synthetic import calib_path, make_inputs, make_state_dict  # noqa: E402

@@ -13,6 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
+os.environ.setdefault("DD3D_CALIB_DIR", os.path.join(HERE, "..", "data"))  # calibrations of the backbone specs the package does not ship
 
 from tests.golden import ref_shims  # noqa: E402
 

@@ -29,7 +29,10 @@ def _conv(d):
         acc = F.conv2d(x, w, None, stride=d["stride"], padding=d["pad"])
         y = acc * s["scale"][:n].view(1, -1, 1, 1) + s["bias"][:n].view(1, -1, 1, 1)
         if s.get("res") is not None:
-            y = y + s["res"].buf.t[..., s["res"].c0:s["res"].c0 + n].permute(0, 3, 1, 2)
+            r = s["res"].buf.t[..., s["res"].c0:s["res"].c0 + n].permute(0, 3, 1, 2)
+            if s.get("res_up"):  # the FPN top-down sum fused into the lateral convolution (dd3d_conv_seg.res_mode 3)
+                r = F.interpolate(r, scale_factor=2, mode="nearest")
+            y = y + r
         lo = torch.full((n, ), float("-inf")) if s.get("lo") is None else s["lo"][:n].clone()
         if d["relu"]:
             lo = lo.clamp(min=0.0)
@@ -89,10 +92,11 @@ class Forms:
 def _track(forms, name, d):
     k = d["kind"]
     if k == "conv":
-        for sg, (wf, wp) in zip(d["segs"], d["out_forms"]):
+        for sg, (wf, wp), rform in zip(d["segs"], d["out_forms"], d["res_forms"]):
             forms.reads(sg["in"], d["in_form"], name)
             if sg.get("res") is not None:
-                forms.reads(sg["res"], "f32", name + " (residual)", d["meta"]["N"])
+                assert rform in ("f32", "planes", "planes_up") and (rform == "planes_up") == bool(sg.get("res_up")), (name, rform)
+                forms.reads(sg["res"], "f32" if rform == "f32" else "planes", name + " (residual)", d["meta"]["N"])
             n = int(sg.get("n_limit") or d["meta"]["N"])
             if wf:
                 forms.wrote(sg["out"], "f32", n)
@@ -104,15 +108,17 @@ def _track(forms, name, d):
     elif k == "preprocess":
         forms.wrote(d["img"].view(), "f32")
     elif k == "fused_stem":
-        forms.wrote(d["vout"], "f32")
+        if d["vout"].buf.has_f32:
+            forms.wrote(d["vout"], "f32")
         if d["planes"]:
             forms.wrote(d["vout"], "planes")
     elif k == "split_planes":
         forms.reads(d["src"], "f32", name)
         forms.wrote(d["dst"], "planes")
     elif k in ("maxpool2x2", "maxpool3x3s2_ceil"):
-        forms.reads(d["vin"], "f32", name)
-        forms.wrote(d["vout"], "f32")
+        forms.reads(d["vin"], d.get("in_form", "f32"), name)
+        if d["vout"].buf.has_f32 and d.get("in_form", "f32") == "f32":
+            forms.wrote(d["vout"], "f32")
         if d.get("planes"):
             forms.wrote(d["vout"], "planes")
     elif k == "upsample2x_add":

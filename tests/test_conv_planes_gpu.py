@@ -55,10 +55,10 @@ ROW_CASES = [  # 3x3 / stride 1: the row-shared kernel (csrc/conv_planes_row.hip
     ("row_t42_sk3", 1, 30, 44, 96, 192, 3, 1, 1, False, False, hip.TILE_256x128_T42, 3),
     ("row_t24_b3", 3, 7, 9, 256, 256, 3, 1, 1, True, False, hip.TILE_128x256_T24, 1),
     ("row_t24_n320", 1, 24, 40, 64, 320, 3, 1, 1, False, True, hip.TILE_128x256_T24, 1),       # two N tiles, the second half empty
-    ("row_w8_256x256", 2, 17, 23, 128, 256, 3, 1, 1, True, True, hip.TILE_256x256_W8, 1),
+    ("row_w8_256x256", 2, 17, 23, 128, 256, 3, 1, 1, True, False, hip.TILE_256x256_W8, 1),  # (this tile carries no residual: registers)
     ("t42_1x1_k448", 1, 24, 40, 448, 128, 1, 1, 0, True, False, hip.TILE_256x128_T42, 1),
     ("t24_s2_sk2", 1, 13, 21, 256, 256, 3, 2, 1, False, False, hip.TILE_128x256_T24, 2),
-    ("w8_1x1", 1, 24, 40, 256, 512, 1, 1, 0, False, True, hip.TILE_256x256_W8, 1),
+    ("w8_1x1", 1, 24, 40, 256, 512, 1, 1, 0, False, False, hip.TILE_256x256_W8, 1),
 ]
 
 
@@ -238,6 +238,103 @@ def test_pool_and_topdown_write_their_planes(hiplib, mode):
         tol = {hip.MATH_F16X2: 2.0**-21, hip.MATH_BF16X2: 2.0**-15}[math]
         assert float((dec - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-8
     assert torch.all(yb.p[0] == 0) and torch.all(yb.p[3] == 0)  # neighbouring chunk images untouched
+
+
+RES_CASES = [
+    # name, B, H, W, Cin, Cout, k, relu, tile, splitk
+    ("block2_128x64w4", 2, 24, 40, 64, 64, 3, True, hip.TILE_128x64_W4, 1),       # DLA level 2 BasicBlock conv2
+    ("block3_64x64w4", 1, 12, 20, 128, 128, 3, True, hip.TILE_64x64_W4, 1),
+    ("block5_sk3_128x64", 1, 6, 10, 96, 160, 3, True, hip.TILE_128x64, 3),         # split-K + residual, a partly filled last chunk
+    ("lateral_1x1_256x128", 2, 12, 20, 128, 256, 1, False, hip.TILE_256x128, 1),   # FPN lateral
+    ("lateral_1x1_t42", 1, 24, 40, 64, 256, 1, False, hip.TILE_256x128_T42, 1),
+    ("lateral_model_choice", 1, 48, 160, 128, 256, 1, False, None, None),
+]
+
+
+@pytest.mark.parametrize("res_form", ["f32", "planes", "planes_up"])
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("case", RES_CASES, ids=[c[0] for c in RES_CASES])
+def test_residual_forms(hiplib, case, mode, res_form):
+    """dd3d_conv_seg.res_mode 1 / 2 / 3 (ABI 4): the residual as an f32 map, as split planes of the same pixel (dla.py:59-60 without an
+    f32 twin of the source) and as the split planes of the map at half the resolution (FPN top-down sum [ext] in the lateral's epilogue);
+    the output is written as planes ONLY (what the planes-only data flow does) and decoded for the comparison."""
+    from dd3d_amd.engine import ConvOp, pack_filter
+    name, B, H, W, Cin, Cout, k, relu, tile, splitk = case
+    math, rtol = MODES[mode]
+    g = torch.Generator().manual_seed(sum(map(ord, name)) % 1000 + len(res_form))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k)**0.5
+    scale, bias = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    up = res_form == "planes_up"
+    res = torch.randn(B, Cout, H // 2 if up else H, W // 2 if up else W, generator=g)
+    plan = _plan(math)
+    wp, meta = pack_filter(w, plan.device)
+    xin = plan.buf("x", B, H, W, Cin, kind="both")
+    xin.t.copy_(x.permute(0, 2, 3, 1))
+    plan.split(xin.view(), name="x.split")
+    cpad = (Cout + 31) // 32 * 32
+    # the residual source is a 32-aligned slice of a wider buffer
+    rbuf = plan.buf("r", B, res.shape[2], res.shape[3], cpad + 32, kind="f32" if res_form == "f32" else "both")
+    rbuf.t[..., 32:32 + Cout] = res.permute(0, 2, 3, 1).to(plan.device)
+    if res_form != "f32":
+        plan.split(rbuf.view(32, cpad), name="r.split")
+    yout = plan.buf("y", B, H, W, cpad, kind="planes")
+    seg = {"in": xin.view(), "out": yout.view(), "w": wp, "scale": scale.to(plan.device), "bias": bias.to(plan.device), "res": rbuf.view(32, cpad),
+           "res_up": up}
+    op = ConvOp(plan, meta, 1, k // 2, [seg], relu, tile=tile, splitk=splitk, name=name, math=math)
+    assert op.in_planes and op.res_forms == [res_form]
+    plan.ops.append(op)
+    plan.launch()
+    torch.cuda.synchronize()
+    assert int(plan.status.cpu()) == 0
+    r = rbuf.nchw(32, Cout).cpu() if res_form == "f32" else None
+    if r is None:  # what the planes hold (lossy in the reduced modes)
+        if math == hip.MATH_F16X2:
+            terms = rbuf.p[1:].view(torch.float16).float() / rbuf.plane_scale
+        else:
+            terms = (rbuf.p[1:].to(torch.int32) << 16).view(torch.float32)
+        r = terms.sum(2).permute(1, 0, 2).reshape(B, res.shape[2], res.shape[3], cpad).permute(0, 3, 1, 2)[:, :Cout].cpu()
+    if up:
+        r = F.interpolate(r, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(x, w, None, padding=k // 2) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + r
+    if relu:
+        ref = F.relu(ref)
+    got = yout.nchw().cpu()
+    assert torch.all(got[:, Cout:] == 0)
+    # the output exists as planes only: its own rounding on top of the convolution's
+    out_step = {hip.MATH_BF16X3: 0.0, hip.MATH_F16X2: 2.0**-21, hip.MATH_BF16X2: 2.0**-15, hip.MATH_BF16: 2.0**-8}[math]
+    tol = (rtol + out_step) * max(1.0, ref.abs().max().item())
+    err = (got[:, :Cout] - ref).abs().max().item()
+    assert err <= tol, f"{name}/{mode}/{res_form}: max abs err {err:.3e} > {tol:.3e} (info {op.info})"
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_pool_of_planes_copies_the_winners_terms(hiplib, mode):
+    """dd3d_maxpool2x2_planes_in (ABI 4): the pooled planes decode to max_pool2d of the decoded input planes, bit for bit, for a channel
+    slice placed in a wider (concat) buffer."""
+    math, _ = MODES[mode]
+    plan = _plan(math)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 96, 10, 14, generator=g)
+    x[:, :, :2] = -x[:, :, :2].abs()  # windows of negative values only
+    xb = plan.buf("x", 3, 10, 14, 160, kind="both")
+    xb.t[..., 32:128] = x.permute(0, 2, 3, 1).to(plan.device)
+    plan.split(xb.view(32, 96), name="x.split")
+    xin = plan.buf("xp", 3, 10, 14, 96, kind="planes")
+    yb = plan.buf("y", 3, 5, 7, 160, kind="planes")
+    plan.launch()
+    torch.cuda.synchronize()
+    xin.p.copy_(xb.p[1:4])
+    yb.p.fill_(0x0777)
+    plan.ops[:] = []
+    plan.maxpool(xin.view(), yb.view(64, 96))
+    assert len(plan.ops) == 1
+    plan.launch()
+    torch.cuda.synchronize()
+    want = F.max_pool2d(xin.nchw().cpu(), 2, 2)
+    got = yb.nchw(64, 96).cpu()
+    assert torch.equal(got, want)
+    assert torch.all(yb.p[:2] == 0x0777)  # chunk images before the slice untouched
 
 
 def test_split_modes_against_float64(hiplib):

@@ -124,7 +124,7 @@ def test_cabi_exports_match_header(hiplib):
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert getattr(hiplib, name) is not None
-    assert hiplib.dd3d_abi_version() == hip.ABI_VERSION == 3 and hiplib.dd3d_arch() == b"gfx950"
+    assert hiplib.dd3d_abi_version() == hip.ABI_VERSION == 4 and hiplib.dd3d_arch() == b"gfx950"
     import ctypes as C
     bm, bn = C.c_int32(), C.c_int32()
     for cfg_id, shape in hip.TILE_SHAPES.items():

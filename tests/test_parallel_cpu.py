@@ -163,6 +163,36 @@ def test_padded_shards_give_every_rank_the_same_number_of_steps():
             assert all(0 <= i < total for i in idx) and valid == sorted(valid, reverse=True)
             pad = [i for i, v in zip(idx, valid) if not v]
             assert len(pad) % group == 0 and all(pad[k] // group == pad[k - k % group] // group for k in range(len(pad)))  # whole groups
+            # every step's batch holds `batch / group` DISTINCT whole groups (round-3 advisor: a repeated nuScenes sample in one batch makes
+            # the reference's sample grouping raise on the padded rank only)
+            for st in range(0, len(idx), batch):
+                step = idx[st:st + batch]
+                assert all(step[k] == step[k - k % group] + k % group for k in range(batch))  # in-order members of whole groups
+                assert len({i // group for i in step}) == batch // group
+
+
+def test_padded_batches_pass_the_reference_sample_grouping():
+    """Every padded batch through the arithmetic of nuscenes_dd3d.py:77-87 (get_group_idxs: images are grouped by sample_token and every
+    group must hold exactly num_images_per_sample members) -- the check that raised on the tail rank with round 3's padding."""
+    from collections import defaultdict
+    from dd3d_amd.parallel import padded_inference_shard
+
+    def get_group_idxs(sample_tokens, num_images_per_sample):
+        groups = defaultdict(list)
+        for i, tok in enumerate(sample_tokens):
+            groups[tok].append(i)
+        if not all(len(g) == num_images_per_sample for g in groups.values()):
+            raise ValueError("Group sizes does not match")
+        return list(groups.values())
+
+    for total, group, world, batch in [(18, 6, 2, 12), (36114, 6, 8, 12), (42, 6, 4, 18), (12, 6, 4, 12), (30, 6, 8, 24)]:
+        for r in range(world):
+            idx, valid = padded_inference_shard(total, group, r, world, batch)
+            for st in range(0, len(idx), batch):
+                tokens = [f"sample{i // group}" for i in idx[st:st + batch]]
+                assert len(get_group_idxs(tokens, group)) == batch // group
+    with pytest.raises(AssertionError, match="distinct groups"):
+        padded_inference_shard(12, 6, 0, 2, 18)  # a batch of three samples out of a dataset of two
 
 
 def test_inference_shard_follows_the_reference_group_sampler():
