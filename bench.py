@@ -165,9 +165,18 @@ def main():
         model.stage_inputs(inputs, plan=plan)  # H2D once: inputs are resident in HBM when the timed region starts
     torch.cuda.synchronize()
 
+    backend = dist.get_backend() if world > 1 else None
+
     def barrier():
         if world > 1:
             dist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")  # (gloo: the host-staged test transport)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     flush = getattr(runner, "flush", lambda: None)  # (a partly filled micro-batch slot runs in full before the clock stops)
     # untimed warm-up: --warmup steps, but never fewer than two rounds over every slot of the pipeline (round 2's driver command,
@@ -186,11 +195,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -206,12 +211,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        eb = time.perf_counter() - tb
-        if world > 1:
-            t = torch.tensor([eb], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            eb = float(t.item())
-        block_ms.append(eb / args.steps * 1e3)
+        block_ms.append(max_over_ranks(time.perf_counter() - tb) / args.steps * 1e3)
 
     # for transparency: the same forward issued strictly one slot at a time on one stream (not part of the timed region)
     serial_ms = None
@@ -227,6 +227,25 @@ def main():
             slot.post_graph.replay()
         torch.cuda.synchronize()
         serial_ms = (time.perf_counter() - t1) / 50 * 1e3 / args.microbatch  # (one replay covers `microbatch` requests)
+
+    # The TRUE bs=1 path (BASELINE.json configs[1] read literally: one image per launch, one request at a time, nothing else in flight):
+    # its own one-image launch plan, one hipGraph replay per image, the host waiting for each.  Not part of the timed region.
+    bs1_ms = None
+    if world == 1 and args.pipeline > 0 and not args.no_graph:
+        one = model.get_plan(B, *_padded(model, args.height, args.width))
+        model.stage_inputs(inputs, plan=one)
+        if one.graph is None:
+            one.capture()
+        for _ in range(5):
+            one.run()
+        torch.cuda.synchronize()
+        reps = 40
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            one.run()
+            torch.cuda.synchronize()  # one request at a time: the next image is not issued before this one's detections exist
+        bs1_ms = (time.perf_counter() - t1) / reps * 1e3
+        one.check_status()
 
     for pl in ([sl.plan for sl in runner.slots] if hasattr(runner, "slots") else [plan]):
         pl.check_status()  # a half-range overflow of the f16x2 arithmetic would invalidate the run: fail loudly
@@ -257,6 +276,18 @@ def main():
             "ms_per_step_one_slot_at_a_time": None if serial_ms is None else round(serial_ms, 4),
             "images_per_s_one_slot_at_a_time": None if serial_ms is None else round(B / serial_ms * 1e3, 2),
             "frac_of_mfma_peak_whole_forward": round(value / world * GFLOP_PER_IMAGE / 1e3 / peak, 4),
+            # configs[1] read literally -- ONE image per launch, one request at a time, the host waiting for each (its own bs-image plan):
+            "bs1_ms_per_image": None if bs1_ms is None else round(bs1_ms / B, 4),
+            "bs1_images_per_s": None if bs1_ms is None else round(B / bs1_ms * 1e3, 2),
+            # what a request waits in the issue mode `value` is measured in: from the moment its slot is full, the slot's forward alone
+            # on the chip; with every slot in flight (the timed region), slots x microbatch requests are in the system (Little's law)
+            "request_latency_ms": None if (serial_ms is None or not args.pipeline) else {
+                "slot_forward_alone": round(serial_ms * args.microbatch, 4),
+                "pipeline_full": round(args.pipeline * args.microbatch * ms_per_step, 4),
+                "one_image_at_a_time": None if bs1_ms is None else round(bs1_ms, 4),
+                "note": "a request of the shipped mode also waits for its slot's micro-batch to fill (arrival-rate dependent, not included)"},
+            "transport": None if world == 1 else ("rccl (torch.distributed backend nccl)" if backend == "nccl" else
+                                                  f"{backend}: host-staged TEST transport of the N > 1 code path -- NOT RCCL, not a scaling number"),
         },
         "blocks": {"n": len(block_ms), "steps_each": args.steps, "ms_per_step": [round(x, 4) for x in block_ms],
                    "median_ms_per_step": round(srt[len(srt) // 2], 4), "min_ms_per_step": round(srt[0], 4), "max_ms_per_step": round(srt[-1], 4),

@@ -387,10 +387,16 @@ constexpr bool epi_residual_ok() { return !(TM * TN >= 8 && WM * WN >= 8); }
 
 template <int TM, int TN, int MODE, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
-                                                int wn, int lane, const unsigned char* evec) {
+                                                int wn, int lane, const unsigned char* evec, unsigned char* scratch) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BN = TN * 32 * WN;
   constexpr bool RES = epi_residual_ok<TM, TN, WM, WN>();
+  // `scratch` (DD3D_EPI_LDS): this wave's private NP * 2 KiB of LDS.  The split planes of a 32 x 32 accumulator block are ONE contiguous
+  // run of memory, [pixel][plane][64 B] -- 32 pixels x NP x 64 B -- but a lane holds a pixel's HALF rows (32 bytes per plane).  Stored
+  // straight from the registers, an instruction writes 64 scattered 16-byte pieces (two per 64-byte row: twice the write requests, all
+  // of them partial lines).  Staged through LDS in the memory layout (16-byte units XOR-swizzled so that both sides are conflict-free)
+  // and read back in address order, every store instruction of the wave writes 1 KiB of consecutive bytes.
+  constexpr int UP = NP * 4;  // 16-byte units per pixel
   constexpr int IG = (TM * TN >= 8 || TM < 2) ? 1 : 2;  // accumulator blocks whose residuals are in flight together
   constexpr int NRAW = 2 * NP > 4 ? 2 * NP : 4;          // 16-byte pieces of one block's residual (f32: 4, planes: 2 per plane)
   const int nlim = s.n_limit > 0 ? s.n_limit : a.N;
@@ -508,9 +514,39 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
               ovf |= !(fabsf(e0) <= 65504.f) | !(fabsf(e1) <= 65504.f);
               if (report && mv) amx = fmaxf(amx, fmaxf(fabsf(e0), fabsf(e1)));
             }
+#ifdef DD3D_ABLATE_EPI_VALU  // (timing experiment: the stores without the arithmetic in front of them)
+            w[t][0] = __float_as_uint(acc[i][j][2 * t]);
+            if constexpr (NP > 1) w[t][1] = __float_as_uint(acc[i][j][2 * t + 1]);
+            if constexpr (NP > 2) w[t][2] = 0;
+#else
             split_pack<MODE>(e0, e1, w[t]);
+#endif
           }
-          if (mv) {
+          if (scratch != nullptr) {
+            // unit (pixel px, plane p, 16-byte slot 2 h + jj) -> LDS slot px * UP + swizzled unit index
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const int u = p * 4 + 2 * h + jj;
+                const int us = NP == 2 ? (u ^ (px & 7)) : (p * 4 + ((2 * h + jj) ^ (px & 3)));
+                *reinterpret_cast<u32x4*>(scratch + (px * UP + us) * 16) = u32x4{w[4 * jj][p], w[4 * jj + 1][p], w[4 * jj + 2][p], w[4 * jj + 3][p]};
+              }
+            const int mblk = m0 + (wm * TM + i) * 32;  // first pixel of the block
+            const gbp dst = (gbp)s.out_planes + (long)(nb >> 5) * cstride + (long)mblk * (NP * 64);
+#pragma unroll
+            for (int k = 0; k < 2 * NP; ++k) {
+              const int U = 64 * k + lane;  // linear 16-byte unit of the block's run
+              const int pp = U / UP, u = U - pp * UP;
+              const int us = NP == 2 ? (u ^ (pp & 7)) : ((u & ~3) + ((u & 3) ^ (pp & 3)));
+              const u32x4 val = *reinterpret_cast<const u32x4*>(scratch + (pp * UP + us) * 16);
+#ifdef DD3D_ABLATE_EPI_STORE  // (timing experiment: everything but the global stores)
+              if (mblk + pp < s.M && a.relu == 12345) *(gu4p)(dst + (long)U * 16) = val;
+#else
+              if (mblk + pp < s.M) *(gu4p)(dst + (long)U * 16) = val;
+#endif
+            }
+          } else if (mv) {
             const gbp dst = (gbp)s.out_planes + (long)(nb >> 5) * cstride + (long)m * (NP * 64) + h * 32;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {

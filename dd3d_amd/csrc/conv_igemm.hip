@@ -839,7 +839,7 @@ extern "C" int dd3d_math_planes(int32_t math_mode) {
 }
 
 extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) {
-  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {128, 256}, {256, 256}};
+  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {128, 256}, {256, 256}, {128, 32}};
   DD3D_REQUIRE(tile_cfg >= 0 && tile_cfg < DD3D_TILE_COUNT, "dd3d_conv_tile_shape: unknown tile_cfg %d", tile_cfg);
   *bm = shapes[tile_cfg][0];
   *bn = shapes[tile_cfg][1];

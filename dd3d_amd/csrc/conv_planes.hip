@@ -53,6 +53,9 @@ __device__ __forceinline__ void sched_interleave() {
 #ifndef DD3D_LDS_KIB_4W
 #define DD3D_LDS_KIB_4W 72
 #endif
+#ifndef DD3D_EPI_LDS
+#define DD3D_EPI_LDS 1  // 1: the transposed epilogue stages its plane stores through LDS (1 KiB of consecutive bytes per store instruction); 0: straight from the registers (A/B)
+#endif
 #ifndef DD3D_EPI_T
 #define DD3D_EPI_T 1  // 1: transposed accumulators + the 16-bytes-per-lane epilogue (conv_common.h::conv_epilogue_t); 0: round-3 form (A/B)
 #endif
@@ -423,7 +426,18 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
 #if DD3D_EPI_T
-  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF);
+#if DD3D_EPI_LDS
+  // plane stores staged through LDS (conv_epilogue_t): the rings are dead, but other waves' surplus LDS-DMAs / fragment reads of the last
+  // K steps may still touch them -- every wave has waited for its own (vmcnt(0) above), one barrier makes that true for all of them
+  unsigned char* scratch = nullptr;
+  if (s.out_planes != nullptr) {
+    __syncthreads();
+    scratch = lds + wave * (NP * 2048);
+  }
+  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, scratch);
+#else
+  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, nullptr);
+#endif
 #else
   conv_epilogue<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);
 #endif
@@ -475,6 +489,7 @@ static int launch_planes_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st)
     case DD3D_TILE_64x64_W4K2:
     case DD3D_TILE_64x64_W4: return launch_planes_tile<1, 1, 2, 2, MODE>(ka, st);
     case DD3D_TILE_128x64_W4: return launch_planes_tile<2, 1, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_128x32_W4: return launch_planes_tile<1, 1, 4, 1, MODE>(ka, st);
     case DD3D_TILE_256x128_T42: return launch_planes_tile<4, 2, 2, 2, MODE>(ka, st);
     case DD3D_TILE_128x256_T24: return launch_planes_tile<2, 4, 2, 2, MODE>(ka, st);
     case DD3D_TILE_256x256_W8:

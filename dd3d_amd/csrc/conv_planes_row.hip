@@ -25,6 +25,9 @@
 #ifndef DD3D_ROW_LDS_KIB_4W
 #define DD3D_ROW_LDS_KIB_4W 76
 #endif
+#ifndef DD3D_EPI_LDS
+#define DD3D_EPI_LDS 1  // 1: the transposed epilogue stages its plane stores through LDS (1 KiB of consecutive bytes per store instruction); 0: straight from the registers (A/B)
+#endif
 #ifndef DD3D_EPI_T
 #define DD3D_EPI_T 1  // 1: transposed accumulators + the 16-bytes-per-lane epilogue (conv_common.h::conv_epilogue_t); 0: round-3 form (A/B)
 #endif
@@ -127,12 +130,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     }
     ld_g += (ld_g + 1 < g_begin + ngroup);
   };
+  // (DD3D_ABLATE_*: timing experiments only -- wrong results -- that remove one ingredient of the K loop; tests/tools/r04_ablate.sh)
+  bool in_loop = false;
   auto emit_a = [&](int stage) {
+#ifdef DD3D_ABLATE_DMA
+    if (in_loop) return;
+#endif
 #pragma unroll
     for (int q = 0; q < PA; ++q)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)nxt_a[q], (ldsbp)(lds + stage * A_STAGE + a_dst[q]), 16, 0, 0);
   };
   auto emit_b = [&](int stage) {  // K-tile ld_kt, then advance
+#ifdef DD3D_ABLATE_DMA
+    if (in_loop) return;
+#endif
     const long koff = (long)ld_kt * (NP * 64);
 #pragma unroll
     for (int q = 0; q < PB; ++q)
@@ -183,11 +194,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     }
   }
 
+#ifdef DD3D_ABLATE_DSREAD
+  bf16x8 fa[2][TM][NP] = {}, fb[2][TN][NP] = {};
+#else
   bf16x8 fa[2][TM][NP], fb[2][TN][NP];
+#endif
   // An invalid (pixel, tap) reads 16 zero bytes kept behind the rings instead of its LDS row: one address select per fragment read,
   // computed before the read is issued (masking the loaded registers would make every MFMA phase wait for its own prefetch).
   auto read_frags = [&](int sa, int sb, int dw, int tap, auto c_c) {
     constexpr int c = decltype(c_c)::value;
+#ifdef DD3D_ABLATE_DSREAD
+    if (a.relu != 12345) return;
+#endif
     const int abase = sa * A_STAGE + fa_off[dw][c];
     const unsigned char* Bs = lds + B_BASE + sb * B_STAGE + fb_off[c];
 #pragma unroll
@@ -213,6 +231,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   constexpr int PB_[6] = {0, NP == 3 ? 2 : (NP == 2 ? 1 : 0), NP == 3 ? 1 : 0, 0, 1, 0};
   auto mfma_chunk = [&](auto c_c) {
     constexpr int c = decltype(c_c)::value;
+#ifdef DD3D_ABLATE_MFMA
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < NPROD; ++t)
 #pragma unroll
@@ -291,6 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     constexpr std::integral_constant<int, 1> D1{};
     constexpr std::integral_constant<int, 2> D2{};
     int dh = g_begin % 3;
+    in_loop = true;
     for (int g = 0; g < ngroup; ++g) {
       const int sa = g & 1;
       step(sa, dh, D0);
@@ -304,8 +326,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if constexpr (SK) {
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
+#ifdef DD3D_ABLATE_EPI
+  if (a.relu != 12345) return;
+#endif
 #if DD3D_EPI_T
-  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF);
+#if DD3D_EPI_LDS
+  // plane stores staged through LDS (conv_epilogue_t): the rings are dead, but other waves' surplus LDS-DMAs / fragment reads of the last
+  // K steps may still touch them -- every wave has waited for its own (vmcnt(0) above), one barrier makes that true for all of them
+  unsigned char* scratch = nullptr;
+  if (s.out_planes != nullptr) {
+    __syncthreads();
+    scratch = lds + wave * (NP * 2048);
+  }
+  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, scratch);
+#else
+  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, nullptr);
+#endif
 #else
   conv_epilogue<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);
 #endif
@@ -354,6 +390,7 @@ static int launch_row_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st) {
     case DD3D_TILE_64x64_W4K2:
     case DD3D_TILE_64x64_W4: return launch_row_tile<1, 1, 2, 2, MODE>(ka, st);
     case DD3D_TILE_128x64_W4: return launch_row_tile<2, 1, 2, 2, MODE>(ka, st);
+    case DD3D_TILE_128x32_W4: return launch_row_tile<1, 1, 4, 1, MODE>(ka, st);
     case DD3D_TILE_256x128_T42: return launch_row_tile<4, 2, 2, 2, MODE>(ka, st);
     case DD3D_TILE_128x256_T24: return launch_row_tile<2, 4, 2, 2, MODE>(ka, st);
     case DD3D_TILE_256x256_W8:

@@ -312,7 +312,7 @@ MATH_TILES = {  # tile configurations instantiated per arithmetic mode
 }
 # the split-plane kernel (csrc/conv_planes.hip): one barrier per K-tile for every tile, so no "two K-tiles per barrier" variants
 PLANE_TILES = (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4, hip.TILE_128x64_W4,
-               hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8)
+               hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8, hip.TILE_128x32_W4)
 BIG_WAVE_TILES = (hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8)  # 8 accumulator blocks per wave; picked by the measured table only
 PLANE_TILE_ALIAS = {hip.TILE_128x64_K2: hip.TILE_128x64, hip.TILE_64x128_K2: hip.TILE_64x128, hip.TILE_64x64_W4K2: hip.TILE_64x64_W4}
 for _m in (hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2):
@@ -341,7 +341,8 @@ def kernel_signature(op):
     cfg = op.L.tile_cfg
     tm_tn_wm_wn = {hip.TILE_256x128: (2, 2, 4, 2), hip.TILE_128x128: (2, 1, 2, 4), hip.TILE_128x64: (1, 1, 4, 2), hip.TILE_64x128: (1, 1, 2, 4),
                    hip.TILE_128x128_W4: (2, 2, 2, 2), hip.TILE_64x64_W4: (1, 1, 2, 2), hip.TILE_128x64_W4: (2, 1, 2, 2),
-                   hip.TILE_256x128_T42: (4, 2, 2, 2), hip.TILE_128x256_T24: (2, 4, 2, 2), hip.TILE_256x256_W8: (4, 2, 2, 4)}
+                   hip.TILE_256x128_T42: (4, 2, 2, 2), hip.TILE_128x256_T24: (2, 4, 2, 2), hip.TILE_256x256_W8: (4, 2, 2, 4),
+                   hip.TILE_128x32_W4: (1, 1, 4, 1)}
     sk = "true" if op.L.splitk > 1 else "false"
     if op.in_planes:
         tm, tn, wm, wn = tm_tn_wm_wn[PLANE_TILE_ALIAS.get(cfg, cfg)]
@@ -400,7 +401,7 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
     nk = Kpad // 32
     best = None
     for cfg in allowed:
-        if cfg in BIG_WAVE_TILES:
+        if cfg in BIG_WAVE_TILES or cfg == hip.TILE_128x32_W4:
             continue  # (no analytic model: the measured table or an explicit `tile=` selects them)
         bm, bn = hip.TILE_SHAPES[cfg]
         if bn == 32 and N > 32:
@@ -1272,7 +1273,11 @@ class ForwardPlan(PlanBase):
             # [ext d2 FPN.forward]: prev = lateral(f) + interpolate(prev, x2, nearest); out = output_conv(prev) -- coarsest level first.  The
             # lateral convolution of a finer level reads the coarser level's SUM out of its split planes (pixel (h/2, w/2)) and adds it in
             # its epilogue: no f32 twin of the laterals, no fpn_topdown launches.
+            # The output convolutions (3x3, Cout -> Cout on every level) only read their own lateral: ONE multi-segment launch for all
+            # levels after the lateral chain (like a tower layer) instead of a launch per level -- the coarse levels' few tiles fill the
+            # tail of the fine level's grid.  P6 / P7 follow (they read the coarsest output).
             prev = None
+            out_segs, out_meta = [], None
             for idx in range(len(names)):
                 f = feats[names[-idx - 1]]
                 st = fpn.stages[-idx - 1]
@@ -1282,14 +1287,17 @@ class ForwardPlan(PlanBase):
                 assert prev is None or up_ok, "FPN levels whose sizes are not exact halves do not occur on a size-divisible canvas"
                 self.conv_module(getattr(fpn, f"fpn_lateral{st}"), f, lat, name=f"fpn_lateral{st}", res=prev, res_up=prev is not None)
                 out = self.buf(f"p{st}", f.B, f.H, f.W, lat.C, kind=p_kind).view()
-                if idx == 0:
-                    self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
-                    results[f"p{st}"] = out
-                    self._top_block(fpn, results, p_kind)
-                else:
-                    self.conv_module(getattr(fpn, f"fpn_output{st}"), lat, out, name=f"fpn_output{st}")
-                    results[f"p{st}"] = out
+                conv = getattr(fpn, f"fpn_output{st}")
+                scale, shift = fold_norm(conv, None)
+                w, meta = self.pack(dense_filter(conv))
+                assert out_meta is None or {k: meta[k] for k in ("N", "Cin", "KH", "KW", "Kpad")} == {k: out_meta[k] for k in ("N", "Cin", "KH", "KW", "Kpad")}
+                assert (conv.stride, conv.padding) == (1, 1)
+                out_meta = meta
+                out_segs.append({"in": lat, "out": out, "w": w, "scale": self._vec(scale), "bias": self._vec(shift)})
+                results[f"p{st}"] = out
                 prev = lat
+            self.ops.append(ConvOp(self, out_meta, 1, 1, out_segs, relu=False, name="fpn_outputs"))
+            self._top_block(fpn, results, p_kind)
             self.fpn_tail_join = 3 if fpn.top_block is not None else None
             return OrderedDict((n, results[n]) for n in fpn._out_features)
         # ---- round-3 lowering (f32 math, DD3D_PLANES=0, DD3D_PLANES_ONLY=0): laterals as f32 (+ planes), separate top-down launches
@@ -1481,23 +1489,31 @@ class ForwardPlan(PlanBase):
             preds = [list(h3.box3d_quat), list(h3.box3d_ctr), list(h3.box3d_depth), list(h3.box3d_size), list(h3.box3d_conf)]
             self.b3d_maps, self.b3d_pitch = fused_predictor("box3d_map", preds, 2, s3, b3, None)
 
-        # One launch for all predictors of all levels: the narrow ones (C or 5 channels) ride along with the widest (11*C) as
-        # extra segments, their filters zero-padded to its Npad and their stores cut at n_limit -- three launches of 25 us
-        # each become one of about the cost of the widest.
-        n_max = max(m["N"] for _, m, _ in pred_groups)
-        npad = (n_max + 31) // 32 * 32
-        meta = dict(pred_groups[0][1], N=n_max, Npad=npad)
-        all_segs = []
-        for _, m, segs in pred_groups:
-            assert (m["Cin"], m["KH"], m["KW"], m["Kpad"]) == (meta["Cin"], meta["KH"], meta["KW"], meta["Kpad"])
-            for sg in segs:
-                key = ("predictor_pad", sg["w"].data_ptr(), npad)
-                if key not in self._packed:  # (the store keeps the source referenced: its address is the key)
-                    wpad = torch.zeros((npad, m["Kpad"]), dtype=torch.float32, device=dev)
-                    wpad[:sg["w"].shape[0]] = sg["w"]
-                    self._packed[key] = (sg["w"], wpad)
-                all_segs.append(dict(sg, w=self._packed[key][1]))
-        self.ops.append(ConvOp(self, meta, 1, 1, all_segs, relu=False, name="predictors"))
+        # Predictor launches.  Round 3: ONE launch, the narrow groups (C or 5 channels) riding along with the widest (11 * C) as extra
+        # segments zero-padded to its Npad -- 192 executed output columns for 63 useful ones, and a kernel form that skipped the unstored
+        # column blocks changed nothing (the idle waves still sat behind the block's barriers).  Round 4: the groups of <= 32 channels
+        # (cls logits (+ nuScenes attr / speed), box2d + centerness) run on the 32-column tile DD3D_TILE_128x32_W4 in their own launch --
+        # blocks for columns nobody stores are never created -- and the wide group(s) keep the measured tile.  DD3D_PRED_SPLIT=0: round 3's form.
+        split = os.environ.get("DD3D_PRED_SPLIT", "1") != "0" and self.use_planes
+        narrow = [g for g in pred_groups if split and g[1]["N"] <= 32]
+        wide = [g for g in pred_groups if g not in narrow]
+        for groups, tile, name in ((narrow, hip.TILE_128x32_W4, "predictors.narrow"), (wide, None, "predictors")):
+            if not groups:
+                continue
+            n_max = max(m["N"] for _, m, _ in groups)
+            npad = (n_max + 31) // 32 * 32
+            meta = dict(groups[0][1], N=n_max, Npad=npad)
+            all_segs = []
+            for _, m, segs in groups:
+                assert (m["Cin"], m["KH"], m["KW"], m["Kpad"]) == (meta["Cin"], meta["KH"], meta["KW"], meta["Kpad"])
+                for sg in segs:
+                    key = ("predictor_pad", sg["w"].data_ptr(), npad)
+                    if key not in self._packed:  # (the store keeps the source referenced: its address is the key)
+                        wpad = torch.zeros((npad, m["Kpad"]), dtype=torch.float32, device=dev)
+                        wpad[:sg["w"].shape[0]] = sg["w"]
+                        self._packed[key] = (sg["w"], wpad)
+                    all_segs.append(dict(sg, w=self._packed[key][1]))
+            self.ops.append(ConvOp(self, meta, 1, 1, all_segs, relu=False, name=name, tile=tile if npad == 32 else None))
 
     # ------------------------------------------------------------------ selection / decode / NMS
     def _postprocess(self, model, world_size, rank=0):

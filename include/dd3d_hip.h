@@ -171,7 +171,8 @@ int dd3d_math_planes(int32_t math_mode);
 #define DD3D_TILE_256x128_T42 12 /* 4 waves (2 x 2), wave tile 128 x 64 */
 #define DD3D_TILE_128x256_T24 13 /* 4 waves (2 x 2), wave tile 64 x 128 */
 #define DD3D_TILE_256x256_W8 14  /* 8 waves (2 x 4), wave tile 128 x 64; one- and two-term modes only */
-#define DD3D_TILE_COUNT 15
+#define DD3D_TILE_128x32_W4 15   /* split-plane kernels: 4 waves (4 x 1), 32 output columns -- the narrow predictors (N <= 32: fcos2d.py:96-110) */
+#define DD3D_TILE_COUNT 16
 /* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
 int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
 int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);

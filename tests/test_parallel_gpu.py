@@ -49,3 +49,34 @@ def test_pipelined_forward_equals_stepwise(hiplib, mode):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "ok=True" in r.stdout
+
+
+@pytest.mark.parametrize("pipeline", ["default", "0"])
+def test_bench_multi_gpu_command_line(hiplib, pipeline):
+    """The driver's N > 1 command, literally -- `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...` -- with two
+    ranks sharing the one GPU of the test box over the host-staged gloo test transport (round-3 verdict: the first 8-GPU run must not be
+    the first execution of bench.py's N > 1 lines).  Checks the JSON line the driver parses: whole-job value, n_gpus, the parallelism
+    string, no pipeline error -- and that the line says the transport was NOT RCCL."""
+    import json
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DD3D_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--repeat-blocks", "1"]
+    if pipeline != "default":
+        cmd += ["--pipeline", pipeline]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 1 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]  # whole-job images / s = ranks x batch / step time
+    c = d["config"]
+    assert c["parallelism"] == "dp2+rccl_allgather_candidates" and c["global_batch"] == 2 and c["pipeline_error"] is None
+    assert c["pipeline_slots"] == (0 if pipeline == "0" else 5)
+    assert "NOT RCCL" in c["transport"] and "gloo" in c["transport"]
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d

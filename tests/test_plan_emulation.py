@@ -72,7 +72,7 @@ def test_emulated_plan_matches_oracle(hiplib, name):
             _, st = N.nuscenes_dd3d_forward(sd, cfg, inputs)
         else:
             _, st = O.dd3d_forward(sd, cfg, inputs, stop_after_heads=True)
-    assert "predictors" in done
+    assert "predictors" in done or "predictors.narrow" in done  # (every group of <= 32 channels: one launch on the 32-column tile)
 
     def close(got, ref, what):
         err = float((got - ref).abs().max())
@@ -261,6 +261,6 @@ def test_storage_forms_are_consistent_in_every_math_mode(hiplib, name, math, mon
     model.stage_inputs(make_inputs(B, H, W, dataset=ds), plan=plan)
     with torch.no_grad():
         done = emulate(plan)
-    assert "predictors" in done
+    assert "predictors" in done or "predictors.narrow" in done  # (every group of <= 32 channels: one launch on the 32-column tile)
     forms = {op.info["in_form"] for op in plan.ops if isinstance(op, ConvOp) and op.L.Cin % 32 == 0}
     assert forms == ({"planes"} if plan.use_planes else {"f32"}), forms

@@ -106,7 +106,11 @@ def test_predictor_folding_reproduces_the_reference_heads(hiplib, name):
     model.load_state_dict(sd, strict=True)
     model.math = "bf16x3"  # the filter layout decoded below (three bf16 planes); the folding itself does not depend on the arithmetic
     plan = ForwardPlan(model, 1, 128, 256, device="cpu", dry_run=True)
-    op = [o for o in plan.ops if isinstance(o, ConvOp) and o.name == "predictors"][0]
+    # (round 4: the groups of <= 32 channels -- cls, box2d + centerness -- run in their own launch on the 32-column tile, the wide box3d
+    # group in another; their segments, in group order, are what round 3's single launch held)
+    pops = [o for o in plan.ops if isinstance(o, ConvOp) and o.name in ("predictors.narrow", "predictors")]
+    assert pops and pops[0].name == "predictors.narrow" and pops[0].info["tile"] == (128, 32) and len(pops) <= 2  # (class-agnostic box3d: 11 channels, all narrow)
+    op = type("Segs", (), {"keep": [k for o in pops for k in o.keep]})()
     with torch.no_grad():
         _, st = O.dd3d_forward(sd, cfg, case_inputs(1, 128, 256, False, "kitti"), stop_after_heads=True)
         L = len(st["features"])
