@@ -18,7 +18,7 @@ Every slot's graphs are replayed once at construction and the untimed warm-up co
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch of the slot's plan:
 conv_igemm_planes_row_kernel<4,2,2,4,2,4,false> of csrc/conv_planes_row.hip at the default four images per launch): algorithmic FLOPs of
 one launch / its mean duration measured here with HIP events on the launch stream (``traffic``: the PMC-derived HBM bytes of that launch
-geometry, profiles/r03_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: dd3d_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
+geometry, profiles/r03_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: tests/tools' dd3d_tools_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
 matrix products spent per f32 product (``--math``: f16x2 3, bf16x3 6, bf16x2 3, bf16 1; the f32-input MFMA peak 157.3 TFLOP/s for f32).
 ``blocks`` repeats the timed block a few times so that a reader can tell box / clock variance from a regression.  ``cpu_baseline`` is
 the CPU oracle (a restatement "port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
@@ -102,12 +102,15 @@ def kernel_time_us(plan, op, iters=5, burst=8):
 
 
 def mfma_ceiling_tflops(blocks=256, iters=1500):
-    """The matrix pipe's rate on realistic operand bits, measured NOW on this chip (libdd3d_hip's dd3d_mfma_probe: the tower kernel's MFMA
+    """The matrix pipe's rate on realistic operand bits, measured NOW on this chip (tests/tools/src/mfma_probe.hip: the tower kernel's MFMA
     instruction and wave tile on register-resident operands, no memory traffic): the two-half-term planes of gaussian values, half of the
     activation (A) values zero as after a ReLU.  The data decides the rate (zeros: 0.98 of nominal), the chip and its thermal state the rest."""
     import ctypes as C
     from dd3d_amd import hip
-    lib = hip.lib()
+    # (bench / test tooling, not the product library: tests/tools/src/mfma_probe.hip -> tests/tools/lib/libdd3d_tools.so, built by
+    # __graft_entry__.build(); absent -> the caller reports no measured ceiling)
+    lib = C.CDLL(os.path.join(ROOT, "tests", "tools", "lib", "libdd3d_tools.so"))
+    lib.dd3d_tools_mfma_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     g = torch.Generator(device="cuda").manual_seed(7)
     x = torch.randn((blocks * 512, 4, 4, 8), device="cuda", generator=g) * 4.0  # [thread][set][A row 0, A row 1, B col 0, B col 1][8]
     x[:, :, :2] *= (torch.rand(x[:, :, :2].shape, device="cuda", generator=g) < 0.5)
@@ -120,7 +123,8 @@ def mfma_ceiling_tflops(blocks=256, iters=1500):
     for rep in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        hip.check(lib.dd3d_mfma_probe(ops.data_ptr(), blocks, iters, sink.data_ptr(), st), "mfma probe")
+        if lib.dd3d_tools_mfma_probe(ops.data_ptr(), blocks, iters, sink.data_ptr(), st) != 0:
+            raise RuntimeError("dd3d_tools_mfma_probe failed")
         e1.record()
         e1.synchronize()
         if rep:  # the first launch ramps the clocks
@@ -316,7 +320,7 @@ def main():
         np_ = hip.MATH_PLANES[plan.math]
         m_rows = towers[0].info["M"]
         alg_bytes = (m_rows * 256 * 2 * np_ * 2 + 3 * 2304 * 256 * 2 * np_) if plan.use_planes else None  # planes in + planes out + split filters
-        # What the matrix pipe sustains on REAL operand bits (dd3d_mfma_probe, timed here; stand-alone: tests/tools/src/mfma_power_bench.hip,
+        # What the matrix pipe sustains on REAL operand bits (dd3d_tools_mfma_probe, timed here; stand-alone: tests/tools/src/mfma_power_bench.hip,
         # profiles/r03_mfma_power_bench.txt, r03l_*): the same v_mfma_f32_32x32x16_f16 stream from registers, no memory traffic, reaches
         # 2.45 PFLOP/s on zeros / constants and 1.45-1.77 PFLOP/s (chip and thermal state) on the two-half-term planes of gaussian data
         # with half of the activations zero -- the chip's power management, not the kernel.
@@ -335,7 +339,7 @@ def main():
             "frac_of_measured_ceiling": (None if math_name == "f32" or not measured_mfma_ceiling_tflops else
                                          round(achieved * PRODUCTS[math_name] / measured_mfma_ceiling_tflops, 4)),
             "ceiling_note": "`frac` is against the nominal dense peak as the contract asks; a register-resident loop of the same MFMA instruction "
-                            "(dd3d_mfma_probe, timed in this run) reaches 0.98 of that peak on zero operands and 0.58-0.71 on realistic ones, "
+                            "(dd3d_tools_mfma_probe, timed in this run) reaches 0.98 of that peak on zero operands and 0.58-0.71 on realistic ones, "
                             "depending on the chip and its thermal state (profiles/r03_mfma_power_bench.txt, r03l_mfma_power_bench_orders.txt)",
             "images_per_launch": plan.B,
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,

@@ -146,11 +146,6 @@ typedef struct dd3d_conv_launch {  /* host memory */
  * watched launches stored a nonzero sampled maximum below `floor` (amax: [n_launches][16][32] floats, see dd3d_conv_launch.amax).  The
  * two words travel in a rank's record; after the all_gather every rank sees every rank's verdict and all act on the same step. */
 int dd3d_fold_range_flags(const int32_t* status, const float* amax, int32_t n_launches, float floor, int32_t* out, void* stream);
-/* Diagnostic: `iters` x 48 v_mfma_f32_32x32x16_f16 per wave on register-resident operands (blocks x 8 waves; the two-half-term products of a
- * 2 x 2 wave tile), no memory traffic in the loop -- what the matrix pipe of this chip sustains on the caller's operand BITS.
- *   ops  halves [blocks * 512 threads][4 sets][8 fragments: A hi0, hi1, lo0, lo1, B hi0, hi1, lo0, lo1][8]; sink: one device float
- * FLOP per launch = 2 * 32 * 32 * 16 * 48 * iters * blocks * 8.  bench.py times it (HIP events) beside the convolution it reports. */
-int dd3d_mfma_probe(const void* ops, int32_t blocks, int32_t iters, float* sink, void* stream);
 /* planes per value of a math mode (0 for DD3D_MATH_F32) */
 int dd3d_math_planes(int32_t math_mode);
 
