@@ -16,9 +16,9 @@ timed steps does all of its work and is complete before the closing synchronize 
 Every slot's graphs are replayed once at construction and the untimed warm-up covers every slot at least twice, whatever --warmup says.
 
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch of the slot's plan:
-conv_igemm_planes_row_kernel<4,2,2,4,2,4,false> of csrc/conv_planes_row.hip at the default four images per launch): algorithmic FLOPs of
+conv_igemm_planes_row_kernel<4,2,2,4,2,4,false,2> of csrc/conv_planes_row.hip at the default four images per launch): algorithmic FLOPs of
 one launch / its mean duration measured here with HIP events on the launch stream (``traffic``: the PMC-derived HBM bytes of that launch
-geometry, profiles/r03_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: tests/tools' dd3d_tools_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
+geometry, profiles/r04_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: tests/tools' dd3d_tools_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
 matrix products spent per f32 product (``--math``: f16x2 3, bf16x3 6, bf16x2 3, bf16 1; the f32-input MFMA peak 157.3 TFLOP/s for f32).
 ``blocks`` repeats the timed block a few times so that a reader can tell box / clock variance from a regression.  ``cpu_baseline`` is
 the CPU oracle (a restatement "port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--cpu-forwards", type=int, default=200, help="upper bound; the CPU leg stops after ~12 s of work")
     ap.add_argument("--math", default=None, help="arithmetic of the convolutions: f16x2 (default) | bf16x3 | f32 | bf16x2 | bf16 (dd3d_amd.engine.default_math)")
     ap.add_argument("--repeat-blocks", type=int, default=5, help="extra timed blocks of --steps steps each (median / min / max reported in `blocks`)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_tower_hbm_bytes.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_tower_hbm_bytes.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel, keyed by kernel signature (see profiles/README.md)")
     return ap.parse_args()
 

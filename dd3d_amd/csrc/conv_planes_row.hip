@@ -34,7 +34,7 @@
 
 namespace dd3d {
 
-template <int TM, int TN, int WM, int WN, int NSB, int MODE, bool SK>
+template <int TM, int TN, int WM, int WN, int NSB, int MODE, bool SK, int NSA>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(const ConvKArgs a) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BM = TM * 32 * WM;
@@ -44,12 +44,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   constexpr int AROWS = BM + 16;                   // BM + 2 used; whole 16-row DMA blocks
   constexpr int PLA = AROWS * 64, PLB = BN * 64;   // bytes per plane of an A / B stage
   constexpr int A_STAGE = NP * PLA, B_STAGE = NP * PLB;
-  constexpr int B_BASE = 2 * A_STAGE;
+  constexpr int B_BASE = NSA * A_STAGE;
   constexpr int NPA = (AROWS / 16) * NP, NPB = (BN / 16) * NP;  // 1-KiB pieces of an A stage / a B stage
   constexpr int PA = (NPA + NW - 1) / NW, PB = (NPB + NW - 1) / NW;  // per wave (the surplus re-fetches the last piece)
   constexpr int ZERO_OFF = B_BASE + NSB * B_STAGE;  // 16 zero bytes invalid taps read (64 reserved)
   constexpr int EV_OFF = ZERO_OFF + 64;              // [scale | bias | lo][BN] floats of the epilogue (conv_epilogue_t)
-  static_assert(NSB >= 2 && NSB <= 3 && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
+  static_assert(NSB >= 2 && NSB <= 3 && NSA >= 2 && NSA <= 4 && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
@@ -264,14 +264,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if (ngroup <= 0) epi_store_vectors<BN, NTHR>(lds + EV_OFF, tid, evv);  // (an empty K slice: the split-K exchange's barriers publish them)
 #endif
   if (ngroup > 0) {
-    // prologue, in issue order: A(group 0) -> A stage 0 | B(tiles 0 .. NSB-1) | A(group 1) -> A stage 1.  Wait for A(0) and B(0).
+    // prologue, in issue order: A(group 0) -> A stage 0 | B(tiles 0 .. NSB-1) | A(groups 1 .. NSA-1) -> A stages 1 ...  Wait for A(0), B(0).
     prepare_a();
     emit_a(0);
 #pragma unroll
     for (int d = 0; d < NSB; ++d) emit_b(d);
-    prepare_a();
-    emit_a(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 1) * PB + PA) : "memory");
+#pragma unroll
+    for (int d = 1; d < NSA; ++d) {
+      prepare_a();
+      emit_a(d);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 1) * PB + (NSA - 1) * PA) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #if DD3D_EPI_T
@@ -280,8 +283,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     read_frags(0, 0, 0, (g_begin % 3) * 3, C0);
     int sb = 0;
     // One step = one K-tile (filter row dh, column dw).  DMA issue order after the prologue: step s issues B(s + NSB) and, when dw == 2
-    // (the group's A stage has just been read for the last time), A(group + 2) behind it.  "B(s+1) has landed" at step s therefore
-    // means: at most the B tiles s+2 .. s+NSB-1 and the A groups issued in steps s+1-NSB .. s-1 are still in flight.
+    // (the group's A stage has just been read for the last time), A(group + NSA) behind it.  "B(s+1) has landed" at step s therefore
+    // means: at most the B tiles s+2 .. s+NSB-1 and the A groups issued in steps s+1-NSB .. s-1 are still in flight (in the first steps
+    // the prologue's extra A groups sit behind B(1) as well: the counted wait then also waits for them -- conservative, never wrong).
+    // NSA A stages = the A stream runs NSA - 1 groups (3 (NSA - 1) K steps) ahead: the activations of a block are read ONCE, so every
+    // A group is an HBM / MALL round trip, and the short steps of the small tiles (a few hundred cycles) do not cover one with NSA = 2.
     auto step = [&](int sa, int dh, auto dw_c) {
       constexpr int dw = decltype(dw_c)::value;
       const int tap = dh * 3 + dw;
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       if constexpr (dw == 2) emit_a(sa);
       sb = sb == NSB - 1 ? 0 : sb + 1;
       constexpr int ndw = dw == 2 ? 0 : dw + 1;
-      const int nsa = dw == 2 ? sa ^ 1 : sa;
+      const int nsa = dw == 2 ? (sa == NSA - 1 ? 0 : sa + 1) : sa;
       const int ndh = dw == 2 ? (dh == 2 ? 0 : dh + 1) : dh;
       read_frags(nsa, sb, ndw, ndh * 3 + ndw, C0);  // (past the end: surplus data, never used)
       mfma_chunk(C1);
@@ -313,12 +319,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     constexpr std::integral_constant<int, 2> D2{};
     int dh = g_begin % 3;
     in_loop = true;
+    int sa = 0;
     for (int g = 0; g < ngroup; ++g) {
-      const int sa = g & 1;
       step(sa, dh, D0);
       step(sa, dh, D1);
       step(sa, dh, D2);
       dh = dh == 2 ? 0 : dh + 1;
+      sa = sa == NSA - 1 ? 0 : sa + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus fetches land before the LDS is released
   }
@@ -348,32 +355,55 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
+// Ring depths of a tile (also computed by dd3d_amd/engine.py::kernel_signature for the bench's bookkeeping):
+//   NSB  B stages: 3 when two A stages + three B stages fit the block's LDS budget, else 2
+//   NSA  A stages: as many (<= 4) as fit -- a block that fits twice into a CU with NSA = 2 (<= 80 KiB) keeps fitting twice, a block that
+//        owns its CU anyway may grow to the whole budget
+template <int TM, int TN, int WM, int WN, int MODE>
+struct RowRings {
+  static constexpr int NP = Planes<MODE>::NP;
+  static constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN;
+  static constexpr int AST = NP * (BM + 16) * 64, BST = NP * BN * 64;
+  // (a 4-wave block whose two A stages alone exceed half a CU's LDS owns its CU anyway: it takes the 8-wave budget)
+  static constexpr int BUDGET = ((WM * WN == 8 || 2 * AST > 64 * 1024) ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
+  static constexpr int NSB = (2 * AST + 3 * BST <= BUDGET) ? 3 : 2;
+  static constexpr int EXTRA = 64 + 12 * BN;  // the zero bytes invalid taps read + the epilogue vectors
+  static constexpr int total(int nsa) { return nsa * AST + NSB * BST + EXTRA; }
+  static constexpr int LIMIT = total(2) <= 80 * 1024 ? 80 * 1024 : (BUDGET > total(2) ? BUDGET : total(2));
+  // Measured (profiles/r04i_a_ring_depth_ab.txt): 3 - 4 A stages instead of 2 change nothing on the backbone convolutions (level 3 conv2
+  // 33.8 -> 34.8 us, level 2 41.8 -> 43.7) and cost 3 % on the pipelined bench (1568 -> 1522 img/s: the larger blocks share CUs less) --
+  // the small tiles are NOT waiting for their activations.  -DDD3D_ROW_NSA_MAX=4 rebuilds the deeper rings.
+#ifdef DD3D_ROW_NSA_MAX
+  static constexpr int NSA_MAX = DD3D_ROW_NSA_MAX;
+#else
+  static constexpr int NSA_MAX = 2;
+#endif
+  static constexpr int NSA = (NSA_MAX >= 4 && total(4) <= LIMIT) ? 4 : ((NSA_MAX >= 3 && total(3) <= LIMIT) ? 3 : 2);
+};
+
 template <int TM, int TN, int WM, int WN, int MODE, bool ALLOW_SK = true>
 static int launch_row_tile(const ConvKArgs& ka, hipStream_t st) {
-  constexpr int NP = Planes<MODE>::NP;
-  constexpr int BM = TM * 32 * WM, BN = TN * 32 * WN, NTHR = 64 * WM * WN;
-  constexpr int A2 = 2 * NP * (BM + 16) * 64, BST = NP * BN * 64;
-  // (a 4-wave block whose two A stages alone exceed half a CU's LDS owns its CU anyway: it takes the 8-wave budget)
-  constexpr int BUDGET = ((WM * WN == 8 || A2 > 64 * 1024) ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
-  constexpr int NSB = (A2 + 3 * BST <= BUDGET) ? 3 : 2;
-  static_assert(A2 + NSB * BST + 64 + 12 * BN <= 160 * 1024, "tile does not fit the LDS");
-  const size_t lds = (size_t)A2 + (size_t)NSB * BST + 64 + 12 * BN;  // + the zero bytes invalid taps read + the epilogue vectors
+  typedef RowRings<TM, TN, WM, WN, MODE> R;
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int NSB = R::NSB, NSA = R::NSA;
+  static_assert(R::total(NSA) <= 160 * 1024, "tile does not fit the LDS");
+  const size_t lds = (size_t)R::total(NSA);
   dim3 grid(ka.ntiles * ka.nn, ka.splitk, 1);
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
-    if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+    if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false, NSA>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
     if constexpr (ALLOW_SK)
-      if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+      if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true, NSA>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
     lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   if constexpr (!ALLOW_SK) DD3D_REQUIRE(ka.splitk == 1, "dd3d_conv2d_igemm_f32: this tile has no split-K form (its accumulators fill the register file)");
   if constexpr (ALLOW_SK) {
     if (ka.splitk > 1) {
-      hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true>), grid, dim3(NTHR), lds, st, ka);
+      hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true, NSA>), grid, dim3(NTHR), lds, st, ka);
       return check_launch("launch_row_tile split-K kernel");
     }
   }
-  hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false>), grid, dim3(NTHR), lds, st, ka);
+  hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false, NSA>), grid, dim3(NTHR), lds, st, ka);
   return check_launch("conv_igemm_planes_row kernel");
 }
 

@@ -353,9 +353,15 @@ def kernel_signature(op):
         row = (L.KH == 3 and L.KW == 3 and L.stride == 1 and L.pad == 1 and (L.splitk == 1 or -(-nk // L.splitk) % 3 == 0)
                and os.environ.get("DD3D_CONV_ROW", "1") != "0")
         if row:  # csrc/conv_planes_row.hip: the three taps of a filter row share one A stage
-            a2, bst = 2 * np_ * (bm + 16) * 64, np_ * bn * 64
-            nsb = 3 if a2 + 3 * bst <= (152 if (wm * wn == 8 or a2 > 65536) else 76) * 1024 else 2
-            return f"dd3d::conv_igemm_planes_row_kernel<{tm}, {tn}, {wm}, {wn}, {nsb}, {op.math}, {sk}>"
+            # ring depths: csrc/conv_planes_row.hip::RowRings
+            ast, bst = np_ * (bm + 16) * 64, np_ * bn * 64
+            budget = (152 if (wm * wn == 8 or 2 * ast > 65536) else 76) * 1024
+            nsb = 3 if 2 * ast + 3 * bst <= budget else 2
+            total = lambda nsa: nsa * ast + nsb * bst + 64 + 12 * bn
+            limit = 80 * 1024 if total(2) <= 80 * 1024 else max(budget, total(2))
+            nsa_max = int(os.environ.get("DD3D_ROW_NSA_MAX", "2"))  # (the library's build-time default; deeper A rings measured no gain)
+            nsa = 4 if (nsa_max >= 4 and total(4) <= limit) else (3 if (nsa_max >= 3 and total(3) <= limit) else 2)
+            return f"dd3d::conv_igemm_planes_row_kernel<{tm}, {tn}, {wm}, {wn}, {nsb}, {op.math}, {sk}, {nsa}>"
         stage = np_ * (bm + bn) * 64
         ns = max(2, min(4, ((144 if (wm * wn == 8 or stage > 32768) else 72) * 1024) // stage))
         return f"dd3d::conv_igemm_planes_kernel<{tm}, {tn}, {wm}, {wn}, {ns}, {op.math}, {sk}, 0>"

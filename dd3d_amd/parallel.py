@@ -100,6 +100,11 @@ def padded_inference_shard(total_size, group_size, rank, world_size, batch_size)
     return idx, valid
 
 
+def graph_exchange_enabled(group=None):
+    """DD3D_GRAPH_EXCHANGE=1 and a device transport (RCCL): the step's all_gather may be captured inside its hipGraph."""
+    return (os.environ.get("DD3D_GRAPH_EXCHANGE", "0") == "1" and dist.is_initialized() and dist.get_backend(group) == "nccl")
+
+
 def gather_candidates(pairs, group=None):
     """The step's only exchange: all_gather every rank's record (ForwardPlan.gather_pairs(): one (record, [W x record]) pair) into
     the rank-major gathered buffer."""
@@ -133,11 +138,24 @@ class DistributedForward:
         model, (Hp, Wp) = self.model, self._geometry
         model.use_graph = self.use_graph
         self.plan = p = model.get_plan(self.B, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange, camera_sharded=self.camera_sharded)
-        self.pre_graph = self.post_graph = None
+        self.pre_graph = self.post_graph = self.step_graph = None
         if self.use_graph and self.exchange:
             # the collective sits between two captured halves
             p.launch()
             torch.cuda.synchronize()
+            if graph_exchange_enabled():
+                # DD3D_GRAPH_EXCHANGE=1 (experimental; round-3 verdict item): the RCCL all_gather is captured INSIDE the step's graph -- one
+                # replay per step instead of replay / collective / replay.  The communicator is created by an eager collective first (a
+                # capture must not contain its initialisation).  Validated with ONE rank only (tests/gpu_rccl_check.py graph): no
+                # multi-GPU box was available to the builder, hence off by default.
+                gather_candidates(p.gather_pairs())
+                torch.cuda.synchronize()
+                self.step_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.step_graph):
+                    p.launch(0, p.num_pre_nms_ops)
+                    gather_candidates(p.gather_pairs())
+                    p.launch(p.num_pre_nms_ops)
+                return
             self.pre_graph, self.post_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.pre_graph):
                 p.launch(0, p.num_pre_nms_ops)
@@ -148,6 +166,9 @@ class DistributedForward:
         p = self.plan
         if not self.exchange:
             p.run()
+            return
+        if self.step_graph is not None:
+            self.step_graph.replay()  # pre half, RCCL all_gather and post half in one captured graph
             return
         if self.pre_graph is not None:
             self.pre_graph.replay()

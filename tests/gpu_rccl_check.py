@@ -2,7 +2,7 @@
 all_gather between the two captured hipGraph halves (`force_exchange`), device tensors in, device tensors out.  Detections must equal
 the single-graph forward of the same model.  (tests/gpu_dist_check.py covers W = 2 ranks over a host-staged gloo gather.)
 
-    python tests/gpu_rccl_check.py
+    python tests/gpu_rccl_check.py [graph]      graph: DD3D_GRAPH_EXCHANGE=1 -- the all_gather captured INSIDE the step's hipGraph
 """
 import os
 import socket
@@ -21,6 +21,9 @@ def main():
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    one_graph = len(sys.argv) > 1 and sys.argv[1] == "graph"
+    if one_graph:
+        os.environ["DD3D_GRAPH_EXCHANGE"] = "1"
     from dd3d_amd import build_model, get_cfg
     from dd3d_amd.parallel import DistributedForward, gather_candidates
     from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
@@ -37,7 +40,8 @@ def main():
     for use_graph in (False, True):
         runner = DistributedForward(model, B, H + (-H) % 128, W + (-W) % 128, use_graph=use_graph, force_exchange=True)
         p = runner.plan
-        assert p.exchange and p.cand_all.data_ptr() != p.cand.data_ptr() and (not use_graph or runner.pre_graph is not None)
+        assert p.exchange and p.cand_all.data_ptr() != p.cand.data_ptr()
+        assert not use_graph or (runner.step_graph is not None if one_graph else runner.pre_graph is not None)
         p.cand_all.fill_(float("nan"))  # the NMS half must see what RCCL delivered, not stale memory
         out = runner.forward(inputs)
         out = runner.forward(inputs)
@@ -62,7 +66,7 @@ def main():
         gather_candidates(pairs)
     e1.record()
     torch.cuda.synchronize()
-    print(f"rccl check: ok={bool(ok)} exchange {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per step (W=1, {sum(l.numel() * l.element_size() for l, _ in pairs)} B)")
+    print(f"rccl check{' (all_gather inside the graph)' if one_graph else ''}: ok={bool(ok)} exchange {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per step (W=1, {sum(l.numel() * l.element_size() for l, _ in pairs)} B)")
     dist.destroy_process_group()
     assert ok
 

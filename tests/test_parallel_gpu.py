@@ -42,6 +42,14 @@ def test_rccl_transport_single_rank(hiplib):
     assert "rccl check: ok=True" in r.stdout
 
 
+def test_rccl_all_gather_captured_inside_the_step_graph(hiplib):
+    """DD3D_GRAPH_EXCHANGE=1: pre half, RCCL all_gather and post half replayed as ONE hipGraph (single rank: all this box can validate)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_rccl_check.py"), "graph"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rccl check (all_gather inside the graph): ok=True" in r.stdout
+
+
 @pytest.mark.parametrize("mode", ["", "nccl", "streams", "microbatch", "fallback"])
 def test_pipelined_forward_equals_stepwise(hiplib, mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round check on the GPU box: the whole GPU suite, smoke, the driver's bench command, its rocprofv3 kernel stats, per-op in-graph costs,
 # the other BASELINE configurations.   bash tests/tools/round_check.sh <tag>      (writes gpurun_out/<tag>/<tag>_*)
-TAG=${1:-r03z}
+TAG=${1:-r04z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -23,5 +23,7 @@ head -6 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200; head -4 $O/${TAG}_bench_
 rm -rf $O/prof $O/prof_serial
 cd $R
 timeout 200 python tests/gpu_prefix_bench.py 2>&1 | grep -v "amdgpu\|build" > $O/${TAG}_prefix_b1.txt; tail -3 $O/${TAG}_prefix_b1.txt
-timeout 300 python tests/gpu_prefix_bench.py 384 1280 5 2>&1 | grep -v "amdgpu\|build" > $O/${TAG}_prefix_b5.txt; tail -3 $O/${TAG}_prefix_b5.txt
+timeout 300 python tests/gpu_prefix_bench.py 384 1280 4 2>&1 | grep -v "amdgpu\|build" > $O/${TAG}_prefix_b4.txt; tail -3 $O/${TAG}_prefix_b4.txt
+bash tests/tools/tower_traffic.sh 4 gpurun_out/$TAG/${TAG}_tower_hbm_bytes.json | cut -c1-400
+bash tests/tools/tower_traffic.sh 1 gpurun_out/$TAG/${TAG}_tower_hbm_bytes.json | cut -c1-400
 timeout 900 python tests/gpu_configs_check.py 2>&1 | grep dd3d_ | cut -c1-200 | tee $O/${TAG}_configs.txt
