@@ -132,6 +132,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   };
   // (DD3D_ABLATE_*: timing experiments only -- wrong results -- that remove one ingredient of the K loop; tests/tools/r04_ablate.sh)
   bool in_loop = false;
+  bool skip_reads = false;
   auto emit_a = [&](int stage) {
 #ifdef DD3D_ABLATE_DMA
     if (in_loop) return;
@@ -205,6 +206,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     constexpr int c = decltype(c_c)::value;
 #ifdef DD3D_ABLATE_DSREAD
     if (a.relu != 12345) return;
+#endif
+#ifdef DD3D_ABLATE_DSREAD_LOOP  // (timing experiment: fragments of the first A group are re-used -- real operand bits, no LDS reads afterwards)
+    if (skip_reads) return;
 #endif
     const int abase = sa * A_STAGE + fa_off[dw][c];
     const unsigned char* Bs = lds + B_BASE + sb * B_STAGE + fb_off[c];
@@ -300,6 +304,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       constexpr int a_in_flight = NSB == 3 ? (dw != 2 ? 1 : 0) : (dw == 0 ? 1 : 0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 2) * PB + a_in_flight * PA) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef DD3D_EXP_GROUP_BARRIER  // (timing experiment, RACY: what one barrier per A group instead of one per K-tile would buy)
+      if constexpr (dw == 2)
+#endif
       __builtin_amdgcn_s_barrier();  // everyone: K-tile s+1 (and, after dw == 2, the next A group) landed; B stage sb / A stage sa free
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       step(sa, dh, D2);
       dh = dh == 2 ? 0 : dh + 1;
       sa = sa == NSA - 1 ? 0 : sa + 1;
+      skip_reads = true;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus fetches land before the LDS is released
   }
