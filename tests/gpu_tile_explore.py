@@ -49,7 +49,7 @@ def main():
     exp = os.environ.get("DD3D_EXP", "dd3d_kitti_dla34")
     cfg = get_cfg(exp)
     model = build_model(cfg)
-    tag = {"dd3d_kitti_dla34": "dla34_kitti", "dd3d_kitti_v99": "v99_kitti", "dd3d_nusc_dla34": "dla34_nusc"}.get(exp, "dla34_kitti")
+    tag = {"dd3d_kitti_dla34": "dla34_kitti", "dd3d_kitti_v99": "v99_kitti", "dd3d_nusc_dla34": "dla34_nusc", "dd3d_nusc_v99": "v99_nusc"}.get(exp, "dla34_kitti")
     model.load_state_dict(make_state_dict(model, calib=load_calib(tag)))
     model.use_graph = False
     engine.ConvOp.__init__ = _rec_init
