@@ -210,7 +210,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 #ifdef DD3D_ABLATE_DSREAD_LOOP  // (timing experiment: fragments of the first A group are re-used -- real operand bits, no LDS reads afterwards)
     if (skip_reads) return;
 #endif
-    const int abase = sa * A_STAGE + fa_off[dw][c];
+    // One address register per phase (stage + lane part) and the (row block, plane) part as the read's immediate offset; an invalid
+    // (pixel, tap) selects a base that the same immediate brings onto the 16 zero bytes: one v_cndmask per read (round 3: add, select, add;
+    // towers 305 -> 300 us, level 3 35.4 -> 34.0 us, bench +2.5 % on one box: profiles/r04p_a_read_addressing_ab.txt).  Going further --
+    // the vertical validity folded into the LDS-DMA's source select and the three dw masks kept as SGPR lane masks, no v_and / v_cmp in
+    // the loop -- passed the parity suite and measured 0.7 % SLOWER (r04q_*): the compiler's loop then needs 250 registers.
+    const unsigned char* pa = lds + sa * A_STAGE + fa_off[dw][c];
     const unsigned char* Bs = lds + B_BASE + sb * B_STAGE + fb_off[c];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -221,8 +226,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 #endif
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const int off = ok ? abase + p * PLA + i * 32 * 64 : ZERO_OFF;
-        fa[c][i][p] = *reinterpret_cast<const bf16x8*>(lds + off);
+        const int C = p * PLA + i * 32 * 64;  // (compile-time: the loops are unrolled; < 64 KiB, <= ZERO_OFF)
+        const unsigned char* src = ok ? pa : lds + (ZERO_OFF - C);
+        fa[c][i][p] = *reinterpret_cast<const bf16x8*>(src + C);
       }
     }
 #pragma unroll
