@@ -185,7 +185,9 @@ def main():
     flush = getattr(runner, "flush", lambda: None)  # (a partly filled micro-batch slot runs in full before the clock stops)
     # untimed warm-up: --warmup steps, but never fewer than two rounds over every slot of the pipeline (round 2's driver command,
     # --warmup 5 on 16 slots, left 11 slots cold inside the timed block)
-    warm = max(args.warmup, 2 * args.pipeline * args.microbatch) if args.pipeline > 0 else args.warmup
+    # (one step at a time: at least 40 -- twice in five runs of this round the HIP runtime stalled ~50 ms once, somewhere in the first 45
+    # graph replays of a fresh process (profiles/r04z_bench_serial.json, block 1); the untimed warm-up now covers that)
+    warm = max(args.warmup, 2 * args.pipeline * args.microbatch) if args.pipeline > 0 else max(args.warmup, 40)
     for _ in range(warm):
         runner.step()
     flush()
@@ -240,7 +242,7 @@ def main():
         model.stage_inputs(inputs, plan=one)
         if one.graph is None:
             one.capture()
-        for _ in range(5):
+        for _ in range(30):
             one.run()
         torch.cuda.synchronize()
         reps = 40
