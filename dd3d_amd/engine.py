@@ -720,7 +720,7 @@ class PlanBase:
         local = wp.data_ptr() in self._split_local
         row_scale = (self._split_local[wp.data_ptr()] if local else self._split)[(wp.data_ptr(), hip.MATH_F16X2)][2]
         host = scale.detach().float().cpu().contiguous()
-        key = (hash(host.numpy().tobytes()), host.numel(), wp.data_ptr(), float(in_scale))
+        key = (host.numpy().tobytes(), wp.data_ptr(), float(in_scale))  # (the bytes themselves: a few KB per vector, exact)
         store = self._split_local[wp.data_ptr()] if local else self._descaled
         if key not in store:
             n = host.numel()
