@@ -36,6 +36,8 @@ sys.path.insert(0, ROOT)
 # streams then never share a queue.  Measured on one box: 1372 img/s against 1355 with the default, 1344 with 8 (profiles/r03k_hw_queues.txt).
 # Must be in the environment before the HIP runtime starts; an explicit setting of the caller wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(os.environ.get("DD3D_BENCH_COMPUTE_STREAMS", "5")) + 1))
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails with `hipIpcGetMemHandle: invalid argument`); the driver exports it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
