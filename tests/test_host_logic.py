@@ -80,6 +80,36 @@ def test_plan_construction_dry_run(kitti_dla34, hiplib):
         plan.launch()  # no CPU execution path exists
 
 
+def test_planes_only_data_flow_of_the_default_plan(kitti_dla34, hiplib, monkeypatch):
+    """Round 4: nothing between the stem and the predictor maps has an f32 storage -- residual adds, 2x2 pools and the FPN top-down sum read
+    split planes (dd3d_conv_seg.res_mode 2 / 3, dd3d_maxpool2x2_planes_in); DD3D_PLANES_ONLY=0 restores round 3's twins and launches."""
+    from dd3d_amd.engine import ConvOp, ForwardPlan
+    cfg, model, sd = kitti_dla34
+    model.load_state_dict(sd)
+    plan = ForwardPlan(model, 2, 128, 256, device="cpu", dry_run=True)
+    inner = {n: b for n, b in plan.bufs.items() if n.startswith(("level", "fpn_lateral", "p", "tower"))}
+    assert len(inner) > 40 and all(b.np == 2 and not b.has_f32 for b in inner.values()), [n for n, b in inner.items() if b.has_f32]
+    names = [op.name for op in plan.ops]
+    assert "fpn_outputs" in names and not any(n.startswith("fpn_topdown") for n in names) and "top_block.p6.relu" not in names
+    convs = {op.name: op for op in plan.ops if isinstance(op, ConvOp)}
+    assert convs["fpn_lateral5"].res_forms == [None] and convs["fpn_lateral4"].res_forms == ["planes_up"] and convs["fpn_lateral3"].res_forms == ["planes_up"]
+    blocks = [c for n, c in convs.items() if n.endswith(".conv2")]
+    assert len(blocks) == 12 and all(c.res_forms == ["planes"] for c in blocks)  # every BasicBlock's residual add (dla.py:59-60)
+    assert convs["fpn_outputs"].info["nsegs"] == 3 and convs["top_block.p6"].info["nsegs"] == 2  # p6 and relu(p6) from one launch
+    pools = [op for op in plan.ops if op.name.endswith(".pool")]
+    assert len(pools) == 4 and all(op.desc["in_form"] == "planes" for op in pools)
+    assert [op.name for op in plan.ops if op.name.startswith("predictors")] == ["predictors.narrow", "predictors"]
+    assert convs["predictors.narrow"].info["tile"] == (128, 32)
+    monkeypatch.setenv("DD3D_PLANES_ONLY", "0")
+    monkeypatch.setenv("DD3D_PRED_SPLIT", "0")
+    monkeypatch.setenv("DD3D_RES_F32", "1")  # (with the twins present the residuals still prefer the planes unless told otherwise)
+    old = ForwardPlan(model, 2, 128, 256, device="cpu", dry_run=True)
+    onames = [op.name for op in old.ops]
+    assert "fpn_topdown4" in onames and "fpn_output3" in onames and "top_block.p6.relu" in onames and "predictors.narrow" not in onames
+    assert old.bufs["level2.cat"].has_f32 and old.bufs["fpn_lateral3"].has_f32
+    assert all(c.res_forms == ["f32"] for c in old.ops if isinstance(c, ConvOp) and c.name.endswith(".conv2"))
+
+
 def test_registry_and_state_dict_surface(kitti_dla34):
     from dd3d_amd import BACKBONE_REGISTRY, META_ARCH_REGISTRY
     cfg, model, sd = kitti_dla34
