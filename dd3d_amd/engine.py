@@ -405,6 +405,12 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
         cfg = next(c for c, nm in hip.TILE_NAMES.items() if nm == hit[0])
         return (PLANE_TILE_ALIAS.get(cfg, cfg) if planes else cfg), int(hit[1])
     nk = Kpad // 32
+    # Large launches of the two-term modes with N >= 256: the 8-wave 256 x 256 tile (wave tile 128 x 64: one ds_read_b128 per two MFMAs) beat
+    # every other tile by 7-9 % on every such shape measured in round 4 -- head towers, the merged FPN output launch, V2-99's 1 x 1 concat
+    # convolutions, from 158 blocks (profiles/r04h_*, r04t_*) -- so it is the default there, not only where a table entry names it.
+    if planes and hip.MATH_PLANES[math] <= 2 and N >= 256 and hip.TILE_256x256_W8 in allowed and -(-N // 256) * 256 <= 1.15 * N:
+        if sum(-(-m // 256) for m in m_list) * -(-N // 256) >= 150:
+            return hip.TILE_256x256_W8, 1
     best = None
     for cfg in allowed:
         if cfg in BIG_WAVE_TILES or cfg == hip.TILE_128x32_W4:

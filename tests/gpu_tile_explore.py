@@ -61,7 +61,11 @@ def main():
     table = {}
     engine.TILE_TABLE = {m: {} for m in engine.TILE_TABLE}  # measure against the analytic model
     engine.PLANE_TILE_TABLE = {m: {} for m in engine.PLANE_TILE_TABLE}
+    only = os.environ.get("DD3D_EXPLORE_ONLY", "")  # comma-separated op-name prefixes (e.g. the big launches whose other tiles the block limit skips)
+    max_blocks = int(os.environ.get("DD3D_EXPLORE_MAXBLOCKS", "6000"))
     for name, pl, meta, stride, pad, segs, relu, kw in RECORD:
+        if only and not any(name.startswith(o) for o in only.split(",")):
+            continue
         m_list = tuple(s["out"].B * s["out"].H * s["out"].W for s in segs)
         key = (m_list, meta["N"], meta["Kpad"], meta["Cin"], stride)
         if key in seen:
@@ -82,7 +86,7 @@ def main():
             for sk in (1, 2, 3, 4, 6, 8, 12, 16):
                 if sk > 1 and (nk // sk < 3 or blocks * sk > 1300):
                     continue
-                if sk == 1 and blocks > 6000 and cfg_id != cur_cfg:
+                if sk == 1 and blocks > max_blocks and cfg_id != cur_cfg:
                     continue
                 try:
                     op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name, math=math, **{k: v for k, v in kw.items() if k != 'math'})
@@ -103,7 +107,7 @@ def main():
 
     import json
     mname = next(k for k, v in engine.MATH_NAMES.items() if v == plan.math)
-    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}_{mname}{'_planes' if plan.use_planes else ''}.json")
+    out = os.path.join("gpurun_out", f"tile_table_{exp}_{H}x{W}_b{B}_{mname}{'_planes' if plan.use_planes else ''}{'_only' if only else ''}.json")
     os.makedirs("gpurun_out", exist_ok=True)
     with open(out, "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
