@@ -35,7 +35,15 @@ struct StemFusedK {
   dd3d_stem_args a;
 };
 
-constexpr int SF_TH = 8, SF_TW = 32;                      // level1 outputs per block
+// (Measured, profiles/r04w_stem_tile_variants.txt: an 8 x 16 tile on 4-wave blocks -- 78 KiB of LDS, two blocks per CU at different phases -- 164 us
+// for four images against 160 for this 8 x 32 tile on 8 waves; 8 x 16 on 8 waves 197, 8 x 32 on 4 waves 206.  The parity tests pass for all four.)
+#ifndef DD3D_STEM_TW
+#define DD3D_STEM_TW 32
+#endif
+#ifndef DD3D_STEM_WAVES
+#define DD3D_STEM_WAVES 8
+#endif
+constexpr int SF_TH = 8, SF_TW = DD3D_STEM_TW;               // level1 outputs per block
 constexpr int SF_R0 = 2 * SF_TH + 1, SF_C0 = 2 * SF_TW + 1;  // level0 tile 17 x 65
 constexpr int SF_RB = SF_R0 + 2, SF_CB = SF_C0 + 2;          // base tile 19 x 67
 constexpr int SF_RI = SF_RB + 6, SF_CI = SF_CB + 7;          // image patch 25 x 74 (the Cin-4 reads run to tap slot 7)
@@ -47,7 +55,7 @@ constexpr int SF_0_PLANE = SF_G0 * 16 * 32;
 constexpr int SF_REGION_A = 2 * SF_0_PLANE > 2 * SF_IMG_PLANE ? 2 * SF_0_PLANE : 2 * SF_IMG_PLANE;
 constexpr int SF_REGION_B = 2 * SF_B_PLANE;
 constexpr int SF_LDS = SF_REGION_A + SF_REGION_B;
-constexpr int SF_WAVES = 8;
+constexpr int SF_WAVES = DD3D_STEM_WAVES;
 static_assert(SF_LDS <= 160 * 1024 && SF_N1 * 32 * 4 <= SF_REGION_B, "stem tile does not fit the LDS");
 
 // value -> (hi, lo) halves of value * plane scale; returns nonzero if the scaled value leaves the half range
