@@ -600,5 +600,6 @@ __device__ __forceinline__ void sched_barrier_phase() {
 int launch_conv_planes(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st);  // conv_planes.hip
 bool conv_planes_row_applicable(const ConvKArgs& ka);                                          // conv_planes_row.hip
 int launch_conv_planes_row(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st);
+int conv_planes_row_rings(int math_mode, int tile_cfg, int* nsb, int* nsa);                     // conv_planes_row.hip
 
 }  // namespace dd3d

@@ -846,6 +846,19 @@ extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) 
   return DD3D_OK;
 }
 
+extern "C" int dd3d_conv_row_rings(int32_t tile_cfg, int32_t math_mode, int32_t* nsb, int32_t* nsa) {
+  using namespace dd3d;
+  DD3D_REQUIRE(nsb && nsa, "dd3d_conv_row_rings: null output");
+  int b = 0, a = 0;
+  const int rc = conv_planes_row_rings(math_mode, tile_cfg, &b, &a);
+  if (rc != DD3D_OK) {
+    set_error("dd3d_conv_row_rings: tile_cfg %d has no row-shared split-plane kernel in math mode %d", tile_cfg, math_mode);
+    return rc;
+  }
+  *nsb = b, *nsa = a;
+  return DD3D_OK;
+}
+
 extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   using namespace dd3d;
   DD3D_REQUIRE(L && L->segs && L->tiles, "dd3d_conv2d_igemm_f32: null descriptor");

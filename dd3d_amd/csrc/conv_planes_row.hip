@@ -444,6 +444,43 @@ static int launch_row_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st) {
   DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no row-shared split-plane kernel", tile_cfg);
 }
 
+// Ring depths of the instantiation a (tile, mode) pair launches -- what a profile reader needs to name the kernel (rocprofv3 prints the
+// template arguments); dd3d_amd/engine.py::kernel_signature restates the rule and a CPU test compares the two for every tile and mode.
+template <int MODE>
+static int row_rings_mode(int tile_cfg, int* nsb, int* nsa) {
+#define DD3D_RR(TM, TN, WM, WN) { typedef RowRings<TM, TN, WM, WN, MODE> R; *nsb = R::NSB; *nsa = R::NSA; return DD3D_OK; }
+  switch (tile_cfg) {
+    case DD3D_TILE_256x128: DD3D_RR(2, 2, 4, 2)
+    case DD3D_TILE_128x128: DD3D_RR(2, 1, 2, 4)
+    case DD3D_TILE_128x64_K2:
+    case DD3D_TILE_128x64: DD3D_RR(1, 1, 4, 2)
+    case DD3D_TILE_64x128_K2:
+    case DD3D_TILE_64x128: DD3D_RR(1, 1, 2, 4)
+    case DD3D_TILE_128x128_W4: DD3D_RR(2, 2, 2, 2)
+    case DD3D_TILE_64x64_W4K2:
+    case DD3D_TILE_64x64_W4: DD3D_RR(1, 1, 2, 2)
+    case DD3D_TILE_128x64_W4: DD3D_RR(2, 1, 2, 2)
+    case DD3D_TILE_128x32_W4: DD3D_RR(1, 1, 4, 1)
+    case DD3D_TILE_256x128_T42: DD3D_RR(4, 2, 2, 2)
+    case DD3D_TILE_128x256_T24: DD3D_RR(2, 4, 2, 2)
+    case DD3D_TILE_256x256_W8:
+      if constexpr (Planes<MODE>::NP <= 2) DD3D_RR(4, 2, 2, 4)
+      break;
+  }
+#undef DD3D_RR
+  return DD3D_E_UNSUPPORTED;
+}
+
+int conv_planes_row_rings(int math_mode, int tile_cfg, int* nsb, int* nsa) {
+  switch (math_mode) {
+    case DD3D_MATH_BF16X3: return row_rings_mode<DD3D_MATH_BF16X3>(tile_cfg, nsb, nsa);
+    case DD3D_MATH_BF16X2: return row_rings_mode<DD3D_MATH_BF16X2>(tile_cfg, nsb, nsa);
+    case DD3D_MATH_BF16: return row_rings_mode<DD3D_MATH_BF16>(tile_cfg, nsb, nsa);
+    case DD3D_MATH_F16X2: return row_rings_mode<DD3D_MATH_F16X2>(tile_cfg, nsb, nsa);
+  }
+  return DD3D_E_UNSUPPORTED;
+}
+
 // The row-shared form applies to 3x3 / stride 1 / pad 1 convolutions whose K slices start on a filter row.
 bool conv_planes_row_applicable(const ConvKArgs& ka) {
   return ka.KH == 3 && ka.KW == 3 && ka.stride == 1 && ka.pad == 1 && (ka.Cin % 32) == 0 && (ka.splitk == 1 || ka.kt_per_split % 3 == 0);

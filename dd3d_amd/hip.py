@@ -123,7 +123,7 @@ class BevArgs(C.Structure):
 
 
 EXPORTS = [
-    "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv2d_igemm_f32",
+    "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv_row_rings", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
     "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8",
     "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_maxpool2x2_planes_in", "dd3d_upsample2x_add_planes", "dd3d_ese_fused", "dd3d_stem_fused_f16x2", "dd3d_fold_range_flags"
@@ -153,6 +153,7 @@ def lib():
     L.dd3d_last_error.restype = C.c_char_p
     L.dd3d_arch.restype = C.c_char_p
     L.dd3d_conv_tile_shape.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.dd3d_conv_row_rings.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.dd3d_conv2d_igemm_f32.argtypes = [C.POINTER(ConvLaunch), C.c_void_p]
     L.dd3d_preprocess_u8_nhwc4.argtypes = [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -170,6 +170,10 @@ int dd3d_math_planes(int32_t math_mode);
 #define DD3D_TILE_COUNT 16
 /* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
 int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
+/* B / A ring depths (NSB, NSA) of the row-shared split-plane kernel instantiation that `tile_cfg` launches in `math_mode` -- the 5th and
+ * 8th template arguments rocprofv3 prints for `conv_igemm_planes_row_kernel<...>` (profile bookkeeping; DD3D_E_UNSUPPORTED when the pair
+ * has no such kernel) */
+int dd3d_conv_row_rings(int32_t tile_cfg, int32_t math_mode, int32_t* nsb, int32_t* nsa);
 int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* launch, void* stream);
 
 /* f32 NHWC -> split planes of `math_mode` (the entry into the plane format for tensors a non-convolution kernel produced: pooled

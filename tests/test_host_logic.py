@@ -110,6 +110,27 @@ def test_planes_only_data_flow_of_the_default_plan(kitti_dla34, hiplib, monkeypa
     assert all(c.res_forms == ["f32"] for c in old.ops if isinstance(c, ConvOp) and c.name.endswith(".conv2"))
 
 
+def test_kernel_signature_restates_the_librarys_ring_depths(hiplib):
+    """bench.py matches its tower launch against PMC records keyed by the kernel name rocprofv3 prints; engine.kernel_signature derives that
+    name on the host.  Its ring depths (NSB, NSA) must be the library's (csrc/conv_planes_row.hip::RowRings) for every tile and mode."""
+    import ctypes as C
+    import types
+    from dd3d_amd import hip
+    from dd3d_amd.engine import PLANE_TILES, kernel_signature
+    for math in (hip.MATH_BF16X3, hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2):
+        for cfg in PLANE_TILES:
+            nsb, nsa = C.c_int32(), C.c_int32()
+            rc = hiplib.dd3d_conv_row_rings(cfg, math, C.byref(nsb), C.byref(nsa))
+            if cfg == hip.TILE_256x256_W8 and hip.MATH_PLANES[math] > 2:
+                assert rc != 0
+                continue
+            assert rc == 0, (hip.TILE_NAMES[cfg], math)
+            L = types.SimpleNamespace(tile_cfg=cfg, splitk=1, Kpad=2304, KH=3, KW=3, stride=1, pad=1)
+            sig = kernel_signature(types.SimpleNamespace(L=L, in_planes=True, math=math))
+            args = [a.strip() for a in sig[sig.index("<") + 1:sig.index(">")].split(",")]
+            assert "planes_row_kernel" in sig and (int(args[4]), int(args[7])) == (nsb.value, nsa.value), (sig, nsb.value, nsa.value)
+
+
 def test_registry_and_state_dict_surface(kitti_dla34):
     from dd3d_amd import BACKBONE_REGISTRY, META_ARCH_REGISTRY
     cfg, model, sd = kitti_dla34
