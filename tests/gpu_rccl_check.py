@@ -55,6 +55,16 @@ def main():
             ok &= len(a) == len(b) and len(a) > 0
             ok &= torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores_3d, b.scores_3d)
             ok &= torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.pred_boxes3d.quat, b.pred_boxes3d.quat)
+    # timing of a whole step of the last runner (captured halves or one captured graph around the collective)
+    for _ in range(5):
+        runner.step()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(50):
+        runner.step()
+    torch.cuda.synchronize()
+    print(f"step ({'one graph incl. the all_gather' if one_graph else 'graph half, all_gather, graph half'}): {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms")
     # timing of the exchange itself (ONE all_gather_into_tensor of the rank's record)
     pairs = runner.plan.gather_pairs()
     for _ in range(5):
