@@ -172,6 +172,8 @@ def main():
     torch.cuda.synchronize()
 
     backend = dist.get_backend() if world > 1 else None
+    from dd3d_amd.parallel import ensure_exchange_ready
+    transport = ensure_exchange_ready() if world > 1 else None  # (the runner ran it before capturing its graphs; cached)
 
     def barrier():
         if world > 1:
@@ -203,8 +205,15 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local)
     ms_per_step = elapsed / args.steps * 1e3
+    # N > 1: every rank's own clock over the timed block and the device it ran on -- lets a reader of the line confirm that RCCL saw N
+    # DISTINCT GPUs and that no rank idled (value itself uses the max over ranks, as the contract says)
+    per_rank = None
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "ms_per_step": round(elapsed_local / args.steps * 1e3, 4)})
     value = world * B * args.steps / elapsed
 
     # the same timed block repeated (not `value`): spread of box / clock state within one run
@@ -239,9 +248,11 @@ def main():
     # The TRUE bs=1 path (BASELINE.json configs[1] read literally: one image per launch, one request at a time, nothing else in flight):
     # its own one-image launch plan, one hipGraph replay per image, the host waiting for each.  Not part of the timed region.
     bs1_ms = None
+    parity_src = None  # (plan, image_sizes) of a forward of `inputs` whose detections the parity report reads (outside the clock)
     if world == 1 and args.pipeline > 0 and not args.no_graph:
         one = model.get_plan(B, *_padded(model, args.height, args.width))
-        model.stage_inputs(inputs, plan=one)
+        _, one_sizes = model.stage_inputs(inputs, plan=one)
+        parity_src = (one, one_sizes)
         if one.graph is None:
             one.capture()
         for _ in range(30):
@@ -296,6 +307,13 @@ def main():
                 "note": "a request of the shipped mode also waits for its slot's micro-batch to fill (arrival-rate dependent, not included)"},
             "transport": None if world == 1 else ("rccl (torch.distributed backend nccl)" if backend == "nccl" else
                                                   f"{backend}: host-staged TEST transport of the N > 1 code path -- NOT RCCL, not a scaling number"),
+            # N > 1: the start-up self-test of the exchange (dd3d_amd.parallel.exchange_selftest: one stamped all_gather + checksum, before any
+            # graph capture) and what it found: ranks the transport carried, every rank's device, how many DISTINCT GPUs
+            "rccl_nranks": None if world == 1 else (transport["nranks"] if backend == "nccl" else 0),
+            "exchange_selftest": None if world == 1 else {k: transport[k] for k in ("nranks", "backend", "ms", "distinct_devices")},
+            "rank_devices": None if world == 1 else [{k: d.get(k) for k in ("host", "device", "pci_bus_id", "name", "visible")} for d in transport["devices"]],
+            "rank_ms_per_step": None if per_rank is None else [r["ms_per_step"] for r in sorted(per_rank, key=lambda r: r["rank"])],
+            "graph_exchange": None if world == 1 else bool(getattr(runner, "step_graph", None) is not None),
         },
         "blocks": {"n": len(block_ms), "steps_each": args.steps, "ms_per_step": [round(x, 4) for x in block_ms],
                    "median_ms_per_step": round(srt[len(srt) // 2], 4), "min_ms_per_step": round(srt[0], 4), "max_ms_per_step": round(srt[-1], 4),
@@ -350,8 +368,12 @@ def main():
             "flops_per_launch": flops, "avg_launch_us": round(us, 2), "tile": list(towers[0].info["tile"]),
             "blocks": towers[0].info["blocks"],
         }
+        out["config"]["f16x2_range"] = _headroom([sl.plan for sl in runner.slots] if hasattr(runner, "slots") else [plan])
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+            out["cpu_baseline"], oracle_out = cpu_baseline(cfg, sd, args)
+            # the metric's second half ("3D-box L1 vs ref"): the HIP detections of the bench image against the oracle forward the CPU leg
+            # has just run on the same image (tests/parity.py; outside the clock)
+            out["parity"] = parity(model, cfg, inputs, parity_src, plan, oracle_out)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -382,6 +404,42 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
+def _headroom(plans):
+    """Worst f16x2 range headroom over the plans that ran (dd3d_amd.engine.PlanBase.range_headroom): how near the per-element overflow
+    guard (and the bf16x3 fallback behind it) the run came."""
+    rows = [h for h in (p.range_headroom() for p in plans) if h]
+    if not rows:
+        return None
+    worst = min(rows, key=lambda h: h["overflow_headroom_x"])
+    low = min(rows, key=lambda h: h["underflow_headroom_x"])
+    r = lambda x: round(float(x), 4)
+    return {"plane_scale": worst["plane_scale"], "largest_activation": r(worst["largest_activation"]), "overflow_at": r(worst["overflow_at"]),
+            "overflow_headroom_x": r(worst["overflow_headroom_x"]), "largest_in": worst["largest_in"],
+            "underflow_headroom_x": r(low["underflow_headroom_x"]), "smallest_in": low["smallest_in"], "launches_watched": worst["launches_watched"],
+            "note": "sampled per-launch maxima of |activation| (a lower bound: one wave tile per block); the guard trips per element at overflow_at"}
+
+
+def parity(model, cfg, inputs, src, plan, oracle_out):
+    """tests/parity.py::parity_report of image 0 of the bench inputs: HIP detections (the one-image plan the bs=1 figure was timed on, or
+    a fresh forward) vs the oracle's.  Belongs to the cpu_baseline leg: the oracle is the checker here, never the thing measured."""
+    from tests.parity import parity_report
+    ref, stages = oracle_out
+    if src is None:
+        model.use_graph = False
+        p, sizes = model.stage_inputs(inputs)
+        p.run()
+    else:
+        p, sizes = src
+        p.run()
+    torch.cuda.synchronize()
+    out = model.collect(p, inputs, sizes)
+    rep = parity_report(out[0], ref[0], plan=p, stages=stages, cfg=cfg, image=0)
+    rep = {k: (round(v, 9) if isinstance(v, float) else v) for k, v in rep.items()}
+    rep["image"] = "image 0 of the timed batch (synthetic seed 1000), one-image launch plan, default arithmetic of the run"
+    rep["reference"] = "oracle/dd3d_oracle.py forward of the same uint8 image (cpu_baseline leg); quantities: boxes3d.py:47-64 corners, :142-144 vectorize"
+    return rep
+
+
 def cpu_baseline(cfg, sd, args, budget_s=12.0):
     """The oracle (oracle/dd3d_oracle.py, a torch-CPU fp32 restatement of the reference forward) on the host cores:
     one warm-up at 1/16 of the pixels, then single-image forwards of the bench workload until ~``budget_s`` of CPU
@@ -395,14 +453,14 @@ def cpu_baseline(cfg, sd, args, budget_s=12.0):
         O.dd3d_forward(sd, cfg, make_inputs(1, max(128, args.height // 4 // 128 * 128), max(128, args.width // 4 // 128 * 128)))
         n, t0 = 0, time.perf_counter()
         while n < args.cpu_forwards and (n == 0 or time.perf_counter() - t0 < budget_s * n / (n + 1)):
-            O.dd3d_forward(sd, cfg, inputs)
+            last = O.dd3d_forward(sd, cfg, inputs)
             n += 1
         dt = (time.perf_counter() - t0) / n
     return {
         "value": round(1.0 / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
         "sample": f"{n} forward(s) of 1 synthetic {args.height}x{args.width} image (after a small warm-up), oracle/dd3d_oracle.py on "
                   f"torch {torch.__version__} CPU fp32 with {threads} threads (os.cpu_count()={os.cpu_count()})",
-    }
+    }, last
 
 
 if __name__ == "__main__":

@@ -4,6 +4,8 @@
 
 #include "common.h"
 
+DD3D_NOTE_BUILD_FLAGS
+
 namespace dd3d {
 
 static thread_local char g_err[512] = "";
@@ -252,8 +254,20 @@ __global__ void invert3x3_kernel(const float* __restrict__ K, float* __restrict_
   o[8] = (a * e - bb * d) * r;
 }
 
+// Union of the build-time knobs the translation units report (build_flags.h); zero-initialised storage, so the static registrations of the
+// other translation units may run before this one's.
+static char g_build_flags[2048];
+void register_build_flags(const char* file, const char* flags) {
+  if (flags == nullptr || flags[0] == 0) return;
+  const char* base = strrchr(file, '/');
+  base = base ? base + 1 : file;
+  const size_t n = strlen(g_build_flags);
+  if (n + 8 < sizeof(g_build_flags)) snprintf(g_build_flags + n, sizeof(g_build_flags) - n, "%s%s:%s", n ? "; " : "", base, flags);
+}
+
 }  // namespace dd3d
 
+extern "C" const char* dd3d_build_flags(void) { return dd3d::g_build_flags; }
 extern "C" int dd3d_abi_version(void) { return DD3D_ABI_VERSION; }
 extern "C" const char* dd3d_last_error(void) { return dd3d::g_err; }
 extern "C" const char* dd3d_arch(void) { return "gfx950"; }

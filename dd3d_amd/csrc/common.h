@@ -5,11 +5,22 @@
 #include <stdio.h>
 #include <string.h>
 
+#include "build_flags.h"
 #include "dd3d_hip.h"
 
 namespace dd3d {
 
 void set_error(const char* fmt, ...);
+
+// Every translation unit reports the build-time knobs it was compiled with (build_flags.h); dd3d_build_flags() returns their union.
+void register_build_flags(const char* file, const char* flags);
+struct BuildFlagsNote {
+  BuildFlagsNote(const char* file, const char* flags) { register_build_flags(file, flags); }
+};
+#define DD3D_NOTE_BUILD_FLAGS \
+  namespace {                 \
+  const dd3d::BuildFlagsNote dd3d_build_flags_note_(__FILE__, DD3D_BUILD_FLAGS); \
+  }
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -514,13 +514,7 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
               ovf |= !(fabsf(e0) <= 65504.f) | !(fabsf(e1) <= 65504.f);
               if (report && mv) amx = fmaxf(amx, fmaxf(fabsf(e0), fabsf(e1)));
             }
-#ifdef DD3D_ABLATE_EPI_VALU  // (timing experiment: the stores without the arithmetic in front of them)
-            w[t][0] = __float_as_uint(acc[i][j][2 * t]);
-            if constexpr (NP > 1) w[t][1] = __float_as_uint(acc[i][j][2 * t + 1]);
-            if constexpr (NP > 2) w[t][2] = 0;
-#else
             split_pack<MODE>(e0, e1, w[t]);
-#endif
           }
           if (scratch != nullptr) {
             // unit (pixel px, plane p, 16-byte slot 2 h + jj) -> LDS slot px * UP + swizzled unit index
@@ -540,11 +534,7 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
               const int pp = U / UP, u = U - pp * UP;
               const int us = NP == 2 ? (u ^ (pp & 7)) : ((u & ~3) + ((u & 3) ^ (pp & 3)));
               const u32x4 val = *reinterpret_cast<const u32x4*>(scratch + (pp * UP + us) * 16);
-#ifdef DD3D_ABLATE_EPI_STORE  // (timing experiment: everything but the global stores)
-              if (mblk + pp < s.M && a.relu == 12345) *(gu4p)(dst + (long)U * 16) = val;
-#else
               if (mblk + pp < s.M) *(gu4p)(dst + (long)U * 16) = val;
-#endif
             }
           } else if (mv) {
             const gbp dst = (gbp)s.out_planes + (long)(nb >> 5) * cstride + (long)m * (NP * 64) + h * 32;

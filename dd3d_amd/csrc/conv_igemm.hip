@@ -23,6 +23,8 @@
 
 #include "conv_common.h"
 
+DD3D_NOTE_BUILD_FLAGS
+
 namespace dd3d {
 
 constexpr int LDS_ROW = BK + 4;  // register-staged kernel: 144-B rows keep the 16-B slots of 16 rows distinct mod 256 B
@@ -901,14 +903,22 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.out_plane_scale = L->out_plane_scale > 0.f ? L->out_plane_scale : 1.f;
   ka.status = L->status;
   ka.amax = L->amax;
-  if (ka.single) {  // (only a single-segment launch hands its descriptor over on the host; the caller vouches for device-side ones)
-    const dd3d_conv_seg& s0 = ka.seg0;
-    DD3D_REQUIRE(s0.res_mode >= 0 && s0.res_mode <= 3 && (s0.res_mode == 0 || s0.res), "dd3d_conv2d_igemm_f32: res_mode=%d / null residual", s0.res_mode);
-    DD3D_REQUIRE(s0.res_mode <= 1 || L->in_planes, "dd3d_conv2d_igemm_f32: a split-plane residual (res_mode %d) needs the split-plane-input kernels",
-                 s0.res_mode);
-    DD3D_REQUIRE(s0.res_mode != 3 || ((s0.Ho % 2) == 0 && (s0.Wo % 2) == 0), "dd3d_conv2d_igemm_f32: res_mode 3 needs even Ho, Wo (%d x %d)", s0.Ho,
-                 s0.Wo);
-    DD3D_REQUIRE(s0.res_mode == 0 || !L->in_planes || L->tile_cfg != DD3D_TILE_256x256_W8, "dd3d_conv2d_igemm_f32: DD3D_TILE_256x256_W8 carries no residual");
+  if (L->seg0_host != nullptr) {  // a host copy of the descriptors: every segment's residual contract is checked (without one the caller vouches)
+    for (int i = 0; i < L->nsegs; ++i) {
+      const dd3d_conv_seg& sg = L->seg0_host[i];
+      DD3D_REQUIRE(sg.res_mode >= 0 && sg.res_mode <= 3 && (sg.res_mode == 0 || sg.res), "dd3d_conv2d_igemm_f32: segment %d: res_mode=%d / null residual", i,
+                   sg.res_mode);
+      DD3D_REQUIRE(sg.res_mode <= 1 || L->in_planes, "dd3d_conv2d_igemm_f32: segment %d: a split-plane residual (res_mode %d) needs the split-plane-input kernels",
+                   i, sg.res_mode);
+      DD3D_REQUIRE(sg.res_mode != 3 || ((sg.Ho % 2) == 0 && (sg.Wo % 2) == 0), "dd3d_conv2d_igemm_f32: segment %d: res_mode 3 needs even Ho, Wo (%d x %d)", i,
+                   sg.Ho, sg.Wo);
+      DD3D_REQUIRE(sg.res_mode == 0 || !L->in_planes || L->tile_cfg != DD3D_TILE_256x256_W8,
+                   "dd3d_conv2d_igemm_f32: segment %d: DD3D_TILE_256x256_W8 carries no residual", i);
+      const int stored = sg.n_limit > 0 ? sg.n_limit : L->N;
+      DD3D_REQUIRE(sg.res_mode != 1 || !L->in_planes || ((sg.res_pitch % 4) == 0 && sg.res_pitch >= ((stored + 3) & ~3)),
+                   "dd3d_conv2d_igemm_f32: segment %d: an f32 residual of the split-plane kernels is read in 16-byte pieces: res_pitch=%d must be a "
+                   "multiple of 4 and cover %d channels rounded up to 4", i, sg.res_pitch, stored);
+    }
   }
   if (L->in_planes) {
     DD3D_REQUIRE(L->math_mode != DD3D_MATH_F32 && !smallc && L->zero_page && !L->in_relu,

@@ -20,6 +20,8 @@
 
 #include "conv_common.h"
 
+DD3D_NOTE_BUILD_FLAGS
+
 namespace dd3d {
 
 // Scheduling pattern of one phase: NMFMA matrix instructions, NDMA LDS-DMA issues and NDS fragment reads in ONE region.  The DMAs go
@@ -186,9 +188,6 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
   };
   auto emit = [&](int stage, auto qb_c, auto qe_c) {  // row blocks [qb, qe) of the prepared tile
     constexpr int QB = decltype(qb_c)::value, QE = decltype(qe_c)::value;
-#ifdef DD3D_ABLATE_DMA
-    return;
-#endif
     unsigned char* st = lds + stage * STAGE;
 #pragma unroll
     for (int q = QB; q < QE; ++q)
@@ -253,17 +252,10 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
   const int frag_off[2] = {lrow * 64 + (((0 + kh) ^ swz) << 4), lrow * 64 + (((2 + kh) ^ swz) << 4)};  // k-chunk 0 / 1
   const int a_row0 = wm * TM * 32 * 64, b_row0 = A_BYTES + wn * TN * 32 * 64;
 
-#ifdef DD3D_ABLATE_DSREAD
-  bf16x8 fa[2][TM][NP] = {}, fb[2][TN][NP] = {};
-#else
   bf16x8 fa[2][TM][NP], fb[2][TN][NP];  // fragment sets of the two 16-k chunks
-#endif
   auto read_frags = [&](int stage, auto c_c) {
     constexpr int c = decltype(c_c)::value;
     const unsigned char* st = lds + stage * STAGE;
-#ifdef DD3D_ABLATE_DSREAD
-    if (a.relu != 12345) return;
-#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -279,9 +271,6 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
   constexpr int PB_[6] = {0, NP == 3 ? 2 : (NP == 2 ? 1 : 0), NP == 3 ? 1 : 0, 0, 1, 0};
   auto mfma_chunk = [&](auto c_c) {
     constexpr int c = decltype(c_c)::value;
-#ifdef DD3D_ABLATE_MFMA
-    return;
-#endif
 #pragma unroll
     for (int t = 0; t < NPROD; ++t)
 #pragma unroll

@@ -19,6 +19,8 @@
 
 #include "conv_common.h"
 
+DD3D_NOTE_BUILD_FLAGS
+
 #ifndef DD3D_ROW_LDS_KIB_8W
 #define DD3D_ROW_LDS_KIB_8W 152  // LDS a block of the 8-wave tiles may take (decides NSB = 3 or 2)
 #endif
@@ -130,21 +132,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     }
     ld_g += (ld_g + 1 < g_begin + ngroup);
   };
-  // (DD3D_ABLATE_*: timing experiments only -- wrong results -- that remove one ingredient of the K loop; tests/tools/r04_ablate.sh)
-  bool in_loop = false;
-  bool skip_reads = false;
   auto emit_a = [&](int stage) {
-#ifdef DD3D_ABLATE_DMA
-    if (in_loop) return;
-#endif
 #pragma unroll
     for (int q = 0; q < PA; ++q)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)nxt_a[q], (ldsbp)(lds + stage * A_STAGE + a_dst[q]), 16, 0, 0);
   };
   auto emit_b = [&](int stage) {  // K-tile ld_kt, then advance
-#ifdef DD3D_ABLATE_DMA
-    if (in_loop) return;
-#endif
     const long koff = (long)ld_kt * (NP * 64);
 #pragma unroll
     for (int q = 0; q < PB; ++q)
@@ -195,21 +188,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     }
   }
 
-#ifdef DD3D_ABLATE_DSREAD
-  bf16x8 fa[2][TM][NP] = {}, fb[2][TN][NP] = {};
-#else
   bf16x8 fa[2][TM][NP], fb[2][TN][NP];
-#endif
   // An invalid (pixel, tap) reads 16 zero bytes kept behind the rings instead of its LDS row: one address select per fragment read,
   // computed before the read is issued (masking the loaded registers would make every MFMA phase wait for its own prefetch).
   auto read_frags = [&](int sa, int sb, int dw, int tap, auto c_c) {
     constexpr int c = decltype(c_c)::value;
-#ifdef DD3D_ABLATE_DSREAD
-    if (a.relu != 12345) return;
-#endif
-#ifdef DD3D_ABLATE_DSREAD_LOOP  // (timing experiment: fragments of the first A group are re-used -- real operand bits, no LDS reads afterwards)
-    if (skip_reads) return;
-#endif
     // One address register per phase (stage + lane part) and the (row block, plane) part as the read's immediate offset; an invalid
     // (pixel, tap) selects a base that the same immediate brings onto the 16 zero bytes: one v_cndmask per read (round 3: add, select, add;
     // towers 305 -> 300 us, level 3 35.4 -> 34.0 us, bench +2.5 % on one box: profiles/r04p_a_read_addressing_ab.txt).  Going further --
@@ -219,11 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     const unsigned char* Bs = lds + B_BASE + sb * B_STAGE + fb_off[c];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-#ifdef DD3D_ROW_NOMASK  // timing experiment only (wrong at image borders): what the per-read address selects cost
-      const bool ok = true;
-#else
       const bool ok = (vmask[i] >> tap) & 1u;
-#endif
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int C = p * PLA + i * 32 * 64;  // (compile-time: the loops are unrolled; < 64 KiB, <= ZERO_OFF)
@@ -241,9 +220,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   constexpr int PB_[6] = {0, NP == 3 ? 2 : (NP == 2 ? 1 : 0), NP == 3 ? 1 : 0, 0, 1, 0};
   auto mfma_chunk = [&](auto c_c) {
     constexpr int c = decltype(c_c)::value;
-#ifdef DD3D_ABLATE_MFMA
-    return;
-#endif
 #pragma unroll
     for (int t = 0; t < NPROD; ++t)
 #pragma unroll
@@ -310,9 +286,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       constexpr int a_in_flight = NSB == 3 ? (dw != 2 ? 1 : 0) : (dw == 0 ? 1 : 0);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 2) * PB + a_in_flight * PA) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef DD3D_EXP_GROUP_BARRIER  // (timing experiment, RACY: what one barrier per A group instead of one per K-tile would buy)
-      if constexpr (dw == 2)
-#endif
       __builtin_amdgcn_s_barrier();  // everyone: K-tile s+1 (and, after dw == 2, the next A group) landed; B stage sb / A stage sa free
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -331,7 +304,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     constexpr std::integral_constant<int, 1> D1{};
     constexpr std::integral_constant<int, 2> D2{};
     int dh = g_begin % 3;
-    in_loop = true;
     int sa = 0;
     for (int g = 0; g < ngroup; ++g) {
       step(sa, dh, D0);
@@ -339,7 +311,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       step(sa, dh, D2);
       dh = dh == 2 ? 0 : dh + 1;
       sa = sa == NSA - 1 ? 0 : sa + 1;
-      skip_reads = true;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus fetches land before the LDS is released
   }
@@ -347,9 +318,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if constexpr (SK) {
     if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
   }
-#ifdef DD3D_ABLATE_EPI
-  if (a.relu != 12345) return;
-#endif
 #if DD3D_EPI_T
 #if DD3D_EPI_LDS
   // plane stores staged through LDS (conv_epilogue_t): the rings are dead, but other waves' surplus LDS-DMAs / fragment reads of the last

@@ -9,6 +9,8 @@
 // reference's operation order (fp contraction off), so results agree with it to rounding of cos / sin / sqrt.
 #include "common.h"
 
+DD3D_NOTE_BUILD_FLAGS
+
 #pragma clang fp contract(off)
 
 namespace dd3d {

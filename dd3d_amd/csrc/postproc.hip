@@ -15,6 +15,8 @@
 
 #include "common.h"
 
+DD3D_NOTE_BUILD_FLAGS
+
 namespace dd3d {
 
 constexpr int PT = 1024;        // threads per block for the per-image / per-level kernels

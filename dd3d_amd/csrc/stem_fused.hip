@@ -21,6 +21,8 @@
 
 #include "common.h"
 
+DD3D_NOTE_BUILD_FLAGS
+
 namespace dd3d {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

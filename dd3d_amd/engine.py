@@ -336,13 +336,17 @@ def default_math():
     return MATH_NAMES[os.environ.get("DD3D_MATH", "f16x2")]
 
 
+# (TM, TN, WM, WN) of the split-plane kernels' tiles: 32 x 32 accumulator blocks per wave and the block's wave grid
+TILE_WAVE_GRID = {hip.TILE_256x128: (2, 2, 4, 2), hip.TILE_128x128: (2, 1, 2, 4), hip.TILE_128x64: (1, 1, 4, 2), hip.TILE_64x128: (1, 1, 2, 4),
+                  hip.TILE_128x128_W4: (2, 2, 2, 2), hip.TILE_64x64_W4: (1, 1, 2, 2), hip.TILE_128x64_W4: (2, 1, 2, 2),
+                  hip.TILE_256x128_T42: (4, 2, 2, 2), hip.TILE_128x256_T24: (2, 4, 2, 2), hip.TILE_256x256_W8: (4, 2, 2, 4),
+                  hip.TILE_128x32_W4: (1, 1, 4, 1)}
+
+
 def kernel_signature(op):
     """Name of the kernel instantiation a ConvOp launches, as rocprofv3 prints it (bench.py / profiles bookkeeping)."""
     cfg = op.L.tile_cfg
-    tm_tn_wm_wn = {hip.TILE_256x128: (2, 2, 4, 2), hip.TILE_128x128: (2, 1, 2, 4), hip.TILE_128x64: (1, 1, 4, 2), hip.TILE_64x128: (1, 1, 2, 4),
-                   hip.TILE_128x128_W4: (2, 2, 2, 2), hip.TILE_64x64_W4: (1, 1, 2, 2), hip.TILE_128x64_W4: (2, 1, 2, 2),
-                   hip.TILE_256x128_T42: (4, 2, 2, 2), hip.TILE_128x256_T24: (2, 4, 2, 2), hip.TILE_256x256_W8: (4, 2, 2, 4),
-                   hip.TILE_128x32_W4: (1, 1, 4, 1)}
+    tm_tn_wm_wn = TILE_WAVE_GRID
     sk = "true" if op.L.splitk > 1 else "false"
     if op.in_planes:
         tm, tn, wm, wn = tm_tn_wm_wn[PLANE_TILE_ALIAS.get(cfg, cfg)]
@@ -353,14 +357,17 @@ def kernel_signature(op):
         row = (L.KH == 3 and L.KW == 3 and L.stride == 1 and L.pad == 1 and (L.splitk == 1 or -(-nk // L.splitk) % 3 == 0)
                and os.environ.get("DD3D_CONV_ROW", "1") != "0")
         if row:  # csrc/conv_planes_row.hip: the three taps of a filter row share one A stage
-            # ring depths: csrc/conv_planes_row.hip::RowRings
-            ast, bst = np_ * (bm + 16) * 64, np_ * bn * 64
-            budget = (152 if (wm * wn == 8 or 2 * ast > 65536) else 76) * 1024
-            nsb = 3 if 2 * ast + 3 * bst <= budget else 2
-            total = lambda nsa: nsa * ast + nsb * bst + 64 + 12 * bn
-            limit = 80 * 1024 if total(2) <= 80 * 1024 else max(budget, total(2))
-            nsa_max = int(os.environ.get("DD3D_ROW_NSA_MAX", "2"))  # (the library's build-time default; deeper A rings measured no gain)
-            nsa = 4 if (nsa_max >= 4 and total(4) <= limit) else (3 if (nsa_max >= 3 and total(3) <= limit) else 2)
+            # ring depths: what the LIBRARY instantiates (dd3d_conv_row_rings: they are build-time properties of the .so); the formula below
+            # (csrc/conv_planes_row.hip::RowRings with the product build's defaults) only serves a box without the library
+            nsb = nsa = None
+            try:
+                b_, a_ = C.c_int32(), C.c_int32()
+                if hip.lib().dd3d_conv_row_rings(PLANE_TILE_ALIAS.get(cfg, cfg), op.math, C.byref(b_), C.byref(a_)) == 0:
+                    nsb, nsa = b_.value, a_.value
+            except (hip.HipLibraryMissing, OSError):
+                pass
+            if nsb is None:
+                nsb, nsa = row_rings_default(np_, bm, bn, wm * wn)
             return f"dd3d::conv_igemm_planes_row_kernel<{tm}, {tn}, {wm}, {wn}, {nsb}, {op.math}, {sk}, {nsa}>"
         stage = np_ * (bm + bn) * 64
         ns = max(2, min(4, ((144 if (wm * wn == 8 or stage > 32768) else 72) * 1024) // stage))
@@ -368,6 +375,15 @@ def kernel_signature(op):
     if op.math == hip.MATH_BF16X3:
         return f"dd3d::conv_igemm_bf16x3_kernel ({hip.TILE_NAMES[cfg]}, split-K {sk})"
     return f"dd3d::conv_igemm_f32[_dma]_kernel ({hip.TILE_NAMES[cfg]}, split-K {sk})"
+
+
+def row_rings_default(np_, bm, bn, nwaves):
+    """(NSB, NSA) of csrc/conv_planes_row.hip::RowRings for the product build (no -DDD3D_ROW_* knob); a CPU test compares it with
+    dd3d_conv_row_rings for every tile and mode."""
+    ast, bst = np_ * (bm + 16) * 64, np_ * bn * 64
+    budget = (152 if (nwaves == 8 or 2 * ast > 65536) else 76) * 1024
+    nsb = 3 if 2 * ast + 3 * bst <= budget else 2
+    return nsb, 2
 
 
 def tile_key(m_list, N, Kpad, stride):
@@ -389,6 +405,18 @@ PLANE_TILE_TABLE = {m: _load_tile_table(n + "_planes") for n, m in (("bf16x3", h
                                                                      ("f16x2", hip.MATH_F16X2))}
 
 
+def _tile_overrides():
+    """DD3D_TILE_OVERRIDE: `key=tile:splitk` pairs separated by ';' (key as `tile_key` prints it) that win over the measured table --
+    for sweeps of the issue mode, where the tile that minimises one launch's latency need not maximise the throughput of several slots."""
+    spec = os.environ.get("DD3D_TILE_OVERRIDE", "")
+    out = {}
+    for item in filter(None, (s.strip() for s in spec.split(";"))):
+        key, val = item.split("=")
+        tile, _, sk = val.partition(":")
+        out[key.strip()] = [tile.strip(), int(sk or 1)]
+    return out
+
+
 def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
     """Pick (tile_cfg, splitk): a measured table entry when this exact shape has one, else minimise the modelled makespan
     on 256 CUs: every block costs BM*BN*K MACs on its CU's matrix pipe (partial tiles cost the same as full ones); split-K
@@ -399,6 +427,9 @@ def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
     # share their CUs -- pipelined throughput 960 -> 921 img/s, profiles/r02_notes.md)
     key = tile_key(m_list, N, Kpad, stride)
     hit = PLANE_TILE_TABLE[math].get(key) if planes else TILE_TABLE[math].get(key)
+    forced = _tile_overrides().get(key)  # DD3D_TILE_OVERRIDE="M[+M..],N,Kpad,stride=tile:splitk;..." (measurement sweeps, tests/gpu_issue_sweep.sh)
+    if forced is not None:
+        hit = forced
     if hit is None and planes and math == hip.MATH_BF16X3:
         hit = TILE_TABLE[math].get(key)
     if hit is not None:
@@ -540,7 +571,7 @@ class ConvOp:
             self.keep += [w, scale_vec, s["bias"], s.get("lo")]  # (what the launch reads; kept alive here)
         self.desc = dict(kind="conv", segs=segs, meta=meta, stride=stride, pad=pad, relu=bool(relu), in_relu=bool(in_relu),
                          in_form="planes" if in_planes else "f32", out_forms=self.out_forms, res_forms=self.res_forms)
-        self.segs_host = arr  # kept alive: single-segment launches hand the descriptor over by value (seg0_host)
+        self.segs_host = arr  # kept alive: the library reads the host copy at every launch (seg0_host)
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
         # split-K: private partial-sum slab + per-tile arrival counters (private, so that independent convs may overlap)
@@ -558,7 +589,7 @@ class ConvOp:
         L.Cin, L.N, L.Kpad, L.Npad = meta["Cin"], meta["N"], meta["Kpad"], meta["Npad"]
         L.relu, L.splitk, L.math_mode, L.tile_cfg = int(relu), sk, math, cfg
         L.zero_page = plan.zero_page.data_ptr()
-        L.seg0_host = self.segs_host.ctypes.data if len(segs) == 1 else None
+        L.seg0_host = self.segs_host.ctypes.data  # (host copy of every segment: one segment travels by value, all are validated by the library)
         assert not in_relu or math == hip.MATH_BF16X3
         L.in_relu = int(in_relu)
         L.in_planes = int(in_planes)
@@ -667,6 +698,26 @@ class PlanBase:
         """Largest sampled |value * plane scale| of every watched launch of the last forward (CPU tensor, order of `amax_names`)."""
         return self.amax[:len(self.amax_names), :, 0].amax(1).cpu()
 
+    HALF_MAX = 65504.0
+
+    def range_headroom(self):
+        """How close the last forward came to the two ends of the f16x2 range guard (None for the other arithmetic modes / before a
+        forward): per-launch sampled maxima of |value * plane scale| against the half format's largest finite value (overflow side: the
+        status bit trips per ELEMENT at 65504, so `overflow_headroom_x` < ~4 on a sample means real data may trip it) and against
+        AMAX_FLOOR (underflow side, per tensor).  Reads the maxima from the device: call after the forward has been waited for."""
+        if self.math != hip.MATH_F16X2 or not self.amax_names:
+            return None
+        mx = self.amax_values().tolist()
+        seen = [(n, v) for n, v in zip(self.amax_names, mx) if v > 0.0]
+        if not seen:
+            return None
+        hi_n, hi = max(seen, key=lambda t: t[1])
+        lo_n, lo = min(seen, key=lambda t: t[1])
+        return {"plane_scale": self.act_scale, "launches_watched": len(seen),
+                "largest_scaled_activation": hi, "largest_in": hi_n, "overflow_headroom_x": self.HALF_MAX / hi,
+                "largest_activation": hi / self.act_scale, "overflow_at": self.HALF_MAX / self.act_scale,
+                "smallest_launch_maximum_scaled": lo, "smallest_in": lo_n, "underflow_headroom_x": lo / self.AMAX_FLOOR}
+
     def check_status(self):
         """Raise if a kernel flagged a numeric fault (reads one int32 and the per-launch maxima from the device; call after the forward
         has been waited for).  DD3D_MATH_F16X2 keeps activations as two IEEE halves of value * plane scale: exact to 2^-24 relative
@@ -687,6 +738,16 @@ class PlanBase:
                     f"the outputs of {len(low)} convolution(s) sit below the half range's useful part (smallest: {n}, max |x| = "
                     f"{v / self.act_scale:.3g} at plane scale {self.act_scale:g}; the pair (hi, lo) has an absolute floor of {2.0**-25 / self.act_scale:.2g}): "
                     "raise DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
+            # not a fault yet, but close: the sampled maximum of some launch is within DD3D_RANGE_WARN_X (default 4) of the half format's
+            # largest value -- a real checkpoint's user sees how near the fallback to bf16x3 (half the throughput) is before it happens
+            top = float(mx.max()) if mx.numel() else 0.0
+            warn_x = float(os.environ.get("DD3D_RANGE_WARN_X", "4"))
+            if top > 0.0 and self.HALF_MAX / top < warn_x and not getattr(self, "_range_warned", False):
+                import warnings
+                self._range_warned = True
+                n = self.amax_names[int(mx.argmax())]
+                warnings.warn(f"dd3d_amd: f16x2 range headroom is {self.HALF_MAX / top:.2f}x (launch {n}: sampled max |x| = {top / self.act_scale:.4g}, "
+                              f"overflow at {self.HALF_MAX / self.act_scale:g}); lower DD3D_F16_ACT_SCALE or expect the bf16x3 fallback")
 
     def adopt_weight_store(self, model):
         """Use the model's weight store (created on first use; dropped by DD3D.invalidate_plans when the weights change)."""
@@ -1739,7 +1800,7 @@ class ForwardPlan(PlanBase):
         """With the exchange, the verdict is the OR over all ranks' records (delivered by the step's all_gather), so that every rank raises on
         the same step; the local words are cleared as well."""
         # (DenseDepthPlan shares this class without the post-processing half: no exchange, no gathered buffer)
-        if not (getattr(self, "exchange", False) and self.math == hip.MATH_F16X2 and getattr(self, "gathered", None) is not None and not self.dry_run):
+        if not (getattr(self, "exchange", False) and self.math == hip.MATH_F16X2 and getattr(self, "gathered", None) is not None):
             return super().check_status()
         fl = self.gathered.view(self.world_size, self.record_len)[:, self.flags_off:self.flags_off + 2].view(torch.int32).cpu()
         over = [r for r in range(self.world_size) if int(fl[r, 0]) & hip.STATUS_F16_OVERFLOW]

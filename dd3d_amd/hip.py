@@ -16,7 +16,7 @@ _lib = None
 MAX_LEVELS = 8
 MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16, MATH_F16X2 = 0, 1, 2, 3, 4
 MATH_PLANES = {MATH_F32: 0, MATH_BF16X3: 3, MATH_BF16X2: 2, MATH_BF16: 1, MATH_F16X2: 2}  # 16-bit terms per value (dd3d_math_planes)
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATUS_F16_OVERFLOW = 1
 CAND_FIELDS = 22
 DET_FIELDS = 32
@@ -123,7 +123,7 @@ class BevArgs(C.Structure):
 
 
 EXPORTS = [
-    "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_conv_tile_shape", "dd3d_conv_row_rings", "dd3d_conv2d_igemm_f32",
+    "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_build_flags", "dd3d_conv_tile_shape", "dd3d_conv_row_rings", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
     "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8",
     "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_maxpool2x2_planes_in", "dd3d_upsample2x_add_planes", "dd3d_ese_fused", "dd3d_stem_fused_f16x2", "dd3d_fold_range_flags"
@@ -136,6 +136,11 @@ class HipLibraryMissing(RuntimeError):
 
 def lib_path():
     return _LIB_PATH
+
+
+def build_flags():
+    """Build-time knobs of the loaded library ("" = the product build)."""
+    return lib().dd3d_build_flags().decode()
 
 
 def lib():
@@ -152,6 +157,8 @@ def lib():
     L.dd3d_abi_version.restype = C.c_int
     L.dd3d_last_error.restype = C.c_char_p
     L.dd3d_arch.restype = C.c_char_p
+    if hasattr(L, "dd3d_build_flags"):
+        L.dd3d_build_flags.restype = C.c_char_p
     L.dd3d_conv_tile_shape.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.dd3d_conv_row_rings.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.dd3d_conv2d_igemm_f32.argtypes = [C.POINTER(ConvLaunch), C.c_void_p]
@@ -186,6 +193,12 @@ def lib():
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if the .so is stale
     assert L.dd3d_abi_version() == ABI_VERSION, "libdd3d_hip.so ABI version mismatch; rebuild"
+    # A library compiled with build-time knobs (-DDD3D_...: ring depths, schedules, store forms -- A/B variants of tests/tools) says so;
+    # it is only accepted when the caller chose it (DD3D_HIP_LIB names it, or DD3D_ALLOW_VARIANT_LIB=1), never as the default library.
+    flags = L.dd3d_build_flags().decode()
+    if flags and not (os.environ.get("DD3D_HIP_LIB") or os.environ.get("DD3D_ALLOW_VARIANT_LIB") == "1"):
+        raise HipLibraryMissing(f"{_LIB_PATH} was built with non-default knobs ({flags}): rebuild it with __graft_entry__.build(force=True), "
+                                "or select a variant explicitly with DD3D_HIP_LIB / DD3D_ALLOW_VARIANT_LIB=1")
     _lib = L
     return L
 

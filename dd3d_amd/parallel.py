@@ -87,22 +87,179 @@ def padded_inference_shard(total_size, group_size, rank, world_size, batch_size)
     largest = len(inference_shard(total_size, group_size, 0, world_size))  # rank 0 always holds a full shard
     steps = -(-largest // batch_size)
     per_batch, num_groups = batch_size // group_size, total_size // group_size
-    assert per_batch <= num_groups, f"a batch of {per_batch} groups cannot be filled with distinct groups of a dataset that has {num_groups}"
+    if per_batch > num_groups:
+        raise ValueError(f"a step's batch holds {per_batch} groups but the dataset has only {num_groups}: no batch can be filled with distinct "
+                         f"groups -- use batch_size <= {num_groups * group_size}")
     own_groups = [i // group_size for i in own[::group_size]]
-    pool = own_groups + [g for g in range(num_groups) if g not in set(own_groups)]  # candidates for padding, in order of preference
+    own_set = set(own_groups)
+    pool = own_groups + [g for g in range(num_groups) if g not in own_set]  # candidates for padding, in order of preference
     idx, valid = [], []
     for st in range(steps):
         real = own_groups[st * per_batch:(st + 1) * per_batch]
-        fill = [g for g in pool if g not in set(real)][:per_batch - len(real)]
+        fill = []
+        if len(real) < per_batch:  # (only the tail of a shard: a full batch never walks the pool)
+            real_set = set(real)
+            for g in pool:
+                if g not in real_set:
+                    fill.append(g)
+                    if len(real) + len(fill) == per_batch:
+                        break
         for g, v in [(g, True) for g in real] + [(g, False) for g in fill]:
             idx += list(range(g * group_size, (g + 1) * group_size))
             valid += [v] * group_size
     return idx, valid
 
 
+def graph_exchange_mode():
+    """DD3D_GRAPH_EXCHANGE: "0" (default) the collective runs eagerly between the step's two captured graph halves -- the form every
+    torch.distributed user runs; "1" capture it INSIDE the step's hipGraph; "probe" let `graph_exchange_probe` decide at start-up.
+    The default stays "0" although the one-graph step measured 1.7 % faster on one rank (profiles/r04y_*): no box with more than one GPU was
+    ever available to validate a captured multi-rank RCCL collective, a probe cannot be guaranteed not to hang on a transport that does not
+    support capture, and a hang in the first real N > 1 run costs more than 15 us per step ever returns."""
+    v = os.environ.get("DD3D_GRAPH_EXCHANGE", "0").strip().lower()
+    return v if v in ("0", "1", "probe") else "0"
+
+
+_PROBE_RESULT = {}
+
+
+def graph_exchange_probe(group=None, timeout_s=20.0):
+    """Can THIS transport replay a captured all_gather?  Captures a tiny all_gather_into_tensor (on a communicator of its own, so that a
+    failure cannot poison the one the steps use) into a hipGraph, replays it twice on changing inputs, checks what arrived on every rank
+    and takes the AND over the ranks (one eager all_reduce), so that every rank reaches the same decision.  A capture error or wrong
+    data -> False; a replay that does not complete within `timeout_s` -> False as well (the probe's stream and communicator are then
+    abandoned).  Cached per process."""
+    key = id(group)
+    if key in _PROBE_RESULT:
+        return _PROBE_RESULT[key]
+    ok = False
+    if dist.is_initialized() and dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+        import time
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        try:
+            pg = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group), backend="nccl")
+            dev = torch.device("cuda", torch.cuda.current_device())
+            src = torch.zeros(64, dtype=torch.float32, device=dev)
+            dst = torch.zeros(64 * world, dtype=torch.float32, device=dev)
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                src.fill_(float(rank) + 0.25)
+                dist.all_gather_into_tensor(dst, src, group=pg)  # eager first: creates the communicator outside the capture
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    dist.all_gather_into_tensor(dst, src, group=pg)
+                good = True
+                for it in range(2):
+                    src.fill_(1000.0 * (it + 1) + rank)
+                    dst.zero_()
+                    g.replay()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    t0 = time.perf_counter()
+                    while not ev.query():
+                        if time.perf_counter() - t0 > timeout_s:
+                            raise TimeoutError("captured all_gather did not complete")
+                        time.sleep(0.001)
+                    want = torch.arange(world, dtype=torch.float32, device=dev).repeat_interleave(64) + 1000.0 * (it + 1)
+                    good = good and bool(torch.equal(dst, want))
+            ok = good
+        except Exception as e:  # capture not supported by this RCCL build / timeout: the eager exchange stays
+            import warnings
+            warnings.warn(f"dd3d_amd: the all_gather cannot be captured in a hipGraph on this transport ({type(e).__name__}: {e}); "
+                          "the exchange runs eagerly between the two graph halves")
+            ok = False
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+        ok = bool(int(verdict.item()))
+    _PROBE_RESULT[key] = ok
+    return ok
+
+
 def graph_exchange_enabled(group=None):
-    """DD3D_GRAPH_EXCHANGE=1 and a device transport (RCCL): the step's all_gather may be captured inside its hipGraph."""
-    return (os.environ.get("DD3D_GRAPH_EXCHANGE", "0") == "1" and dist.is_initialized() and dist.get_backend(group) == "nccl")
+    """The step's all_gather is captured inside its hipGraph: DD3D_GRAPH_EXCHANGE=1, or =probe and the probe passed; a device transport
+    (RCCL) in any case."""
+    mode = graph_exchange_mode()
+    if mode == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return False
+    return True if mode == "1" else graph_exchange_probe(group)
+
+
+def device_identity():
+    """What tells two ranks' GPUs apart: host, HIP device ordinal, PCI bus id, name, memory -- gathered by `exchange_selftest` so that a
+    multi-GPU run can show that RCCL saw N DISTINCT devices."""
+    import socket
+    d = {"host": socket.gethostname(), "pid": os.getpid(), "device": None, "pci_bus_id": None, "name": None, "total_memory_gib": None,
+         "visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")}
+    if torch.cuda.is_available():
+        i = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(i)
+        d.update(device=i, name=pr.name, total_memory_gib=round(pr.total_memory / 2**30, 1))
+        try:  # (PyTorch >= 2.4 exposes it; the ordinal + host still identify the device without it)
+            d["pci_bus_id"] = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except AttributeError:
+            pass
+        try:
+            d["uuid"] = str(pr.uuid)
+        except AttributeError:
+            pass
+    return d
+
+
+def exchange_selftest(group=None, words=4096, timeout_s=120.0, device=None):
+    """Start-up check of the step's transport, BEFORE any graph is captured: one small all_gather_into_tensor of a rank-stamped record and
+    a checksum of what arrived, so that a transport that cannot carry the exchange fails fast and says why, instead of hanging the first
+    step inside a hipGraph.  The wait is a polled event with a deadline (a stuck RCCL kernel would block a plain synchronize forever).
+    Also gathers every rank's `device_identity`.  Returns {"nranks", "backend", "ms", "devices": [...], "distinct_devices"}; raises
+    RuntimeError on a timeout, wrong data, or two ranks of an RCCL job on the same GPU.  One rank / no process group: a no-op record."""
+    import time
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {"nranks": 1, "backend": None, "ms": 0.0, "devices": [device_identity()], "distinct_devices": 1}
+    world, rank, backend = dist.get_world_size(group), dist.get_rank(group), dist.get_backend(group)
+    on_gpu = backend == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    stamp = lambda r: torch.arange(words, dtype=torch.float32) * 0.5 + 7919.0 * (r + 1)
+    src = stamp(rank).to(dev)
+    dst = torch.zeros(world * words, dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
+    work = dist.all_gather_into_tensor(dst, src, group=group, async_op=True)
+    if on_gpu:
+        ev = torch.cuda.Event()
+        work.wait()  # (orders the current stream behind the collective; does not block the host)
+        ev.record()
+        while not ev.query():
+            if time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError(
+                    f"dd3d_amd exchange self-test: rank {rank}/{world} on {device_identity()} waited {timeout_s:.0f} s for one {4 * words}-byte "
+                    "all_gather over RCCL.  Check that every rank sees its own GPU (LOCAL_RANK -> torch.cuda.set_device), that "
+                    "HSA_ENABLE_IPC_MODE_LEGACY=0 is exported (dmabuf IPC), and that MASTER_ADDR is reachable (127.0.0.1 on one node)")
+            time.sleep(0.0005)
+    else:
+        from datetime import timedelta
+        if not work.wait(timedelta(seconds=timeout_s)):
+            raise RuntimeError(f"dd3d_amd exchange self-test: rank {rank}/{world}: the {backend} all_gather did not complete in {timeout_s:.0f} s")
+    ms = (time.perf_counter() - t0) * 1e3
+    got = dst.cpu().view(world, words)
+    bad = [r for r in range(world) if not torch.equal(got[r], stamp(r))]
+    if bad:
+        raise RuntimeError(f"dd3d_amd exchange self-test: rank {rank}/{world} received wrong records from rank(s) {bad} over {backend}")
+    idents = [None] * world
+    dist.all_gather_object(idents, device_identity(), group=group)
+    keys = {(d["host"], d.get("pci_bus_id") or d["device"]) for d in idents}
+    if on_gpu and len(keys) != world:
+        raise RuntimeError(f"dd3d_amd exchange self-test: {world} RCCL ranks share {len(keys)} GPU(s): {idents}")
+    return {"nranks": world, "backend": backend, "ms": round(ms, 3), "devices": idents, "distinct_devices": len(keys)}
+
+
+_SELFTEST = {}
+
+
+def ensure_exchange_ready(group=None):
+    """`exchange_selftest` once per process and process group: both runners call it before they capture any graph."""
+    key = id(group)
+    if key not in _SELFTEST:
+        _SELFTEST[key] = exchange_selftest(group)
+    return _SELFTEST[key]
 
 
 def gather_candidates(pairs, group=None):
@@ -132,6 +289,7 @@ class DistributedForward:
         # force_exchange=False with several ranks drops the collective (per-image results only; never with camera_sharded)
         self.exchange = (self.world > 1 and force_exchange is not False) or bool(force_exchange) or self.camera_sharded
         self.B, self._geometry, self.use_graph = B, (Hp, Wp), use_graph
+        self.transport = ensure_exchange_ready() if (self.exchange and self.world > 1) else None  # fails fast, before any graph is captured
         self._build()
 
     def _build(self):
@@ -143,7 +301,7 @@ class DistributedForward:
             # the collective sits between two captured halves
             p.launch()
             torch.cuda.synchronize()
-            if graph_exchange_enabled():
+            if graph_exchange_enabled(None):
                 # DD3D_GRAPH_EXCHANGE=1 (experimental; round-3 verdict item): the RCCL all_gather is captured INSIDE the step's graph -- one
                 # replay per step instead of replay / collective / replay.  The communicator is created by an eager collective first (a
                 # capture must not contain its initialisation).  Validated with ONE rank only (tests/gpu_rccl_check.py graph): no
@@ -223,6 +381,79 @@ class DistributedForward:
         return out
 
 
+class _DeviceRuntime:
+    """What PipelinedForward needs of the device: streams, events, graph capture.  The product runtime is HIP through torch.cuda."""
+    dry_run = False
+
+    def stream(self):
+        return torch.cuda.Stream()
+
+    def event(self):
+        return torch.cuda.Event()
+
+    def on(self, stream):
+        return torch.cuda.stream(stream)
+
+    def current_stream(self):
+        return torch.cuda.current_stream()
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+
+    def warm(self, plan):
+        plan.launch()  # outside capture: sets kernel attributes, faults pages
+        torch.cuda.synchronize()
+
+    def capture(self, slot, plan, first, last, half):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            plan.launch(first, last)
+        return g
+
+
+class HostOrderRuntime(_DeviceRuntime):
+    """Test runtime (tests/test_parallel_cpu.py): no device -- streams and events are no-ops, everything runs synchronously in issue order on
+    dry-run launch plans, and a "graph replay" calls `pre_hook(slot)` / `post_hook(slot)` instead of kernels.  What remains is exactly the
+    host logic whose ORDER matters across ranks: which slot's collective is issued when (slot ring wrap-around, micro-batches, flushes, the
+    range-guard fallback's re-issue order), driven over a real process group (gloo) with several ranks."""
+    dry_run = True
+
+    class _Null:
+        def wait_event(self, *a):
+            pass
+
+        wait_stream = record = synchronize = wait_event
+
+        def query(self):
+            return True
+
+    class _Replay:
+        def __init__(self, fn):
+            self.replay = fn
+
+    def __init__(self, pre_hook=None, post_hook=None):
+        self.pre_hook, self.post_hook = pre_hook, post_hook
+
+    def stream(self):
+        return self._Null()
+
+    event = current_stream = stream
+
+    def on(self, stream):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def synchronize(self):
+        pass
+
+    def warm(self, plan):
+        pass
+
+    def capture(self, slot, plan, first, last, half):
+        hook = self.pre_hook if half == "pre" else self.post_hook
+        return self._Replay((lambda: hook(slot)) if hook is not None else (lambda: None))
+
+
 class PipelinedForward:
     """Throughput mode of the same step: `depth` plan slots (each with its own activation buffers and its own pair of captured hipGraph
     halves; the packed weights are the model's, shared by all slots); the trunk + heads + select/decode of step i+1 run on a compute
@@ -246,22 +477,24 @@ class PipelinedForward:
     range, `result()` -- on a model on the default arithmetic -- drains the pipeline, rebuilds every slot on the three-term bf16 split,
     re-runs the requests in flight and returns (what `DD3D.forward` does for a single forward).  With several ranks the verdict of every
     rank travels in the exchanged records, so all ranks take this path for the same slot run."""
-    def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1, microbatch=1):
-        from dd3d_amd.engine import ForwardPlan
+    def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1, microbatch=1, runtime=None):
         assert depth >= 1 and compute_streams >= 1 and microbatch >= 1
         self.model = model
+        self.rt = rt = runtime or _DeviceRuntime()
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.exchange = self.world > 1 or bool(force_exchange)
+        self.transport = ensure_exchange_ready() if (self.exchange and self.world > 1) else None  # fails fast, before any graph is captured
         self.B, self.microbatch = B, int(microbatch)
         model._sync_flags()
         # compute_streams > 1: consecutive steps' trunks are issued on different streams and may share the chip
-        self.compute_streams = [torch.cuda.Stream() for _ in range(compute_streams)]
-        self.post_stream = torch.cuda.Stream()
+        self.compute_streams = [rt.stream() for _ in range(compute_streams)]
+        self.post_stream = rt.stream()
         self.slots = []
         for i in range(depth):
             slot = type("Slot", (), {})()
-            slot.pre_done, slot.post_done, slot.released = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            slot.index = i
+            slot.pre_done, slot.post_done, slot.released = rt.event(), rt.event(), rt.event()
             slot.post_done.record()
             slot.released.record()
             slot.requests = [None] * self.microbatch  # (inputs, image_sizes) of the requests staged into the slot
@@ -279,28 +512,27 @@ class PipelinedForward:
         """(Re)build every slot's launch plan and pair of graph halves for the model's current arithmetic, and replay them once."""
         from dd3d_amd.engine import ForwardPlan
         Hp, Wp = self._geometry
+        rt = self.rt
         for slot in self.slots:
-            p = ForwardPlan(self.model, self.B * self.microbatch, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange)
-            p.launch()  # warm-up outside capture
-            torch.cuda.synchronize()
-            pre, post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(pre):
-                p.launch(0, p.num_pre_nms_ops)
-            with torch.cuda.graph(post):
-                p.launch(p.num_pre_nms_ops)
-            slot.plan, slot.pre_graph, slot.post_graph = p, pre, post
-        torch.cuda.synchronize()
+            extra = dict(device="cpu", dry_run=True) if rt.dry_run else {}
+            p = ForwardPlan(self.model, self.B * self.microbatch, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange, **extra)
+            rt.warm(p)
+            slot.plan = p
+            slot.pre_graph = rt.capture(slot, p, 0, p.num_pre_nms_ops, "pre")
+            slot.post_graph = rt.capture(slot, p, p.num_pre_nms_ops, None, "post")
+        rt.synchronize()
         # first replay of every slot's graphs (a hipGraph's first launch uploads it: ~10x a steady replay), on the streams they will use;
         # a collective is NOT issued here (the ranks would have to agree on it) -- the post half runs on the zeroed record
-        for slot in self.slots:
-            with torch.cuda.stream(slot.compute_stream):
-                slot.pre_graph.replay()
-                slot.pre_done.record(slot.compute_stream)
-            self.post_stream.wait_event(slot.pre_done)
-            with torch.cuda.stream(self.post_stream):
-                slot.post_graph.replay()
-                slot.post_done.record(self.post_stream)
-        torch.cuda.synchronize()
+        if not rt.dry_run:
+            for slot in self.slots:
+                with rt.on(slot.compute_stream):
+                    slot.pre_graph.replay()
+                    slot.pre_done.record(slot.compute_stream)
+                self.post_stream.wait_event(slot.pre_done)
+                with rt.on(self.post_stream):
+                    slot.post_graph.replay()
+                    slot.post_done.record(self.post_stream)
+            rt.synchronize()
         for slot in self.slots:
             slot.plan.status.zero_()
         self.plan = self.slots[0].plan
@@ -329,7 +561,7 @@ class PipelinedForward:
             staged = [(j, r) for j, r in enumerate(slot.requests[:slot.fill]) if r is not None]
             if slot.generation == 0 or not staged or all(slot.collected[j] for j, _ in staged):
                 continue
-            with torch.cuda.stream(slot.compute_stream):
+            with self.rt.on(slot.compute_stream):
                 for j, (inputs, _) in staged:
                     self.model.stage_inputs(inputs, plan=slot.plan, first=j * self.B, partial=True)
             if slot.enqueued:
@@ -337,12 +569,12 @@ class PipelinedForward:
 
     def _enqueue(self, slot):
         cs, ps = slot.compute_stream, self.post_stream
-        with torch.cuda.stream(cs):
+        with self.rt.on(cs):
             slot.pre_graph.replay()
             slot.pre_done.record(cs)
         ps.wait_event(slot.pre_done)
         ps.wait_event(slot.released)
-        with torch.cuda.stream(ps):
+        with self.rt.on(ps):
             if self.exchange:
                 gather_candidates(slot.plan.gather_pairs())
             slot.post_graph.replay()
@@ -391,17 +623,17 @@ class PipelinedForward:
         for slot in self.slots:
             for j in range(self.microbatch):
                 self.model.stage_inputs(batched_inputs, plan=slot.plan, first=j * self.B, partial=True)
-        torch.cuda.synchronize()
+        self.rt.synchronize()
 
     def submit(self, batched_inputs):
         slot, j = self._position()
         # device-resident inputs (DeviceInputMapper / DeviceResizer outputs) were produced on the caller's current stream: the staging
         # copies on the slot's compute stream must order after them, and the allocator must not recycle them before the copies ran
-        slot.compute_stream.wait_stream(torch.cuda.current_stream())
+        slot.compute_stream.wait_stream(self.rt.current_stream())
         for x in batched_inputs:
             if x["image"].is_cuda:
                 x["image"].record_stream(slot.compute_stream)
-        with torch.cuda.stream(slot.compute_stream):
+        with self.rt.on(slot.compute_stream):
             _, image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan, first=j * self.B, partial=True)
         slot.requests[j] = (batched_inputs, image_sizes)
         if slot.fill == self.microbatch:

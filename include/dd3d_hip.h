@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DD3D_ABI_VERSION 4
+#define DD3D_ABI_VERSION 5
 
 #define DD3D_OK 0
 #define DD3D_E_INVALID (-1)  /* bad argument (shape / alignment / enum) */
@@ -44,6 +44,10 @@ int dd3d_abi_version(void);
 const char* dd3d_last_error(void);
 /* "gfx950" -- the only architecture the code objects are built for. */
 const char* dd3d_arch(void);
+/* "" for the product build.  Otherwise the -DDD3D_...=... knobs the library's translation units were compiled with ("file: KNOB=value; ..."):
+ * an A/B variant (tests/tools/build_variant.sh; every knob still computes correct results).  dd3d_amd/hip.py refuses such a library unless the
+ * caller selected it explicitly. */
+const char* dd3d_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on f32 MFMA (v_mfma_f32_32x32x2_f32), fused epilogue.
@@ -106,8 +110,14 @@ typedef struct dd3d_conv_launch {  /* host memory */
   int32_t* tile_counters; /* device, ceil(N/BN) * ntiles int32, ZERO on entry when splitk > 1 (else NULL).  The slice of an
                              output tile that arrives last sums the partial slabs in slice order and applies the epilogue
                              inside the same launch; the counters are zero again when the launch has completed. */
-  const dd3d_conv_seg* seg0_host; /* HOST copy of segs[0], or NULL.  With nsegs == 1 the descriptor then travels in the kernel
-                                     arguments (tiles are taken as m0 = i * BM) and the device copies are not read. */
+  const dd3d_conv_seg* seg0_host; /* HOST copy of segs[0 .. nsegs-1], or NULL.  With nsegs == 1 the descriptor then travels in the kernel
+                                     arguments (tiles are taken as m0 = i * BM) and the device copies are not read.  With a host copy the
+                                     library VALIDATES every segment's residual contract before launching (ABI 5); without one (NULL) the
+                                     caller vouches for the device-side descriptors:
+                                       res_mode in 0..3 and res != NULL unless 0; res_mode 2 / 3 only with in_planes;
+                                       res_mode 3: even Ho, Wo;  DD3D_TILE_256x256_W8: res_mode 0 (its waves hold no residual);
+                                       res_mode 1 with in_planes: res_pitch % 4 == 0 and res_pitch >= (channels stored rounded up to 4)
+                                       -- the epilogue reads the residual row in 16-byte pieces. */
   int32_t in_relu; /* 1: the input is rectified on the fly, out = epilogue(conv(max(in, 0))) -- LastLevelP6P7: p7 = conv(relu(p6)).
                       DD3D_MATH_BF16X3 with f32 input only */
   int32_t in_planes; /* 1: every segment reads its split-plane input (seg.in_planes) instead of the f32 one; Cin % 32 == 0 and a

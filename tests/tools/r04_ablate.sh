@@ -1,5 +1,6 @@
 #!/bin/bash
-# What bounds the K loop of the backbone-sized convolutions: the shipped kernels against builds that drop one ingredient (wrong results).
+# What bounds the K loop of the backbone-sized convolutions: the shipped kernels against builds that drop one ingredient (wrong results;
+# build them with: for v in DMA MFMA DSREAD EPI; do bash tests/tools/build_variant.sh abl_$v --ablations -DDD3D_ABLATE_$v; done).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04c
 mkdir -p $O
