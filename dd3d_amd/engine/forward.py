@@ -1,0 +1,544 @@
+"""Launch-plan builder and executor of the DD3D forward path on MI355X.
+
+``ForwardPlan`` walks the parameter tree of a ``DD3D`` model once per input geometry (B, Hp, Wp), packs the
+weights (filters re-ordered for the implicit-GEMM K order, norms folded into per-channel scale/shift), lays
+out every activation as an NHWC fp32 buffer in HBM and records the sequence of libdd3d_hip launches.
+``run()`` replays that sequence on the current HIP stream -- either launch by launch or as one captured
+hipGraph -- with no host synchronisation between the uint8 image and the final detection buffer.
+
+PyTorch is used here for device memory, streams and graph capture only; all arithmetic is in
+dd3d_amd/csrc (C ABI: include/dd3d_hip.h).
+
+Reference behaviour being reproduced: tridet/modeling/dd3d/core.py:64-164 (DD3D.forward, inference branch).
+"""
+import ctypes as C
+import math
+import os
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from dd3d_amd import hip
+from dd3d_amd.layers import fold_norm
+
+from dd3d_amd.engine.backbones import BackboneLowering
+from dd3d_amd.engine.ops import CallOp, ConvOp
+from dd3d_amd.engine.plan import PlanBase
+from dd3d_amd.engine.tiling import MATH_NAMES
+
+
+class ForwardPlan(PlanBase, BackboneLowering):
+    """Static launch plan of DD3D.forward (inference) for one (B, Hp, Wp)."""
+    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0, exchange=None, camera_sharded=False):
+        super().__init__(device or model.device, dry_run=dry_run)
+        self.camera_sharded = camera_sharded
+        # the candidate exchange between select/decode and NMS exists when there are several ranks; `exchange=True` keeps its
+        # buffers and the two-phase launch for one rank too (single-GPU check of the RCCL transport, tests/gpu_rccl_check.py)
+        self.exchange = world_size > 1 if exchange is None else bool(exchange)
+        self.adopt_weight_store(model)
+        self._trunk(model, B, Hp, Wp)
+        # ---- heads + post-processing
+        self._heads(model, self.features)
+        self._postprocess(model, world_size, rank)
+
+    def _trunk(self, model, B, Hp, Wp):
+        """Static inputs, pre-processing, backbone and FPN (shared with DenseDepthPlan)."""
+        if getattr(model, "math", None) is not None:
+            self.math = MATH_NAMES[model.math] if isinstance(model.math, str) else int(model.math)
+        self.model = model
+        self.B, self.Hp, self.Wp = B, Hp, Wp
+        dev = self.device
+
+        # ---- static inputs
+        self.in_u8 = torch.zeros((B, 3, Hp, Wp), dtype=torch.uint8, device=dev)
+        self.in_sizes = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        self.in_K = torch.zeros((B, 9), dtype=torch.float32, device=dev)
+        self.in_outsize = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        self.inv_K = torch.zeros((B, 9), dtype=torch.float32, device=dev)
+
+        # ---- preprocess.  With the fused stem (DLA, two-half-term arithmetic: FusedStemOp) the normalised image exists only inside
+        # that kernel's LDS tiles; `normalized_image()` produces it on demand (tests).
+        from dd3d_amd.modeling.dla import DLA
+        bb = model.backbone
+        self.fused_stem = self._can_fuse_stem(bb.bottom_up) if isinstance(bb.bottom_up, DLA) else False
+        self._norm = ((C.c_float * 3)(*[float(v) for v in model.pixel_mean.flatten().tolist()]),
+                      (C.c_float * 3)(*[float(v) for v in model.pixel_std.flatten().tolist()]))
+        img = self.buf("img4", B, Hp, Wp, 4) if (not self.fused_stem or self.dry_run) else None
+
+        def _pre(lib, st, img=img):
+            self.amax[:max(1, len(self.amax_names))].zero_()  # (captured with the rest of the forward: the maxima are per forward)
+            if img is not None:
+                hip.check(
+                    lib.dd3d_preprocess_u8_nhwc4(self.in_u8.data_ptr(), self.in_sizes.data_ptr(), img.t.data_ptr(), B, Hp, Wp, self._norm[0], self._norm[1], st),
+                    "preprocess"
+                )
+            hip.check(lib.dd3d_invert_intrinsics(self.in_K.data_ptr(), self.inv_K.data_ptr(), B, st), "invert_intrinsics")
+
+        self.ops.append(CallOp(_pre, "preprocess", dict(kind="preprocess", img=img, mean=list(self._norm[0]), std=list(self._norm[1]))))
+
+        # ---- backbone + FPN
+        img_view = img.view() if img is not None else None  # (None: the fused stem reads the uint8 input itself)
+        if isinstance(bb.bottom_up, DLA):
+            feats = self._dla(bb.bottom_up, img_view)
+        else:
+            feats = self._vovnet(bb.bottom_up, img_view)
+        self.bottom_up = feats
+        outs = self._fpn(bb, feats)  # name -> view, finest first
+        # the heads see DD3D.IN_FEATURES (core.py:32-34,84): all FPN outputs in every reference config, a subset is allowed
+        self.features = [outs[n] for n in getattr(model, "in_features", list(outs))]
+        if self.fpn_tail_join is not None:
+            self.join(self.fpn_tail_join)  # P6 / P7 (side branch) feed the towers
+        self.strides = [s.stride for s in model.backbone_output_shape]
+
+    def normalized_image(self):
+        """The padded, normalised input canvas (B, 3, Hp, Wp) as the preprocess kernel writes it -- from the plan's buffer when the plan
+        has one, else (fused stem) by running that kernel into a scratch buffer on the current stream."""
+        if "img4" in self.bufs:
+            return self.bufs["img4"].nchw(0, 3)
+        t = torch.zeros((self.B, self.Hp, self.Wp, 4), dtype=torch.float32, device=self.device)
+        hip.check(self.lib.dd3d_preprocess_u8_nhwc4(self.in_u8.data_ptr(), self.in_sizes.data_ptr(), t.data_ptr(), self.B, self.Hp, self.Wp,
+                                                    self._norm[0], self._norm[1], hip.current_stream()), "preprocess")
+        return t[..., :3].permute(0, 3, 1, 2)
+
+    # ------------------------------------------------------------------ heads (fcos2d.py:130-156, fcos3d.py:160-188)
+    def _heads(self, model, feats):
+        dev = self.device
+        h2, h3 = model.fcos2d_head, (None if model.only_box2d else model.fcos3d_head)
+        L = len(feats)
+        towers = [("cls", h2.cls_tower), ("box2d", h2.box2d_tower)] + ([("box3d", h3.box3d_tower)] if h3 is not None else [])
+        nt = len(towers)
+        Cf = feats[0].C
+        depth = max(len(t) for _, t in towers)
+        ping = [self.buf(f"towerA.{l}", f.B, f.H, f.W, nt * Cf, kind="planes") for l, f in enumerate(feats)]  # conv -> conv only
+        pong = [self.buf(f"towerB.{l}", f.B, f.H, f.W, nt * Cf, kind="planes") for l, f in enumerate(feats)]
+        cur = [[feats[l] for _ in range(nt)] for l in range(L)]  # current input view per (level, tower)
+        for i in range(depth):
+            dstbufs = ping if i % 2 == 0 else pong
+            segs, meta = [], None
+            for t, (tname, tower) in enumerate(towers):
+                if i >= len(tower):
+                    continue
+                conv = tower[i]
+                w, meta = self.pack(conv.weight)
+                for l in range(L):
+                    # ModuleListDial: level l uses norm[l] (normalization.py:30-40)
+                    norm = conv.norm[l] if isinstance(conv.norm, torch.nn.ModuleList) else conv.norm
+                    scale, shift = fold_norm(conv, norm)
+                    out = dstbufs[l].view(t * Cf, Cf)
+                    segs.append({"in": cur[l][t], "out": out, "w": w, "scale": self._vec(scale), "bias": self._vec(shift)})
+                    cur[l][t] = out
+            self.ops.append(ConvOp(self, meta, 1, 1, segs, relu=True, name=f"towers.{i}"))
+        self.tower_out = cur
+
+        C_ = model.num_classes
+
+        pred_groups = []  # every predictor group becomes a set of segments of ONE launch (see the end of this method)
+
+        def fused_predictor(name, convs, tower_idx, level_scale, level_bias_extra, lo):
+            """convs: list of (module per level-or-shared) concatenated along N.  level_scale(l) -> per-channel scale vector."""
+            ws, metas = {}, None
+            n_total = sum(c[0].out_channels for c in convs)
+            pitch = (n_total + 3) // 4 * 4
+            segs, maps = [], []
+            for l in range(L):
+                key = tuple(id(c[l if len(c) > 1 else 0]) for c in convs)
+                if key not in ws:
+                    mods = [c[l if len(c) > 1 else 0] for c in convs]
+                    w, metas = self.pack([m.weight for m in mods])
+                    b = torch.cat([
+                        m.bias.detach().float().cpu() if m.bias is not None else torch.zeros(m.out_channels) for m in mods
+                    ])
+                    ws[key] = (w, b)
+                w, b = ws[key]
+                sc = level_scale(l)
+                bias = b * sc + level_bias_extra(l)  # (conv + b) * scale + offset, cf. fcos2d.py:146-150, fcos3d.py:175-180
+                f = feats[l]
+                out = self.buf(f"{name}.{l}", f.B, f.H, f.W, pitch)
+                maps.append(out)
+                segs.append({
+                    "in": cur[l][tower_idx], "out": out.view(0, pitch), "w": w, "scale": self._vec(sc), "bias": self._vec(bias),
+                    "lo": None if lo is None else self._vec(lo), "n_limit": n_total
+                })
+            pred_groups.append((name, metas, segs))
+            return maps, pitch
+
+        ones = lambda n: torch.ones(n)
+        zeros = lambda n: torch.zeros(n)
+        # cls logits (+ nuScenes attr/speed on the cls tower, nuscenes_dd3d.py:371-374)
+        cls_convs = [[h2.cls_logits]]
+        n_cls_extra = 0
+        if hasattr(model, "attr_logits"):
+            cls_convs += [[model.attr_logits], [model.speed]]
+            n_cls_extra = model.attr_logits.out_channels + model.speed.out_channels
+        n_cls = C_ + n_cls_extra
+        lo_cls = None
+        if n_cls_extra:
+            lo_cls = torch.full((n_cls, ), -float("inf"))
+            lo_cls[-1] = 0.0  # speed = relu(conv)
+        self.cls_maps, self.cls_pitch = fused_predictor("cls_map", cls_convs, 0, lambda l: ones(n_cls), lambda l: zeros(n_cls), lo_cls)
+
+        # box2d_reg (scale_l, relu) + centerness  (fcos2d.py:143-152)
+        def s2(l):
+            s = h2.scales_box2d_reg[l].scale.detach().float().cpu() if h2.use_scale else torch.ones(1)
+            return torch.cat([s.expand(4), torch.ones(1)])
+
+        lo2 = torch.tensor([0., 0., 0., 0., -float("inf")])
+        self.b2d_maps, self.b2d_pitch = fused_predictor(
+            "box2d_map", [[h2.box2d_reg], [h2.centerness]], 1, s2, lambda l: zeros(5), lo2
+        )
+
+        self.b3d_maps, self.b3d_pitch = None, 0
+        if h3 is not None:
+            C3 = 1 if h3.class_agnostic else C_
+
+            def s3(l):
+                if not h3.use_scale:
+                    return ones(11 * C3)
+                g = lambda ml: ml[l].scale.detach().float().cpu()
+                return torch.cat([
+                    ones(4 * C3), g(h3.scales_proj_ctr).expand(2 * C3), g(h3.scales_depth).expand(C3), g(h3.scales_size).expand(3 * C3),
+                    g(h3.scales_conf).expand(C3)
+                ])
+
+            def b3(l):
+                o = zeros(11 * C3)
+                if h3.use_scale:
+                    o[6 * C3:7 * C3] = h3.offsets_depth[l].bias.detach().float().cpu()
+                return o
+
+            preds = [list(h3.box3d_quat), list(h3.box3d_ctr), list(h3.box3d_depth), list(h3.box3d_size), list(h3.box3d_conf)]
+            self.b3d_maps, self.b3d_pitch = fused_predictor("box3d_map", preds, 2, s3, b3, None)
+
+        # Predictor launches.  Round 3: ONE launch, the narrow groups (C or 5 channels) riding along with the widest (11 * C) as extra
+        # segments zero-padded to its Npad -- 192 executed output columns for 63 useful ones, and a kernel form that skipped the unstored
+        # column blocks changed nothing (the idle waves still sat behind the block's barriers).  Round 4: the groups of <= 32 channels
+        # (cls logits (+ nuScenes attr / speed), box2d + centerness) run on the 32-column tile DD3D_TILE_128x32_W4 in their own launch --
+        # blocks for columns nobody stores are never created -- and the wide group(s) keep the measured tile.  DD3D_PRED_SPLIT=0: round 3's form.
+        split = os.environ.get("DD3D_PRED_SPLIT", "1") != "0" and self.use_planes
+        narrow = [g for g in pred_groups if split and g[1]["N"] <= 32]
+        wide = [g for g in pred_groups if g not in narrow]
+        for groups, tile, name in ((narrow, hip.TILE_128x32_W4, "predictors.narrow"), (wide, None, "predictors")):
+            if not groups:
+                continue
+            n_max = max(m["N"] for _, m, _ in groups)
+            npad = (n_max + 31) // 32 * 32
+            meta = dict(groups[0][1], N=n_max, Npad=npad)
+            all_segs = []
+            for _, m, segs in groups:
+                assert (m["Cin"], m["KH"], m["KW"], m["Kpad"]) == (meta["Cin"], meta["KH"], meta["KW"], meta["Kpad"])
+                for sg in segs:
+                    key = ("predictor_pad", sg["w"].data_ptr(), npad)
+                    if key not in self._packed:  # (the store keeps the source referenced: its address is the key)
+                        wpad = torch.zeros((npad, m["Kpad"]), dtype=torch.float32, device=dev)
+                        wpad[:sg["w"].shape[0]] = sg["w"]
+                        self._packed[key] = (sg["w"], wpad)
+                    all_segs.append(dict(sg, w=self._packed[key][1]))
+            self.ops.append(ConvOp(self, meta, 1, 1, all_segs, relu=False, name=name, tile=tile if npad == 32 else None))
+
+    # ------------------------------------------------------------------ selection / decode / NMS
+    def _postprocess(self, model, world_size, rank=0):
+        cfg, dev, B = model.cfg, self.device, self.B
+        L = len(self.features)
+        inf2 = cfg.DD3D.FCOS2D.INFERENCE
+        topk = int(inf2.PRE_NMS_TOPK)
+        C_ = model.num_classes
+        # candidate slots per image: level l can never hold more than H*W*C candidates, so it gets min(topk, H*W*C) slots -- the
+        # buffer the ranks exchange carries no slot that cannot be filled (KITTI 384x1280: 3750 instead of 5000 slots)
+        caps = [min(topk, f.H * f.W * C_) for f in self.features]
+        self.slot_off = [sum(caps[:l]) for l in range(L + 1)]
+        NS = self.slot_off[L]
+        self.topk, self.num_levels, self.slots_per_image = topk, L, NS
+        a = hip.SelectArgs()
+        sizes = []
+        for l, f in enumerate(self.features):
+            a.cls[l] = self.cls_maps[l].t.data_ptr()
+            a.box2d[l] = self.b2d_maps[l].t.data_ptr()
+            a.box3d[l] = self.b3d_maps[l].t.data_ptr() if self.b3d_maps is not None else None
+            a.H[l], a.W[l], a.stride[l] = f.H, f.W, self.strides[l]
+            sizes.append(f.H * f.W * C_)
+        a.cls_pitch, a.b2d_pitch, a.b3d_pitch = self.cls_pitch, self.b2d_pitch, self.b3d_pitch
+        a.num_levels, a.B, a.num_classes = L, B, C_
+        a.loc_offset_half = int(cfg.DD3D.FEATURE_LOCATIONS_OFFSET == "half")
+        a.thresh_with_ctr = int(bool(inf2.THRESH_WITH_CTR))
+        a.topk, a.pre_nms_thresh = topk, float(inf2.PRE_NMS_THRESH)
+        a.attr_off, a.num_attr, a.speed_off = 0, 0, -1
+        if hasattr(model, "attr_logits"):  # nuScenes extras ride on the cls map (see _heads)
+            a.attr_off, a.num_attr = C_, model.attr_logits.out_channels
+            a.speed_off = C_ + model.attr_logits.out_channels
+        if self.b3d_maps is not None:
+            c3 = cfg.DD3D.FCOS3D
+            a.class_agnostic_3d = int(bool(c3.CLASS_AGNOSTIC_BOX3D))
+            a.min_depth, a.max_depth = float(c3.MIN_DEPTH), float(c3.MAX_DEPTH)
+            a.focal_factor = float(c3.SCALE_DEPTH_BY_FOCAL_LENGTHS_FACTOR)
+            a.scale_depth_by_focal = int(bool(c3.SCALE_DEPTH_BY_FOCAL_LENGTHS))
+            a.allocentric = int(bool(c3.PREDICT_ALLOCENTRIC_ROT))
+            a.depth_is_distance = int(bool(c3.PREDICT_DISTANCE))
+            self.canon = torch.tensor([list(r) for r in c3.CANONICAL_BOX3D_SIZES], dtype=torch.float32, device=dev)
+            a.canon_sizes = self.canon.data_ptr()
+        a.inv_K = self.inv_K.data_ptr()
+        off = 0
+        for l in range(L):
+            a.scratch_off[l] = off
+            off += sizes[l]
+        a.scratch_img_stride = off
+        for l in range(L + 1):
+            a.slot_off[l] = self.slot_off[l]
+        self.scratch_idx = torch.empty(B * off, dtype=torch.int32, device=dev)
+        self.scratch_score = torch.empty(B * off, dtype=torch.float32, device=dev)
+        # What a rank hands to the others is ONE contiguous record of 4-byte words:
+        #   [candidates B x F x NS | counts B x L | resize targets B x 4 | K^-1 B x 9 | camera->global pose B x 7]
+        # (the last two are what the BEV stages need of an image beside its detections: with them in the record, the owner of a nuScenes
+        # sample can aggregate cameras that OTHER ranks decoded).  The post-select stages read records out of the gathered buffer, so
+        # they are ordered behind the collective.
+        pad4 = lambda n: (n + 3) // 4 * 4
+        n_c, n_k, n_o, n_i, n_p = pad4(B * hip.CAND_FIELDS * NS), pad4(B * L), pad4(B * 4), pad4(B * 9), pad4(B * 7)
+        self.record_fields = dict(cand=(0, hip.CAND_FIELDS * NS), counts=(n_c, L), outsize=(n_c + n_k, 4), inv_K=(n_c + n_k + n_o, 9),
+                                  pose=(n_c + n_k + n_o + n_i, 7))  # name -> (word offset in a record, words per image)
+        self.flags_off = n_c + n_k + n_o + n_i + n_p  # 4 words per RECORD (not per image): the rank's range-guard verdict (below)
+        self.record_len = self.flags_off + 4
+
+        def views(rec):
+            f = self.record_fields
+            cut = lambda name: rec[f[name][0]:f[name][0] + B * f[name][1]]
+            return (cut("cand").view(B, hip.CAND_FIELDS, NS), cut("counts").view(torch.int32).view(B, L), cut("outsize").view(B, 4),
+                    cut("inv_K").view(B, 9), cut("pose").view(B, 7))
+
+        self.record = torch.zeros(self.record_len, dtype=torch.float32, device=dev)
+        self.cand, self.counts, outsize, inv_K, pose = views(self.record)
+        outsize.copy_(self.in_outsize)
+        self.in_outsize = outsize  # stage_inputs writes the resize targets straight into the record
+        self.inv_K = inv_K         # dd3d_invert_intrinsics writes K^-1 straight into the record (the launch reads self.inv_K when it runs)
+        self.in_pose = pose
+        self.in_pose[:, 0] = 1.0   # identity rotation until stage_inputs fills it (models without BEV stages never do)
+        self.npass = torch.zeros((B, L), dtype=torch.int32, device=dev)
+        a.inv_K = self.inv_K.data_ptr()
+        a.scratch_idx, a.scratch_score = self.scratch_idx.data_ptr(), self.scratch_score.data_ptr()
+        a.cand, a.counts, a.npass = self.cand.data_ptr(), self.counts.data_ptr(), self.npass.data_ptr()
+        self.select_args = a
+        self.ops.append(CallOp(lambda lib, st: hip.check(lib.dd3d_fcos_select_decode(C.byref(a), st), "select_decode"), "select_decode"))
+        if self.exchange and self.math == hip.MATH_F16X2 and not self.dry_run:
+            # the rank's range-guard verdict (status bits, underflow flag) rides in its record: after the all_gather every rank sees every
+            # rank's and all of them raise / fall back on the SAME step (a rank that raised alone would leave its peers in the next collective)
+            flags = self.record[self.flags_off:self.flags_off + 4]
+
+            def _flags(lib, st, flags=flags):
+                hip.check(lib.dd3d_fold_range_flags(self.status.data_ptr(), self.amax.data_ptr(), len(self.amax_names), float(self.AMAX_FLOOR),
+                                                    flags.data_ptr(), st), "fold_range_flags")
+
+            self.ops.append(CallOp(_flags, "range_flags", dict(kind="range_flags")))
+        self.num_pre_nms_ops = len(self.ops)
+
+        # The exchange (dd3d_amd.parallel): every rank's record is all-gathered into `gathered` [W x record]; each rank then finalises
+        # the images it OWNS out of the gathered buffer (no rank repeats another rank's NMS):
+        #   * default -- its own B images, i.e. ITS segment (class-aware NMS is per image; a nuScenes sample's cameras are rank-local
+        #     when the caller shards whole samples, as the reference's InferenceGroupSampler does, group_sampler.py:30-35);
+        #   * camera_sharded (NuscenesDD3D, "images shard one-per-GPU"): global image g = rank * B + b, the 6 consecutive global images
+        #     6 s .. 6 s + 5 are the cameras of sample s, and the rank that decoded a sample's FIRST camera owns the sample: it runs the
+        #     2D NMS of all six cameras and the sample-level BEV aggregation on records other ranks delivered.
+        inf = cfg.DD3D.INFERENCE
+        bev_single = bool(inf.DO_BEV_NMS) and self.b3d_maps is not None
+        bev_sample = bool(getattr(model, "aggregates_samples", False)) and bool(inf.DO_POSTPROCESS) and self.b3d_maps is not None
+        self.world_size, self.rank = world_size, rank
+        self.camera_sharded = bool(self.camera_sharded)
+        if self.camera_sharded:
+            ncam = int(getattr(model, "num_images_per_sample", 6))
+            if not (self.exchange and bev_sample):
+                raise ValueError("camera_sharded needs the candidate exchange and a model that aggregates samples (NuscenesDD3D with DO_POSTPROCESS)")
+            if (world_size * B) % ncam:
+                raise ValueError(f"camera_sharded: {world_size} ranks x {B} images per step do not make whole {ncam}-camera samples")
+            own = [s_ for s_ in range(world_size * B // ncam) if (s_ * ncam) // B == rank]  # contiguous: the owner grows with the sample
+            self.own_samples = own
+            self.G = G = ncam * len(own)
+            self.img_first = ncam * own[0] if own else 0
+        else:
+            self.own_samples = None
+            self.G = G = B
+            self.img_first = rank * B if self.exchange else 0
+        if self.exchange:
+            self.gathered = torch.zeros(world_size * self.record_len, dtype=torch.float32, device=dev)
+            self.cand_all, self.counts_all, self.outsize_all, _, _ = views(self.gathered[rank * self.record_len:(rank + 1) * self.record_len])
+            src = self.gathered
+        else:
+            self.gathered = None
+            self.cand_all, self.counts_all, self.outsize_all = self.cand, self.counts, self.in_outsize
+            src = self.record
+
+        def field_ptr(name):  # record 0's block of a field in the buffer the post stages read
+            return src.data_ptr() + 4 * self.record_fields[name][0]
+
+        def addressing(args):
+            args.img_first, args.img_per_rec, args.rec_stride = (self.img_first, B, self.record_len) if self.exchange else (0, 0, 0)
+
+        self.has_bev_inputs = self.has_global_boxes = False
+        self.det_cap = NS if (not inf.DO_NMS or inf2.POST_NMS_TOPK <= 0) else min(NS, int(inf2.POST_NMS_TOPK) + 156)
+        self.det = torch.zeros((G, self.det_cap, hip.DET_FIELDS), dtype=torch.float32, device=dev)
+        self.det_count = torch.zeros((G, ), dtype=torch.int32, device=dev)
+        if bev_single or bev_sample:
+            self.has_bev_inputs = True
+            self.in_group = torch.zeros((B, ), dtype=torch.int32, device=dev)
+        if G == 0:
+            return  # a camera-sharded rank that owns no sample of the step: it only contributes its record
+        ncap = (NS + 63) // 64 * 64
+        n = hip.NmsArgs()
+        self.sort_idx = torch.zeros((G, ncap), dtype=torch.int32, device=dev)
+        self.sbox = torch.zeros((G, ncap, 4), dtype=torch.float32, device=dev)
+        self.scls = torch.zeros((G, ncap), dtype=torch.int32, device=dev)
+        self.mask = torch.zeros((G, ncap, ncap // 64), dtype=torch.int64, device=dev)
+        self.nvalid = torch.zeros((G, 2), dtype=torch.int32, device=dev)
+        n.cand, n.counts = field_ptr("cand"), field_ptr("counts")
+        addressing(n)
+        n.G, n.num_levels, n.topk = G, L, topk
+        for l in range(L + 1):
+            n.slot_off[l] = self.slot_off[l]
+        n.do_nms, n.use_score3d = int(bool(inf.DO_NMS)), int(self.b3d_maps is not None)
+        n.nms_thresh, n.post_topk = float(inf2.NMS_THRESH), int(inf2.POST_NMS_TOPK)
+        # BEV stages (core.py:135-150, nuscenes_dd3d.py:423-465) run after the 2D NMS; the resize / clip / non-empty filter
+        # of detector_postprocess sits between them, so it moves into whichever kernel comes at that point.
+        n.do_postprocess = int(bool(inf.DO_POSTPROCESS) and not bev_single)
+        n.out_size = field_ptr("outsize")
+        n.sort_idx, n.sbox, n.scls = self.sort_idx.data_ptr(), self.sbox.data_ptr(), self.scls.data_ptr()
+        n.mask, n.nvalid = self.mask.data_ptr(), self.nvalid.data_ptr()
+        n.det, n.det_count, n.det_cap = self.det.data_ptr(), self.det_count.data_ptr(), self.det_cap
+        self.nms_args = n
+        self.nms_op = CallOp(lambda lib, st: hip.check(lib.dd3d_nms_finalize(C.byref(n), st), "nms_finalize"), "nms_finalize")
+        self.ops.append(self.nms_op)
+        if bev_single or bev_sample:
+            # One BEV problem per call over the G images this rank finalises (the reference concatenates the batch: one
+            # batched_nms_rotated, postprocessing.py:86-94).  Capacity: the LDS sorter holds 8192 BOXES -- actual detections, counted
+            # on the device (<= POST_NMS_TOPK per image after the 2D stage: 81 images at 100); more trips the overflow flag, count_out
+            # = -1, and collect() raises.
+            ntot = G * self.det_cap
+            ncapb = (ntot + 63) // 64 * 64
+            self.bev_work = torch.zeros((ntot, 16), dtype=torch.float32, device=dev)
+            self.bev_sbox = torch.zeros((ntot, 8), dtype=torch.float32, device=dev)
+            self.bev_mask = torch.zeros((min(ncapb, 8192), ncapb // 64), dtype=torch.int64, device=dev)  # rows: sorted boxes (<= 8192)
+            self.bev_meta = torch.zeros((4, ), dtype=torch.int32, device=dev)
+            self.own_group = torch.arange(G, dtype=torch.int32, device=dev)  # dummy_group_idxs = {i: [i]} (core.py:137)
+            if self.camera_sharded:  # sample membership is positional: cameras 6 s .. 6 s + 5 of the global order
+                self.in_group = torch.arange(G, dtype=torch.int32, device=dev) // ncam
+            self.bev_args = []
+            self.det_stages = [(self.det, self.det_count)]  # every stage's buffers stay referenced: the arg structs hold raw pointers
+
+            def stage(group, max_dets, write_global, do_pp, name):
+                b = hip.BevArgs()
+                det_out = torch.zeros_like(self.det)
+                cnt_out = torch.zeros_like(self.det_count)
+                b.det_in, b.count_in = self.det.data_ptr(), self.det_count.data_ptr()
+                b.inv_K, b.pose, b.group = field_ptr("inv_K"), field_ptr("pose"), group.data_ptr()
+                b.out_size = field_ptr("outsize")
+                addressing(b)
+                b.G, b.det_cap, b.num_classes = G, self.det_cap, C_
+                b.iou_thresh, b.max_dets = float(inf.BEV_NMS_IOU_THRESH), int(max_dets)
+                b.write_global, b.do_postprocess = int(write_global), int(do_pp)
+                b.work, b.sbox, b.mask, b.meta = self.bev_work.data_ptr(), self.bev_sbox.data_ptr(), self.bev_mask.data_ptr(), self.bev_meta.data_ptr()
+                b.det_out, b.count_out = det_out.data_ptr(), cnt_out.data_ptr()
+                self.bev_args.append(b)
+                self.ops.append(CallOp(lambda lib, st, b=b: hip.check(lib.dd3d_bev_nms_aggregate(C.byref(b), st), name), name))
+                self.det, self.det_count = det_out, cnt_out  # what collect() reads
+                self.det_stages.append((det_out, cnt_out))
+
+            if bev_single:
+                stage(self.own_group, 0, False, bool(inf.DO_POSTPROCESS), "bev_nms")
+            if bev_sample:
+                stage(self.in_group, int(model.max_num_dets_per_sample), True, False, "nusc_sample_aggregate")
+                self.has_global_boxes = True
+
+    def check_status(self):
+        """With the exchange, the verdict is the OR over all ranks' records (delivered by the step's all_gather), so that every rank raises on
+        the same step; the local words are cleared as well."""
+        # (DenseDepthPlan shares this class without the post-processing half: no exchange, no gathered buffer)
+        if not (getattr(self, "exchange", False) and self.math == hip.MATH_F16X2 and getattr(self, "gathered", None) is not None):
+            return super().check_status()
+        fl = self.gathered.view(self.world_size, self.record_len)[:, self.flags_off:self.flags_off + 2].view(torch.int32).cpu()
+        over = [r for r in range(self.world_size) if int(fl[r, 0]) & hip.STATUS_F16_OVERFLOW]
+        under = [r for r in range(self.world_size) if int(fl[r, 1])]
+        if over or under:
+            self.status.zero_()
+            what = (f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}) on "
+                    f"rank(s) {over}" if over else
+                    f"convolution outputs sit below the half range's useful part on rank(s) {under} (absolute floor {2.0**-25 / self.act_scale:.2g})")
+            raise FloatingPointError(f"{what}: run this model with math='bf16x3' (every rank sees this verdict on the same step)")
+
+    def gather_pairs(self):
+        """(local record, gathered buffer [W x record]): the ONE tensor pair the multi-GPU step all-gathers between select/decode and
+        the NMS stages."""
+        return [(self.record, self.gathered)]
+
+    def gathered_field(self, name):
+        """Field `name` (record_fields) of every rank's images as delivered by the exchange: [W * B, words per image], rank-major =
+        global image order.  counts come back as int32."""
+        off, per = self.record_fields[name]
+        g = self.gathered.view(self.world_size, self.record_len)[:, off:off + self.B * per]
+        if name == "counts":
+            g = g.view(torch.int32)
+        return g.reshape(self.world_size * self.B, per)
+
+    def gathered_counts(self):
+        """Candidate counts [W*B, L] of every rank's images as delivered by the exchange (diagnostics / tests)."""
+        return self.gathered_field("counts")
+
+    def image_offset(self, g, name):
+        """Word offset, relative to record 0's block of field `name`, of image g of the post stages -- the arithmetic of
+        csrc/postproc.hip::rec_off (tests check the two against each other)."""
+        per = self.record_fields[name][1]
+        if not self.exchange:
+            return g * per
+        gg = self.img_first + g
+        return (gg // self.B) * self.record_len + (gg % self.B) * per
+
+
+class DenseDepthPlan(ForwardPlan):
+    """Launch plan of DD3DDenseDepth (dense_depth.py:121-151): trunk, the box3d tower (one multi-segment launch per layer), the
+    per-level 1-channel predictors with Scale / Offset folded in (one launch), then per level the aligned bilinear upsampling to
+    the input resolution fused with the focal-length scaling."""
+    def __init__(self, model, B, Hp, Wp, device=None, dry_run=False):
+        PlanBase.__init__(self, device or model.device, dry_run=dry_run)
+        self.adopt_weight_store(model)
+        self._trunk(model, B, Hp, Wp)
+        dev, feats, head = self.device, self.features, model.fcos3d_head
+        L, Cf = len(feats), feats[0].C
+        ping = [self.buf(f"ddA.{l}", f.B, f.H, f.W, Cf, kind="planes") for l, f in enumerate(feats)]
+        pong = [self.buf(f"ddB.{l}", f.B, f.H, f.W, Cf, kind="planes") for l, f in enumerate(feats)]
+        cur = list(feats)
+        for i, conv in enumerate(head.box3d_tower):
+            dst = ping if i % 2 == 0 else pong
+            w, meta = self.pack(conv.weight)
+            segs = []
+            for l in range(L):
+                norm = conv.norm[l] if isinstance(conv.norm, torch.nn.ModuleList) else conv.norm
+                scale, shift = fold_norm(conv, norm)
+                segs.append({"in": cur[l], "out": dst[l].view(), "w": w, "scale": self._vec(scale), "bias": self._vec(shift)})
+                cur[l] = dst[l].view()
+            self.ops.append(ConvOp(self, meta, 1, 1, segs, relu=True, name=f"dd_tower.{i}"))
+        # predictors: a different filter per level (dense_depth.py:63-67,93-97), (conv + b) * scale + offset
+        segs, self.dd_raw = [], []
+        meta = None
+        for l, conv in enumerate(head.dense_depth):
+            w, meta = self.pack(conv.weight)
+            b = conv.bias.detach().float().cpu() if conv.bias is not None else torch.zeros(1)
+            sc = head.scales_depth[l].scale.detach().float().cpu() if head.use_scale else torch.ones(1)
+            off = head.offsets_depth[l].bias.detach().float().cpu() if head.use_scale else torch.zeros(1)
+            out = self.buf(f"dd_raw.{l}", feats[l].B, feats[l].H, feats[l].W, 4)
+            self.dd_raw.append(out)
+            segs.append({"in": cur[l], "out": out.view(0, 4), "w": w, "scale": self._vec(sc), "bias": self._vec(b * sc + off), "n_limit": 1})
+        self.ops.append(ConvOp(self, meta, 1, 1, segs, relu=False, name="dd_predictors"))
+        # upsample + focal scaling (tensor2d.py:28-47, dense_depth.py:140-151)
+        self.depth_maps = []
+        half = int(model.feature_locations_offset == "half")
+        for l, f in enumerate(feats):
+            stride = self.strides[l]
+            assert f.H * stride == Hp and f.W * stride == Wp, "pyramid level does not tile the padded input"
+            o = torch.zeros((B, Hp, Wp), dtype=torch.float32, device=dev)
+            self.depth_maps.append(o)
+            factor = float(model.scale_depth_by_focal_lengths_factor) if model.scale_depth_by_focal_lengths else 0.0
+
+            def _up(lib, st, src=self.dd_raw[l], o=o, stride=stride, factor=factor, f=f):
+                hip.check(lib.dd3d_aligned_bilinear_scale(src.t.data_ptr(), o.data_ptr(), self.inv_K.data_ptr(), B, f.H, f.W, 4, stride, half,
+                                                          factor, st), "aligned_bilinear")
+
+            self.ops.append(CallOp(_up, f"dd_upsample.{l}", dict(kind="aligned_bilinear_scale", src=self.dd_raw[l], out=o, factor=stride,
+                                                                   offset_half=half, focal_factor=factor)))
+
+

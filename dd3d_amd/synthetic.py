@@ -28,11 +28,21 @@ def calib_path(tag):
     return p
 
 
-def load_calib(tag):
+SHIPPED_CALIBS = ("dla34_kitti", "dla34_nusc", "v99_kitti", "v99_nusc")
+
+
+def load_calib(tag, required=False):
+    """Calibration of one synthetic configuration ({} when there is none: the state dict is then uncalibrated and a random network
+    yields no candidates -- or all of them).  `required`: raise instead, naming where the file is expected."""
     p = calib_path(tag)
     if os.path.exists(p):
         with open(p) as f:
             return json.load(f)
+    if required:
+        raise FileNotFoundError(
+            f"no synthetic calibration '{tag}': the package ships {', '.join(SHIPPED_CALIBS)} (dd3d_amd/data/synth_calib_*.json); the other "
+            "backbone specs' files live under tests/data and are found through DD3D_CALIB_DIR (tests/conftest.py sets it) -- "
+            f"expected {os.path.basename(p)} in {_DATA_DIR} or $DD3D_CALIB_DIR={os.environ.get('DD3D_CALIB_DIR')!r}")
     return {}
 
 

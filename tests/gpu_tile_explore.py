@@ -59,8 +59,8 @@ def main():
     torch.cuda.synchronize()
     seen = {}
     table = {}
-    engine.TILE_TABLE = {m: {} for m in engine.TILE_TABLE}  # measure against the analytic model
-    engine.PLANE_TILE_TABLE = {m: {} for m in engine.PLANE_TILE_TABLE}
+    for t in list(engine.TILE_TABLE.values()) + list(engine.PLANE_TILE_TABLE.values()):
+        t.clear()  # measure against the analytic model (in place: dd3d_amd.engine.tiling holds the same dict objects)
     only = os.environ.get("DD3D_EXPLORE_ONLY", "")  # comma-separated op-name prefixes (e.g. the big launches whose other tiles the block limit skips)
     max_blocks = int(os.environ.get("DD3D_EXPLORE_MAXBLOCKS", "6000"))
     for name, pl, meta, stride, pad, segs, relu, kw in RECORD:

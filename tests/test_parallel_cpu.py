@@ -1,6 +1,6 @@
 """The N>1 path's only collective, exercised with world_size 2 on CPU (gloo) on real (dry-run) launch plans: every rank's record
 [candidates | counts | resize targets] travels in ONE all_gather_into_tensor; afterwards a rank's post-select stages read its own
-segment of the gathered buffer, and every rank can see every rank's counts (dd3d_amd/parallel.py, dd3d_amd/engine.py)."""
+segment of the gathered buffer, and every rank can see every rank's counts (dd3d_amd/parallel.py, dd3d_amd/engine/forward.py)."""
 import os
 import socket
 
