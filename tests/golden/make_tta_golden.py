@@ -1,7 +1,11 @@
 """Golden vectors for the TTA wrapper: the reference's own DD3DWithTTA (tridet/modeling/dd3d/test_time_augmentation.py) around the
 reference's own DD3D, on CPU, on top of the third-party shims of ref_shims.py (detectron2 / fvcore transforms restated there, PIL real).
 
-    python tests/golden/make_tta_golden.py      ->  tests/golden/tta_dla34.npz
+    python tests/golden/make_tta_golden.py        ->  tests/golden/tta_dla34.npz            (toy scales, seconds)
+    python tests/golden/make_tta_golden.py nusc   ->  tests/golden/tta_nusc_dla34.npz       (toy scales)
+    python tests/golden/make_tta_golden.py full   ->  tests/golden/tta_dla34_kitti_scales.npz
+        the experiment's own TTA (configs/experiments/dd3d_kitti_dla34.yaml:44-53: MIN_SIZES [320, 384, 448, 512, 576] x flip, IMS_PER_BATCH 80)
+        on one raw-KITTI-sized 370 x 1224 frame: ten augmented copies forwarded as ONE batch on a 640 x 1920 canvas (~2 min of CPU)
 """
 import importlib
 import os
@@ -29,6 +33,19 @@ def tta_case():
     raw = rng.integers(0, 256, (3, 110, 260), dtype=np.uint8)
     K = torch.tensor(KITTI_K) * torch.tensor([[260 / 1224], [110 / 370], [1.0]])
     return {"image": torch.from_numpy(raw), "intrinsics": K, "height": 110, "width": 260}
+
+
+# The experiment as it is run (scripts/train.py:197-228 do_test with TEST.AUG.ENABLED): only the flag do_test itself flips
+# (postprocess_in_inference = False, train.py:206-209) and the input format; sizes, flip, batch size, thresholds are the experiment's.
+FULL_TTA_OVERRIDES = {"DD3D": {"INFERENCE": {"DO_POSTPROCESS": False}}, "INPUT": {"FORMAT": "BGR"}}
+
+
+def full_tta_case():
+    """One synthetic frame of raw KITTI size (370 x 1224) with the cam-2 intrinsics."""
+    from dd3d_amd.synthetic import KITTI_K
+    rng = np.random.default_rng(11)
+    raw = rng.integers(0, 256, (3, 370, 1224), dtype=np.uint8)
+    return {"image": torch.from_numpy(raw), "intrinsics": torch.tensor(KITTI_K), "height": 370, "width": 1224}
 
 
 NUSC_TTA_OVERRIDES = {
@@ -85,11 +102,11 @@ def nusc_main():
     print("wrote", path, [int(out[f"n{i}"]) for i in range(len(res))])
 
 
-def main():
+def main(full=False):
     import dd3d_amd.modeling  # noqa: F401
     from dd3d_amd import META_ARCH_REGISTRY, get_cfg
     from dd3d_amd.synthetic import load_calib, make_state_dict
-    cfg = get_cfg("dd3d_kitti_dla34", _merge(TRAINING_ONLY_KEYS, TTA_OVERRIDES))
+    cfg = get_cfg("dd3d_kitti_dla34", _merge(TRAINING_ONLY_KEYS, FULL_TTA_OVERRIDES if full else TTA_OVERRIDES))
     sd = make_state_dict(META_ARCH_REGISTRY.get("DD3D")(cfg), calib=load_calib("dla34_kitti"))
     ref_shims.install()
     for pkg in ("tridet.data", "tridet.data.augmentations"):
@@ -104,14 +121,25 @@ def main():
     ref = DD3D(cfg)
     ref.load_state_dict(sd, strict=True)
     ref.eval()
-    x = tta_case()
+    x = full_tta_case() if full else tta_case()
     x["extrinsics"] = RefPose()  # DO_BEV_NMS inside every augmented forward reads a pose (core.py:138-141)
+    import time
+    t0 = time.perf_counter()
     with torch.no_grad():
-        inst = DD3DWithTTA(cfg, ref)([x])[0]["instances"]
+        wrapper = DD3DWithTTA(cfg, ref)
+        if full:  # also record what went INTO the merge: detections per augmented copy (the wrapper's own _batch_inference)
+            aug = wrapper.tta_mapper(dict(x))
+            per_copy = [len(o) for o in wrapper._batch_inference([{k: v for k, v in a.items() if k != "transforms"} for a in aug])]
+            shapes = [tuple(a["image"].shape[1:]) for a in aug]
+        inst = wrapper([x])[0]["instances"]
+    print(f"reference DD3DWithTTA: {time.perf_counter() - t0:.1f} s")
     out = dict(boxes=inst.pred_boxes.tensor.numpy(), scores=inst.scores.numpy(), scores_3d=inst.scores_3d.numpy(), classes=inst.pred_classes.numpy(),
                vectorize=inst.pred_boxes3d.vectorize().numpy(), proj_ctr=inst.pred_boxes3d.proj_ctr.numpy(), depth=inst.pred_boxes3d.depth.numpy(),
                image_size=np.array(inst.image_size))
-    path = os.path.join(HERE, "tta_dla34.npz")
+    if full:
+        out.update(per_copy=np.array(per_copy), copy_shapes=np.array(shapes), batch_size=np.array(wrapper.batch_size))
+        print("augmented copies", shapes, "detections per copy", per_copy)
+    path = os.path.join(HERE, "tta_dla34_kitti_scales.npz" if full else "tta_dla34.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, len(inst), "merged detections")
 
@@ -120,4 +148,4 @@ if __name__ == "__main__":
     if "nusc" in sys.argv[1:]:
         nusc_main()
     else:
-        main()
+        main(full="full" in sys.argv[1:])

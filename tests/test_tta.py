@@ -120,3 +120,80 @@ def test_hip_nuscenes_tta_matches_reference_golden(hiplib):
         assert tuple(o.image_size) == (100, 178)
         _check_nusc(i, o.pred_boxes.tensor.cpu().numpy(), o.scores_3d.cpu().numpy(), o.pred_classes.cpu().numpy(), o.pred_attributes.cpu().numpy(),
                     o.pred_speeds.cpu().numpy(), o.pred_boxes3d.vectorize().cpu().numpy(), o.pred_boxes3d_global.vectorize().cpu().numpy(), 1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ the experiment's own TTA, at its scales
+GF = np.load(os.path.join(os.path.dirname(__file__), "golden", "tta_dla34_kitti_scales.npz"))
+
+
+def _full_bundle():
+    from tests.golden.make_tta_golden import FULL_TTA_OVERRIDES
+    from tests.util import bundle
+    return bundle("dd3d_kitti_dla34", "dla34_kitti", FULL_TTA_OVERRIDES)
+
+
+def _match_full(boxes, scores_3d, classes, vec, tol, max_unmatched=0):
+    """Detections matched to the golden's by class and 2D box (the merged list is ranked by scores_3d: two near-equal scores may swap
+    places without any field being wrong); every matched detection within `tol`; at most `max_unmatched` on either side unmatched."""
+    gb, gs, gc, gv = GF["boxes"], GF["scores_3d"], GF["classes"], GF["vectorize"]
+    used, pairs = set(), []
+    for i in range(len(boxes)):
+        cand = [j for j in np.nonzero(gc == classes[i])[0] if j not in used and np.abs(gb[j] - boxes[i]).max() <= max(tol * 2000, 0.05)]
+        if cand:
+            j = min(cand, key=lambda j: np.abs(gb[j] - boxes[i]).max())
+            used.add(j)
+            pairs.append((i, j))
+    unmatched = (len(boxes) - len(pairs)) + (len(gb) - len(pairs))
+    assert unmatched <= 2 * max_unmatched, (len(boxes), len(gb), len(pairs))
+    ih, ig = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+    assert np.allclose(scores_3d[ih], gs[ig], rtol=tol, atol=1e-6)
+    assert np.allclose(vec[ih, 4:], gv[ig, 4:], rtol=tol, atol=tol * 80)
+    q, gq = vec[ih, :4], gv[ig, :4]
+    assert float(np.minimum(np.abs(q - gq).max(1), np.abs(q + gq).max(1)).max()) < max(tol, 1e-5) * 10
+    return len(pairs), unmatched
+
+
+def test_tta_oracle_matches_reference_golden_at_the_experiments_scales():
+    """configs/experiments/dd3d_kitti_dla34.yaml:44-53 -- MIN_SIZES [320, 384, 448, 512, 576] x flip on one 370 x 1224 frame, the ten
+    copies forwarded as ONE batch of IMS_PER_BATCH (80) on a 640 x 1920 canvas (test_time_augmentation.py:59-66,118-133), merged by the
+    class-aware NMS (:163-181): the oracle against the reference's own DD3DWithTTA (tests/golden/make_tta_golden.py full)."""
+    from dd3d_amd.structures import Pose
+    from oracle import tta_oracle as T
+    from tests.golden.make_tta_golden import full_tta_case
+    cfg, sd = _full_bundle()
+    assert list(cfg.TEST.AUG.MIN_SIZES) == [320, 384, 448, 512, 576] and cfg.TEST.AUG.FLIP and cfg.TEST.IMS_PER_BATCH == 80
+    assert [tuple(s) for s in GF["copy_shapes"]] == [(320, 1059)] * 2 + [(384, 1270)] * 2 + [(448, 1482)] * 2 + [(512, 1694)] * 2 + [(576, 1905)] * 2
+    x = full_tta_case()
+    x["extrinsics"] = Pose()
+    with torch.no_grad():
+        r = T.tta_forward(sd, cfg, x)
+    assert r["n_union"] == int(GF["per_copy"].sum()) and r["n_union"] > len(GF["boxes"]) == 390
+    assert np.array_equal(r["pred_classes"].numpy(), GF["classes"])
+    n, un = _match_full(r["pred_boxes"].numpy(), r["scores_3d"].numpy(), r["pred_classes"].numpy(), r["vec"].numpy(), 1e-5)
+    assert (n, un) == (390, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_hip_tta_matches_reference_golden_at_the_experiments_scales(hiplib):
+    """The HIP wrapper on the same frame: five device-side Pillow-exact resizes, ten copies in ONE launch plan (B = 10, 640 x 1920), inverse
+    maps, merge NMS by dd3d_nms_finalize -- against the reference's own merged detections.  A candidate that sits ON a selection cut of one
+    of the ten forwards may flip (bounded here, not waved through: <= 2 of 390)."""
+    from dd3d_amd.structures import Pose
+    from dd3d_amd.tta import DD3DWithTTA
+    from tests.golden.make_tta_golden import full_tta_case
+    from tests.util import gpu_model
+    cfg, sd = _full_bundle()
+    model = gpu_model(cfg, sd, use_graph=True)
+    tta = DD3DWithTTA(cfg, model)
+    assert tta.batch_size == 80
+    x = full_tta_case()
+    x["extrinsics"] = Pose()
+    inst = tta([x])[0]["instances"]
+    assert tuple(inst.image_size) == (370, 1224)
+    plan = next(iter(model._plans.values()))
+    assert (plan.B, plan.Hp, plan.Wp) == (10, 640, 1920)  # the reference's ImageList of the ten copies (size_divisibility 128)
+    n, un = _match_full(inst.pred_boxes.tensor.cpu().numpy(), inst.scores_3d.cpu().numpy(), inst.pred_classes.cpu().numpy(),
+                        inst.pred_boxes3d.vectorize().cpu().numpy(), 1e-3, max_unmatched=2)
+    print(f"[tta full] {n} of 390 merged detections matched, {un} unmatched")
+    assert n >= 388
