@@ -237,21 +237,7 @@ __global__ __launch_bounds__(256) void scale_add_nhwc_kernel(const float* __rest
 __global__ void invert3x3_kernel(const float* __restrict__ K, float* __restrict__ invK, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const float* m = K + 9 * b;
-  const float a = m[0], bb = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-  const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
-  const float det = a * A + bb * Bc + c * Cc;
-  const float r = 1.0f / det;
-  float* o = invK + 9 * b;
-  o[0] = A * r;
-  o[1] = -(bb * i - c * h) * r;
-  o[2] = (bb * f - c * e) * r;
-  o[3] = Bc * r;
-  o[4] = (a * i - c * g) * r;
-  o[5] = -(a * f - c * d) * r;
-  o[6] = Cc * r;
-  o[7] = -(a * h - bb * g) * r;
-  o[8] = (a * e - bb * d) * r;
+  invert3x3(K + 9 * b, invK + 9 * b);  // common.h
 }
 
 // Union of the build-time knobs the translation units report (build_flags.h); zero-initialised storage, so the static registrations of the

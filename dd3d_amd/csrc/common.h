@@ -68,4 +68,21 @@ inline int lds_opt_in(const void* kernel, size_t bytes, const char* what) {
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// inv(K) of a row-major 3x3 by the adjugate, in the operation order dd3d_invert_intrinsics has always used (core.py:93 ImageList.intrinsics.inverse())
+__device__ inline void invert3x3(const float* m, float* o) {
+  const float a = m[0], bb = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
+  const float det = a * A + bb * Bc + c * Cc;
+  const float r = 1.0f / det;
+  o[0] = A * r;
+  o[1] = -(bb * i - c * h) * r;
+  o[2] = (bb * f - c * e) * r;
+  o[3] = Bc * r;
+  o[4] = (a * i - c * g) * r;
+  o[5] = -(a * f - c * d) * r;
+  o[6] = Cc * r;
+  o[7] = -(a * h - bb * g) * r;
+  o[8] = (a * e - bb * d) * r;
+}
+
 }  // namespace dd3d

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   constexpr int PA = (NPA + NW - 1) / NW, PB = (NPB + NW - 1) / NW;  // per wave (the surplus re-fetches the last piece)
   constexpr int ZERO_OFF = B_BASE + NSB * B_STAGE;  // 16 zero bytes invalid taps read (64 reserved)
   constexpr int EV_OFF = ZERO_OFF + 64;              // [scale | bias | lo][BN] floats of the epilogue (conv_epilogue_t)
-  static_assert(NSB >= 2 && NSB <= 3 && NSA >= 2 && NSA <= 4 && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
+  static_assert(NSB >= 2 && NSB <= 6 && NSA >= 2 && NSA <= 4 && (NSB <= 3 || NSA == 2) && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
@@ -250,17 +250,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if (ngroup <= 0) epi_store_vectors<BN, NTHR>(lds + EV_OFF, tid, evv);  // (an empty K slice: the split-K exchange's barriers publish them)
 #endif
   if (ngroup > 0) {
-    // prologue, in issue order: A(group 0) -> A stage 0 | B(tiles 0 .. NSB-1) | A(groups 1 .. NSA-1) -> A stages 1 ...  Wait for A(0), B(0).
+    // prologue.  The loop's counted waits assume the STEADY-STATE issue order -- step t issues B(t + NSB) and, when its dw == 2, the A group
+    // NSA groups ahead behind it -- so the prologue issues in the order the (virtual) steps t = -NSB .. -1 would have: with NSB <= 3
+    //   A(0) | B(0 .. NSB-1) | A(1 .. NSA-1)            and with a deeper B ring (NSB = 4 .. 6, NSA = 2)
+    //   B(0 .. NSB-4) | A(0) | B(NSB-3 .. NSB-1) | A(1)   (virtual step -4 has dw == 2: A(0) sits behind its B).
+    // Then wait for A(0) and B(0): everything issued after the later of the two may stay in flight.
+    constexpr int NB0 = NSB > 3 ? NSB - 3 : 0;  // B tiles issued before A(0)
+#pragma unroll
+    for (int d = 0; d < NB0; ++d) emit_b(d);
     prepare_a();
     emit_a(0);
 #pragma unroll
-    for (int d = 0; d < NSB; ++d) emit_b(d);
+    for (int d = NB0; d < NSB; ++d) emit_b(d);
 #pragma unroll
     for (int d = 1; d < NSA; ++d) {
       prepare_a();
       emit_a(d);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 1) * PB + (NSA - 1) * PA) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB0 > 0 ? NSB - NB0 : NSB - 1) * PB + (NSA - 1) * PA) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #if DD3D_EPI_T
@@ -282,9 +289,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       mfma_chunk(C0);
       if constexpr (dw == 2) prepare_a();
       sched_barrier_phase<TM * TN * NPROD, (TM + TN) * NP, 0>();
-      // A issues among steps s+1-NSB .. s-1: with NSB = 3 those are two steps (one has dw == 2 unless this step has); with NSB = 2 one step
-      constexpr int a_in_flight = NSB == 3 ? (dw != 2 ? 1 : 0) : (dw == 0 ? 1 : 0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 2) * PB + a_in_flight * PA) : "memory");
+      // "B(s+1) has landed": B(s+1) was issued in step s+1-NSB; behind it sit the B tiles s+2 .. s+NSB-1 and the A groups issued in the steps
+      // s+1-NSB .. s-1, i.e. one per step j = 1 .. NSB-1 back whose dw was 2.  When dw == 2 the next A group (issued three steps ago, behind
+      // that step's B) is read right after this barrier: then at most the two B tiles issued since may stay in flight (NSA = 2; a no-op
+      // tightening for NSB <= 3).
+      constexpr int a_in_flight = ((dw + 2) % 3 == 2 && NSB > 1) + ((dw + 1) % 3 == 2 && NSB > 2) + ((dw + 0) % 3 == 2 && NSB > 3) +
+                                  ((dw + 2) % 3 == 2 && NSB > 4) + ((dw + 1) % 3 == 2 && NSB > 5);  // j = 1 .. 5: (dw - j) mod 3 == 2
+      constexpr int steady = (NSB - 2) * PB + a_in_flight * PA;
+      constexpr int wait_n = (dw == 2 && NSA == 2 && steady > 2 * PB) ? 2 * PB : steady;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(wait_n) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // everyone: K-tile s+1 (and, after dw == 2, the next A group) landed; B stage sb / A stage sa free
       asm volatile("" ::: "memory");
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
-// Ring depths of a tile (also computed by dd3d_amd/engine.py::kernel_signature for the bench's bookkeeping):
+// Ring depths of a tile (also computed by dd3d_amd/engine/tiling.py::kernel_signature for the bench's bookkeeping):
 //   NSB  B stages: 3 when two A stages + three B stages fit the block's LDS budget, else 2
 //   NSA  A stages: as many (<= 4) as fit -- a block that fits twice into a CU with NSA = 2 (<= 80 KiB) keeps fitting twice, a block that
 //        owns its CU anyway may grow to the whole budget
@@ -348,7 +361,15 @@ struct RowRings {
   static constexpr int AST = NP * (BM + 16) * 64, BST = NP * BN * 64;
   // (a 4-wave block whose two A stages alone exceed half a CU's LDS owns its CU anyway: it takes the 8-wave budget)
   static constexpr int BUDGET = ((WM * WN == 8 || 2 * AST > 64 * 1024) ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
-  static constexpr int NSB = (2 * AST + 3 * BST <= BUDGET) ? 3 : 2;
+  // B stages: 3 when two A stages + three B stages fit the budget, else 2.  -DDD3D_ROW_NSB_MAX=4..6 lets the ring grow as far as the budget
+  // allows (a deeper filter stream for the small-M / split-K launches whose filters come from the MALL, not the L2) -- measured, see DESIGN.md
+#ifdef DD3D_ROW_NSB_MAX
+  static constexpr int NSB_MAX = DD3D_ROW_NSB_MAX;
+#else
+  static constexpr int NSB_MAX = 3;
+#endif
+  static constexpr int nsb_fit(int n) { return (n > 2 && 2 * AST + n * BST > BUDGET) ? nsb_fit(n - 1) : n; }
+  static constexpr int NSB = nsb_fit(NSB_MAX < 2 ? 2 : (NSB_MAX > 6 ? 6 : NSB_MAX));
   static constexpr int EXTRA = 64 + 12 * BN;  // the zero bytes invalid taps read + the epilogue vectors
   static constexpr int total(int nsa) { return nsa * AST + NSB * BST + EXTRA; }
   static constexpr int LIMIT = total(2) <= 80 * 1024 ? 80 * 1024 : (BUDGET > total(2) ? BUDGET : total(2));
@@ -413,7 +434,7 @@ static int launch_row_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st) {
 }
 
 // Ring depths of the instantiation a (tile, mode) pair launches -- what a profile reader needs to name the kernel (rocprofv3 prints the
-// template arguments); dd3d_amd/engine.py::kernel_signature restates the rule and a CPU test compares the two for every tile and mode.
+// template arguments); dd3d_amd/engine/tiling.py::kernel_signature restates the rule and a CPU test compares the two for every tile and mode.
 template <int MODE>
 static int row_rings_mode(int tile_cfg, int* nsb, int* nsa) {
 #define DD3D_RR(TM, TN, WM, WN) { typedef RowRings<TM, TN, WM, WN, MODE> R; *nsb = R::NSB; *nsa = R::NSA; return DD3D_OK; }

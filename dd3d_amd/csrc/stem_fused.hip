@@ -115,6 +115,15 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
   const float pscale = a.plane_scale;
   int ovf = 0;
 
+  // start-of-forward chores one block takes along (dd3d_stem_args.K / inv_K / zero_f32): K^-1 of every image, and the per-forward range-guard
+  // maxima back to zero -- every consumer runs in a later launch of the stream
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (a.K != nullptr && a.inv_K != nullptr)
+      for (int i = tid; i < a.B; i += 64 * SF_WAVES) invert3x3(a.K + 9 * i, a.inv_K + 9 * i);
+    if (a.zero_f32 != nullptr)
+      for (int i = tid; i < a.zero_count; i += 64 * SF_WAVES) a.zero_f32[i] = 0.f;
+  }
+
   // ------------------------------------------------------------------ stage 0: image patch (normalise, split)
   {
     const int ih0 = 2 * oh0 - 5, iw0 = 2 * ow0 - 5;  // level1 -> level0 (-1) -> base (-1) -> image (-3)
@@ -318,6 +327,8 @@ extern "C" int dd3d_stem_fused_f16x2(const dd3d_stem_args* a, void* stream) {
                a->Wp, a->B);
   DD3D_REQUIRE(!a->out || (a->out_pitch >= 32 && a->out_pitch % 4 == 0), "dd3d_stem_fused_f16x2: out_pitch=%d", a->out_pitch);
   DD3D_REQUIRE(a->plane_scale > 0.f, "dd3d_stem_fused_f16x2: plane_scale=%g", (double)a->plane_scale);
+  DD3D_REQUIRE((a->K == nullptr) == (a->inv_K == nullptr) && a->zero_count >= 0 && (a->zero_count == 0 || a->zero_f32),
+               "dd3d_stem_fused_f16x2: K and inv_K come together; zero_count=%d needs zero_f32", a->zero_count);
   static unsigned long long attr_done[4];
   if (lds_opt_in_needed(attr_done)) {
     if (lds_opt_in(reinterpret_cast<const void*>(stem_fused_f16x2_kernel), (size_t)SF_LDS, "stem_fused_f16x2_kernel") != DD3D_OK) return DD3D_E_LAUNCH;

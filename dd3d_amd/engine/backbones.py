@@ -166,7 +166,9 @@ class BackboneLowering:
         ch = dla.channels
         if self.fused_stem:
             y = self.buf("level1.0", B, H // 2, W // 2, ch[1], kind=self._twin)  # level2: conv input + max-pool input
-            self.ops.append(FusedStemOp(self, self.model, [dla.base_layer, dla.level0[0], dla.level1[0]], y.view(), name="stem"))
+            stem = FusedStemOp(self, self.model, [dla.base_layer, dla.level0[0], dla.level1[0]], y.view(), name="stem")
+            stem.begin_forward = bool(getattr(self, "stem_begins_forward", False))
+            self.ops.append(stem)
             x = y.view()
         else:
             base = self.buf("base", B, H, W, ch[0])

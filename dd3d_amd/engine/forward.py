@@ -76,7 +76,12 @@ class ForwardPlan(PlanBase, BackboneLowering):
                 )
             hip.check(lib.dd3d_invert_intrinsics(self.in_K.data_ptr(), self.inv_K.data_ptr(), B, st), "invert_intrinsics")
 
-        self.ops.append(CallOp(_pre, "preprocess", dict(kind="preprocess", img=img, mean=list(self._norm[0]), std=list(self._norm[1]))))
+        # Round 5: a plan with the fused stem has NO separate start-of-forward launches -- the stem launch zeroes the range-guard maxima and
+        # inverts the intrinsics (dd3d_stem_args.K / inv_K / zero_f32: two tiny launches fewer per forward, 11 us of a 1.18 ms one-image
+        # forward).  DD3D_STEM_BEGIN=0 keeps them (A/B); dry-run plans keep the op (the CPU emulator reads the normalised canvas off it).
+        self.stem_begins_forward = bool(self.fused_stem and not self.dry_run and os.environ.get("DD3D_STEM_BEGIN", "1") != "0")
+        if not self.stem_begins_forward:
+            self.ops.append(CallOp(_pre, "preprocess", dict(kind="preprocess", img=img, mean=list(self._norm[0]), std=list(self._norm[1]))))
 
         # ---- backbone + FPN
         img_view = img.view() if img is not None else None  # (None: the fused stem reads the uint8 input itself)
@@ -372,7 +377,11 @@ class ForwardPlan(PlanBase, BackboneLowering):
             args.img_first, args.img_per_rec, args.rec_stride = (self.img_first, B, self.record_len) if self.exchange else (0, 0, 0)
 
         self.has_bev_inputs = self.has_global_boxes = False
-        self.det_cap = NS if (not inf.DO_NMS or inf2.POST_NMS_TOPK <= 0) else min(NS, int(inf2.POST_NMS_TOPK) + 156)
+        # Capacity of the detection buffer: every candidate slot.  The post-NMS cut keeps `scores >= k-th score` (fcos2d.py:356-362): with
+        # TIED scores at the cut it keeps more than POST_NMS_TOPK, and a network whose scores saturate (heavy-tailed features: sigmoid = 1.0f
+        # for hundreds of candidates) keeps hundreds more -- rounds 1-4 sized the buffer POST_NMS_TOPK + 156 and raised on such an image
+        # (found by tests/test_full_size_gpu.py::test_heavy_tailed_fpn_statistics_at_full_size).  480 KB per image buys the exact semantics.
+        self.det_cap = NS
         self.det = torch.zeros((G, self.det_cap, hip.DET_FIELDS), dtype=torch.float32, device=dev)
         self.det_count = torch.zeros((G, ), dtype=torch.int32, device=dev)
         if bev_single or bev_sample:

@@ -48,12 +48,21 @@ class FusedStemOp:
         a.B, a.Hp, a.Wp, a.out_pitch = B, Hp, Wp, vout.pitch
         a.plane_scale = float(plan.act_scale)
         a.status = plan.status.data_ptr()
+        # start-of-forward chores the launch takes along (no separate launches): K^-1 and the per-forward range-guard maxima.  Their
+        # addresses / extents are only final once the whole plan is built (the record takes over inv_K, convolutions register their
+        # maxima): `begin_forward` = True makes __call__ read them off the plan at launch (= capture) time.
+        self.plan, self.begin_forward = plan, False
         self.a = a
         self.desc = dict(kind="fused_stem", convs=descs, vout=vout, mean=[float(v) for v in model.pixel_mean.flatten()],
                          std=[float(v) for v in model.pixel_std.flatten()], planes=bool(vout.np))
         self.info = dict(name=name, M=B * (Hp // 2) * (Wp // 2), N=32, K=0, tile="fused", splitk=1, math=hip.MATH_F16X2, blocks=0, nsegs=1)
 
     def __call__(self, lib, stream):
+        if self.begin_forward:
+            p, a = self.plan, self.a
+            a.K, a.inv_K = p.in_K.data_ptr(), p.inv_K.data_ptr()
+            n = max(1, len(p.amax_names))
+            a.zero_f32, a.zero_count = p.amax.data_ptr(), n * p.amax.shape[1] * p.amax.shape[2]
         hip.check(lib.dd3d_stem_fused_f16x2(C.byref(self.a), stream), "fused stem " + self.name)
 
 

@@ -69,7 +69,8 @@ class StemArgs(C.Structure):
         ("src", C.c_void_p), ("sizes", C.c_void_p), ("mean", C.c_float * 3), ("stdv", C.c_float * 3), ("w1", C.c_void_p), ("scale1", C.c_void_p),
         ("bias1", C.c_void_p), ("w2", C.c_void_p), ("scale2", C.c_void_p), ("bias2", C.c_void_p), ("w3", C.c_void_p), ("scale3", C.c_void_p),
         ("bias3", C.c_void_p), ("out", C.c_void_p), ("out_planes", C.c_void_p), ("B", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32),
-        ("out_pitch", C.c_int32), ("plane_scale", C.c_float), ("status", C.c_void_p)
+        ("out_pitch", C.c_int32), ("plane_scale", C.c_float), ("status", C.c_void_p), ("K", C.c_void_p), ("inv_K", C.c_void_p),
+        ("zero_f32", C.c_void_p), ("zero_count", C.c_int32)
     ]
 
 

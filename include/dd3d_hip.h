@@ -262,6 +262,13 @@ typedef struct dd3d_stem_args {  /* host memory; all pointers device */
   int32_t B, Hp, Wp, out_pitch;
   float plane_scale;
   int32_t* status;
+  /* ABI 5 -- start-of-forward chores the launch can take along (block (0, 0, 0) does them; each may be NULL / 0), so that a DLA plan needs no
+   * separate launches for them:  inv_K[b] = inverse(K[b]) for b < B (what dd3d_invert_intrinsics computes: core.py:93), and zero_f32[0 .. zero_count)
+   * = 0.f (the per-launch range-guard maxima dd3d_conv_launch.amax points into, which are per forward). */
+  const float* K;
+  float* inv_K;
+  float* zero_f32;
+  int32_t zero_count;
 } dd3d_stem_args;
 int dd3d_stem_fused_f16x2(const dd3d_stem_args* args, void* stream);
 int dd3d_conv2d_smallc_bf16x3(const dd3d_smallc_args* args, void* stream);

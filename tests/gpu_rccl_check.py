@@ -2,7 +2,8 @@
 all_gather between the two captured hipGraph halves (`force_exchange`), device tensors in, device tensors out.  Detections must equal
 the single-graph forward of the same model.  (tests/gpu_dist_check.py covers W = 2 ranks over a host-staged gloo gather.)
 
-    python tests/gpu_rccl_check.py [graph]      graph: DD3D_GRAPH_EXCHANGE=1 -- the all_gather captured INSIDE the step's hipGraph
+    python tests/gpu_rccl_check.py [graph|probe]   graph: DD3D_GRAPH_EXCHANGE=1 -- the all_gather captured INSIDE the step's hipGraph
+                                                   probe: DD3D_GRAPH_EXCHANGE=probe -- dd3d_amd.parallel.graph_exchange_probe decides
 """
 import os
 import socket
@@ -21,15 +22,22 @@ def main():
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    one_graph = len(sys.argv) > 1 and sys.argv[1] == "graph"
-    if one_graph:
-        os.environ["DD3D_GRAPH_EXCHANGE"] = "1"
+    mode = sys.argv[1] if len(sys.argv) > 1 else ""
+    one_graph = mode == "graph"
+    if mode in ("graph", "probe"):
+        os.environ["DD3D_GRAPH_EXCHANGE"] = "1" if one_graph else "probe"
     from dd3d_amd import build_model, get_cfg
     from dd3d_amd.parallel import DistributedForward, gather_candidates
     from dd3d_amd.synthetic import load_calib, make_inputs, make_state_dict
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
     assert dist.get_backend() == "nccl"
+    if mode == "probe":  # the capability probe (a tiny captured all_gather on a communicator of its own) decides; both outcomes are legal
+        from dd3d_amd.parallel import exchange_selftest, graph_exchange_enabled, graph_exchange_probe
+        one_graph = graph_exchange_probe()
+        assert graph_exchange_enabled() == one_graph and graph_exchange_probe() == one_graph  # cached, stable
+        st = exchange_selftest()
+        print(f"probe: captured all_gather usable = {one_graph}; selftest {st['nranks']} rank(s), device {st['devices'][0]}")
     cfg = get_cfg("dd3d_kitti_dla34")
     model = build_model(cfg)
     sd = make_state_dict(model, calib=load_calib("dla34_kitti"))

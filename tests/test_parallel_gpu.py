@@ -50,6 +50,15 @@ def test_rccl_all_gather_captured_inside_the_step_graph(hiplib):
     assert "rccl check (all_gather inside the graph): ok=True" in r.stdout
 
 
+def test_graph_exchange_probe_decides_on_the_transport(hiplib):
+    """DD3D_GRAPH_EXCHANGE=probe (round-4 verdict item 6d): a tiny captured all_gather on a communicator of its own decides whether the
+    step's collective is captured inside its hipGraph; whatever it decides, the step's detections equal the single-graph forward."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_rccl_check.py"), "probe"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "probe: captured all_gather usable =" in r.stdout and "ok=True" in r.stdout
+
+
 @pytest.mark.parametrize("mode", ["", "nccl", "streams", "microbatch", "fallback"])
 def test_pipelined_forward_equals_stepwise(hiplib, mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -79,7 +79,7 @@ def test_fused_stem_equals_the_launch_by_launch_stem_in_the_forward(hiplib, monk
     pf, sizes = fused.stage_inputs(inputs)
     pf.run()
     of = fused.collect(pf, inputs, sizes)
-    assert pf.fused_stem and [op.name for op in pf.ops[:3]] == ["preprocess", "stem", "level2.pool"]
+    assert pf.fused_stem and pf.stem_begins_forward and [op.name for op in pf.ops[:2]] == ["stem", "level2.pool"]  # no separate start-of-forward launches
     monkeypatch.setenv("DD3D_FUSED_STEM", "0")
     plain = gpu_model(cfg, sd, use_graph=False)
     pp, _ = plain.stage_inputs(inputs)
