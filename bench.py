@@ -18,7 +18,7 @@ Every slot's graphs are replayed once at construction and the untimed warm-up co
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch of the slot's plan:
 conv_igemm_planes_row_kernel<4,2,2,4,2,4,false,2> of csrc/conv_planes_row.hip at the default four images per launch): algorithmic FLOPs of
 one launch / its mean duration measured here with HIP events on the launch stream (``traffic``: the PMC-derived HBM bytes of that launch
-geometry, profiles/r04_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: tests/tools' dd3d_tools_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
+geometry, profiles/r05_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: tests/tools' dd3d_tools_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
 matrix products spent per f32 product (``--math``: f16x2 3, bf16x3 6, bf16x2 3, bf16 1; the f32-input MFMA peak 157.3 TFLOP/s for f32).
 ``blocks`` repeats the timed block a few times so that a reader can tell box / clock variance from a regression.  ``cpu_baseline`` is
 the CPU oracle (a restatement "port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
@@ -77,7 +77,7 @@ def parse_args():
     ap.add_argument("--cpu-forwards", type=int, default=200, help="upper bound; the CPU leg stops after ~12 s of work")
     ap.add_argument("--math", default=None, help="arithmetic of the convolutions: f16x2 (default) | bf16x3 | f32 | bf16x2 | bf16 (dd3d_amd.engine.default_math)")
     ap.add_argument("--repeat-blocks", type=int, default=5, help="extra timed blocks of --steps steps each (median / min / max reported in `blocks`)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_tower_hbm_bytes.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_tower_hbm_bytes.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel, keyed by kernel signature (see profiles/README.md)")
     return ap.parse_args()
 
@@ -268,6 +268,7 @@ def main():
 
     for pl in ([sl.plan for sl in runner.slots] if hasattr(runner, "slots") else [plan]):
         pl.check_status()  # a half-range overflow of the f16x2 arithmetic would invalidate the run: fail loudly
+    work_verified = verify_work(runner, plan, B)
     from dd3d_amd.engine import MATH_NAMES, kernel_signature
     math_name = next(k for k, v in MATH_NAMES.items() if v == plan.math)
     peak = PEAK_F32_MFMA_TFLOPS if math_name == "f32" else PEAK_BF16_MFMA_TFLOPS / PRODUCTS[math_name]
@@ -315,6 +316,7 @@ def main():
             "rank_ms_per_step": None if per_rank is None else [r["ms_per_step"] for r in sorted(per_rank, key=lambda r: r["rank"])],
             "graph_exchange": None if world == 1 else bool(getattr(runner, "step_graph", None) is not None),
         },
+        "work_verified": work_verified,
         "blocks": {"n": len(block_ms), "steps_each": args.steps, "ms_per_step": [round(x, 4) for x in block_ms],
                    "median_ms_per_step": round(srt[len(srt) // 2], 4), "min_ms_per_step": round(srt[0], 4), "max_ms_per_step": round(srt[-1], 4),
                    "median_images_per_s": round(world * B / srt[len(srt) // 2] * 1e3, 2),
@@ -402,6 +404,28 @@ def usable_cores():
         except Exception:
             pass
     return max(1, min(n, 32))
+
+
+def verify_work(runner, plan, B):
+    """After the timed blocks (round-4 verdict: nothing was read back from the timed work): every slot position was staged with the same B
+    images, so every position of every slot must hold the SAME detections as slot 0 / position 0 -- counts and every field, bit for bit
+    (same kernels, same tile choices) -- and they must exist.  A slot whose work was skipped, or ran on stale inputs, fails here."""
+    plans = [sl.plan for sl in runner.slots] if hasattr(runner, "slots") else [plan]
+    ref_n, ref_d, checked = None, None, 0
+    for p in plans:
+        counts = p.det_count.cpu()
+        for pos in range(0, p.det.shape[0], B):
+            for b in range(B):
+                n = int(counts[pos + b])
+                d = p.det[pos + b, :n].cpu()
+                if ref_n is None or b >= len(ref_n):
+                    ref_n, ref_d = (ref_n or []) + [n], (ref_d or []) + [d]
+                elif n != ref_n[b] or not torch.equal(d, ref_d[b]):
+                    raise RuntimeError(f"bench: slot position {pos + b} holds other detections than slot 0 ({n} vs {ref_n[b]}): a step did not do its work")
+                checked += 1
+    if not all(n > 0 for n in ref_n):
+        raise RuntimeError("bench: the synthetic image produced no detections: decode / NMS were not exercised")
+    return {"slot_positions_checked": checked, "detections_per_image": ref_n, "identical_across_slots": True}
 
 
 def _headroom(plans):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round check on the GPU box: the whole GPU suite, smoke, the driver's bench command, its rocprofv3 kernel stats, per-op in-graph costs,
 # the other BASELINE configurations.   bash tests/tools/round_check.sh <tag>      (writes gpurun_out/<tag>/<tag>_*)
-TAG=${1:-r04z}
+TAG=${1:-r05z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
