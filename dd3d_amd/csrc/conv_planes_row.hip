@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   constexpr int PA = (NPA + NW - 1) / NW, PB = (NPB + NW - 1) / NW;  // per wave (the surplus re-fetches the last piece)
   constexpr int ZERO_OFF = B_BASE + NSB * B_STAGE;  // 16 zero bytes invalid taps read (64 reserved)
   constexpr int EV_OFF = ZERO_OFF + 64;              // [scale | bias | lo][BN] floats of the epilogue (conv_epilogue_t)
-  static_assert(NSB >= 2 && NSB <= 6 && NSA >= 2 && NSA <= 4 && (NSB <= 3 || NSA == 2) && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
+  static_assert(NSB >= 2 && NSB <= 6 && NSA >= 2 && NSA <= 4 && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
@@ -251,23 +251,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 #endif
   if (ngroup > 0) {
     // prologue.  The loop's counted waits assume the STEADY-STATE issue order -- step t issues B(t + NSB) and, when its dw == 2, the A group
-    // NSA groups ahead behind it -- so the prologue issues in the order the (virtual) steps t = -NSB .. -1 would have: with NSB <= 3
-    //   A(0) | B(0 .. NSB-1) | A(1 .. NSA-1)            and with a deeper B ring (NSB = 4 .. 6, NSA = 2)
-    //   B(0 .. NSB-4) | A(0) | B(NSB-3 .. NSB-1) | A(1)   (virtual step -4 has dw == 2: A(0) sits behind its B).
+    // NSA groups ahead behind it -- so the prologue issues in the order the (virtual) steps t = -NSB .. -1 would have: A group NSA - k sits
+    // behind the B of virtual step -(3 k - 2), i.e. behind B(NSB + 2 - 3 k); the groups whose virtual step lies before the window come first.
+    //   NSB <= 3, NSA = 2 (the product rings):  A(0) | B(0 .. NSB-1) | A(1)
+    //   NSB = 5, NSA = 3:                       A(0) | B(0) B(1) | A(1) | B(2) B(3) B(4) | A(2)    (virtual steps -4 and -1 have dw == 2)
     // Then wait for A(0) and B(0): everything issued after the later of the two may stay in flight.
-    constexpr int NB0 = NSB > 3 ? NSB - 3 : 0;  // B tiles issued before A(0)
+    constexpr int UPFRONT = (1 <= NSA && 1 > NSB) + (2 <= NSA && 4 > NSB) + (3 <= NSA && 7 > NSB) + (4 <= NSA && 10 > NSB);  // k: 3 k - 2 > NSB
+    int next_a = 0;
 #pragma unroll
-    for (int d = 0; d < NB0; ++d) emit_b(d);
-    prepare_a();
-    emit_a(0);
-#pragma unroll
-    for (int d = NB0; d < NSB; ++d) emit_b(d);
-#pragma unroll
-    for (int d = 1; d < NSA; ++d) {
+    for (int u = 0; u < UPFRONT; ++u) {
       prepare_a();
-      emit_a(d);
+      emit_a(next_a++);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB0 > 0 ? NSB - NB0 : NSB - 1) * PB + (NSA - 1) * PA) : "memory");
+#pragma unroll
+    for (int d = 0; d < NSB; ++d) {
+      emit_b(d);
+      const int k3 = NSB + 2 - d;  // = 3 k of the A group that follows this B, if any
+      if (k3 % 3 == 0 && k3 / 3 >= 1 && k3 / 3 <= NSA) {
+        prepare_a();
+        emit_a(next_a++);
+      }
+    }
+    constexpr int DA0 = NSB + 2 - 3 * NSA;  // (UPFRONT == 0) A(0) follows B(DA0)
+    constexpr int PRO_WAIT = UPFRONT > 0 ? (NSB - 1) * PB + (NSA - UPFRONT) * PA : (NSB - 1 - DA0) * PB + (NSA - 1) * PA;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRO_WAIT) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #if DD3D_EPI_T
@@ -290,13 +297,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       if constexpr (dw == 2) prepare_a();
       sched_barrier_phase<TM * TN * NPROD, (TM + TN) * NP, 0>();
       // "B(s+1) has landed": B(s+1) was issued in step s+1-NSB; behind it sit the B tiles s+2 .. s+NSB-1 and the A groups issued in the steps
-      // s+1-NSB .. s-1, i.e. one per step j = 1 .. NSB-1 back whose dw was 2.  When dw == 2 the next A group (issued three steps ago, behind
-      // that step's B) is read right after this barrier: then at most the two B tiles issued since may stay in flight (NSA = 2; a no-op
-      // tightening for NSB <= 3).
+      // s+1-NSB .. s-1, i.e. one per step j = 1 .. NSB-1 back whose dw was 2.  When dw == 2 the next A group is read right after this barrier:
+      // it was issued 3 (NSA - 1) steps ago behind that step's B, so at most the 3 (NSA - 1) - 1 B tiles and NSA - 2 A groups issued since may
+      // stay in flight (a no-op tightening for the product rings).
       constexpr int a_in_flight = ((dw + 2) % 3 == 2 && NSB > 1) + ((dw + 1) % 3 == 2 && NSB > 2) + ((dw + 0) % 3 == 2 && NSB > 3) +
                                   ((dw + 2) % 3 == 2 && NSB > 4) + ((dw + 1) % 3 == 2 && NSB > 5);  // j = 1 .. 5: (dw - j) mod 3 == 2
       constexpr int steady = (NSB - 2) * PB + a_in_flight * PA;
-      constexpr int wait_n = (dw == 2 && NSA == 2 && steady > 2 * PB) ? 2 * PB : steady;
+      constexpr int a_cap = (3 * (NSA - 1) - 1) * PB + (NSA - 2) * PA;
+      constexpr int wait_n = (dw == 2 && steady > a_cap) ? a_cap : steady;
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(wait_n) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // everyone: K-tile s+1 (and, after dw == 2, the next A group) landed; B stage sb / A stage sa free
@@ -361,27 +369,30 @@ struct RowRings {
   static constexpr int AST = NP * (BM + 16) * 64, BST = NP * BN * 64;
   // (a 4-wave block whose two A stages alone exceed half a CU's LDS owns its CU anyway: it takes the 8-wave budget)
   static constexpr int BUDGET = ((WM * WN == 8 || 2 * AST > 64 * 1024) ? DD3D_ROW_LDS_KIB_8W : DD3D_ROW_LDS_KIB_4W) * 1024;
-  // B stages: 3 when two A stages + three B stages fit the budget, else 2.  -DDD3D_ROW_NSB_MAX=4..6 lets the ring grow as far as the budget
-  // allows (a deeper filter stream for the small-M / split-K launches whose filters come from the MALL, not the L2) -- measured, see DESIGN.md
-#ifdef DD3D_ROW_NSB_MAX
-  static constexpr int NSB_MAX = DD3D_ROW_NSB_MAX;
-#else
-  static constexpr int NSB_MAX = 3;
-#endif
-  static constexpr int nsb_fit(int n) { return (n > 2 && 2 * AST + n * BST > BUDGET) ? nsb_fit(n - 1) : n; }
-  static constexpr int NSB = nsb_fit(NSB_MAX < 2 ? 2 : (NSB_MAX > 6 ? 6 : NSB_MAX));
+  // The product rings: two A stages; three B stages when 2 A + 3 B fit the budget, else two.  -DDD3D_ROW_NSA_MAX=3..4 / -DDD3D_ROW_NSB_MAX=4..6 let
+  // the rings grow as far as LIMIT allows -- a block that fits twice into a CU with the product rings (<= 80 KiB) keeps fitting twice, a block
+  // that owns its CU anyway may take the whole budget -- A first, then B.  Measured (profiles/r04i_a_ring_depth_ab.txt, r05g_b_ring_depth_ab.txt,
+  // r05i_ring_depth_ab.txt): see DESIGN.md section 4, round 5; the product keeps 2 + 3.
+  static constexpr int NSB0 = (2 * AST + 3 * BST <= BUDGET) ? 3 : 2;
   static constexpr int EXTRA = 64 + 12 * BN;  // the zero bytes invalid taps read + the epilogue vectors
-  static constexpr int total(int nsa) { return nsa * AST + NSB * BST + EXTRA; }
-  static constexpr int LIMIT = total(2) <= 80 * 1024 ? 80 * 1024 : (BUDGET > total(2) ? BUDGET : total(2));
-  // Measured (profiles/r04i_a_ring_depth_ab.txt): 3 - 4 A stages instead of 2 change nothing on the backbone convolutions (level 3 conv2
-  // 33.8 -> 34.8 us, level 2 41.8 -> 43.7) and cost 3 % on the pipelined bench (1568 -> 1522 img/s: the larger blocks share CUs less) --
-  // the small tiles are NOT waiting for their activations.  -DDD3D_ROW_NSA_MAX=4 rebuilds the deeper rings.
+  static constexpr int TOTAL0 = 2 * AST + NSB0 * BST + EXTRA;
+  static constexpr int LIMIT = TOTAL0 <= 80 * 1024 ? 80 * 1024 : (BUDGET > TOTAL0 ? BUDGET : TOTAL0);
 #ifdef DD3D_ROW_NSA_MAX
   static constexpr int NSA_MAX = DD3D_ROW_NSA_MAX;
 #else
   static constexpr int NSA_MAX = 2;
 #endif
-  static constexpr int NSA = (NSA_MAX >= 4 && total(4) <= LIMIT) ? 4 : ((NSA_MAX >= 3 && total(3) <= LIMIT) ? 3 : 2);
+#ifdef DD3D_ROW_NSB_MAX
+  static constexpr int NSB_MAX = DD3D_ROW_NSB_MAX;
+#else
+  static constexpr int NSB_MAX = 3;
+#endif
+  static constexpr bool fits(int nsa, int nsb) { return nsa * AST + nsb * BST + EXTRA <= LIMIT; }
+  static constexpr int pick_nsa(int n) { return (n > 2 && !fits(n, NSB0)) ? pick_nsa(n - 1) : n; }
+  static constexpr int NSA = pick_nsa(NSA_MAX < 2 ? 2 : (NSA_MAX > 4 ? 4 : NSA_MAX));
+  static constexpr int pick_nsb(int n) { return (n > NSB0 && !fits(NSA, n)) ? pick_nsb(n - 1) : n; }
+  static constexpr int NSB = pick_nsb(NSB_MAX < NSB0 ? NSB0 : (NSB_MAX > 6 ? 6 : NSB_MAX));
+  static constexpr int total(int nsa) { return nsa * AST + NSB * BST + EXTRA; }
 };
 
 template <int TM, int TN, int WM, int WN, int MODE, bool ALLOW_SK = true>
