@@ -47,7 +47,13 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("name", list(CASES))
+# Backbone specs SURVEY section 2 marks OUT OF SCOPE (only DLA-34 and V2-99 are on the hot path): their emulation cases cost four minutes of
+# CPU and are opt-in (DD3D_TEST_VARIANTS=1; tests/conftest.py) -- the round-4 verdict asked for no more time there.
+OUT_OF_SCOPE = {n for n in CASES if n.split("_")[0] in ("v39", "v19", "v57", "v19slim", "v19dw", "v19slimdw", "dla46c", "dla60", "dla102", "dla169",
+                                                         "dlax46c", "dlax60c", "dlax60", "dlax102", "dlax10264")}
+
+
+@pytest.mark.parametrize("name", [pytest.param(n, marks=pytest.mark.variants) if n in OUT_OF_SCOPE else n for n in CASES])
 def test_emulated_plan_matches_oracle(hiplib, name):
     from dd3d_amd import META_ARCH_REGISTRY
     from dd3d_amd.engine import ForwardPlan
