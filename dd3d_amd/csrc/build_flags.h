@@ -76,4 +76,9 @@
 #else
 #define DD3D_BF_12 ""
 #endif
-#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12
+#ifdef DD3D_STEM_CHAINS
+#define DD3D_BF_13 " DD3D_STEM_CHAINS=" DD3D_BF_STR(DD3D_STEM_CHAINS)
+#else
+#define DD3D_BF_13 ""
+#endif
+#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13

@@ -58,6 +58,10 @@ constexpr int SF_REGION_A = 2 * SF_0_PLANE > 2 * SF_IMG_PLANE ? 2 * SF_0_PLANE :
 constexpr int SF_REGION_B = 2 * SF_B_PLANE;
 constexpr int SF_LDS = SF_REGION_A + SF_REGION_B;
 constexpr int SF_WAVES = DD3D_STEM_WAVES;
+#ifndef DD3D_STEM_CHAINS
+#define DD3D_STEM_CHAINS 2  // row groups (independent MFMA accumulation chains) a wave interleaves in the base / level0 stages
+#endif
+constexpr int SF_U = DD3D_STEM_CHAINS;
 static_assert(SF_LDS <= 160 * 1024 && SF_N1 * 32 * 4 <= SF_REGION_B, "stem tile does not fit the LDS");
 
 // value -> (hi, lo) halves of value * plane scale; returns nonzero if the scaled value leaves the half range
@@ -66,13 +70,6 @@ __device__ __forceinline__ int sf_split(float v, float pscale, _Float16& hi, _Fl
   hi = (_Float16)s;
   lo = (_Float16)(s - (float)hi);
   return !(fabsf(s) <= 65504.f);
-}
-
-// acc += (hi + lo) x (whi + wlo) without the lo x lo term
-__device__ __forceinline__ f32x4 sf_mfma3(f16x8 ahi, f16x8 alo, f16x8 whi, f16x8 wlo, f32x4 acc) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo, acc, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi, acc, 0, 0, 0);
 }
 
 // One 16-pixel x 16-channel accumulator block -> the (hi, lo) half planes of a tile in LDS, rows of 16 channels (32 bytes) per pixel.
@@ -164,24 +161,25 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
       const int pr = po / SF_CB, pc = po - pr * SF_CB;
       return !((unsigned)(rb0 + pr) < (unsigned)a.Hp && (unsigned)(cb0 + pc) < (unsigned)a.Wp);  // level0's zero padding
     };
-    // two row groups per iteration: two independent accumulation chains keep the matrix pipe fed (one chain of 21 dependent MFMAs per
-    // group left it idle most of the time: 40 us per image at batch 8)
-    for (int g0 = wave; g0 < SF_GB; g0 += 2 * SF_WAVES) {
-      const int g1 = g0 + SF_WAVES;
-      const bool has1 = g1 < SF_GB;
-      const unsigned char* base[2];
+    // SF_U row groups per iteration: SF_U independent accumulation chains keep the matrix pipe fed (one chain of 21 dependent MFMAs per
+    // group left it idle most of the time: 40 us per image at batch 8; two chains: round 3; SF_U: round 5, profiles/r05j_stem_chains_ab.txt)
+    for (int g0 = wave; g0 < SF_GB; g0 += SF_U * SF_WAVES) {
+      const unsigned char* base[SF_U];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int p = min((u ? (has1 ? g1 : g0) : g0) * 16 + n_lane, SF_NB - 1);
+      for (int u = 0; u < SF_U; ++u) {
+        const int gu = g0 + u * SF_WAVES;
+        const int p = min((gu < SF_GB ? gu : g0) * 16 + n_lane, SF_NB - 1);
         const int r = p / SF_CB, c = p - r * SF_CB;
         base[u] = regA + (r * SF_CI + c + 2 * q4) * 8;
       }
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[SF_U];
+#pragma unroll
+      for (int u = 0; u < SF_U; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ch = 0; ch < 7; ++ch) {
-        f16x8 ahi[2], alo[2];
+        f16x8 ahi[SF_U], alo[SF_U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SF_U; ++u) {
           const unsigned char* src = base[u] + ch * SF_CI * 8;  // filter row ch: pixels (r + ch, c + 2 q4), (.., + 1): 16 bytes, 8-byte aligned
           const u32x2 h0 = *reinterpret_cast<const u32x2*>(src), h1 = *reinterpret_cast<const u32x2*>(src + 8);
           const u32x2 l0 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE), l1 = *reinterpret_cast<const u32x2*>(src + SF_IMG_PLANE + 8);
@@ -189,14 +187,17 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
           alo[u] = __builtin_bit_cast(f16x8, u32x4{l0[0], l0[1], l1[0], l1[1]});
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[u], w[ch][0], acc[u], 0, 0, 0);
+        for (int u = 0; u < SF_U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[u], w[ch][0], acc[u], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][1], acc[u], 0, 0, 0);
+        for (int u = 0; u < SF_U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][1], acc[u], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][0], acc[u], 0, 0, 0);
+        for (int u = 0; u < SF_U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][0], acc[u], 0, 0, 0);
       }
-      ovf |= sf_store_tile(regB, SF_B_PLANE, g0, lane, acc[0], sc, bi, pscale, outside);  // (po < SF_GB * 16: the padded tail of the plane absorbs it)
-      if (has1) ovf |= sf_store_tile(regB, SF_B_PLANE, g1, lane, acc[1], sc, bi, pscale, outside);
+#pragma unroll
+      for (int u = 0; u < SF_U; ++u) {
+        const int gu = g0 + u * SF_WAVES;  // (po < SF_GB * 16: the padded tail of the plane absorbs it)
+        if (gu < SF_GB) ovf |= sf_store_tile(regB, SF_B_PLANE, gu, lane, acc[u], sc, bi, pscale, outside);
+      }
     }
   }
 
@@ -221,34 +222,38 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
       const int pr = po / SF_C0, pc = po - pr * SF_C0;
       return !((unsigned)(r00 + pr) < (unsigned)a.Hp && (unsigned)(c00 + pc) < (unsigned)a.Wp);
     };
-    for (int g0 = wave; g0 < SF_G0; g0 += 2 * SF_WAVES) {
-      const int g1 = g0 + SF_WAVES;
-      const bool has1 = g1 < SF_G0;
-      const unsigned char* base[2];
+    for (int g0 = wave; g0 < SF_G0; g0 += SF_U * SF_WAVES) {
+      const unsigned char* base[SF_U];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int p = min((u ? (has1 ? g1 : g0) : g0) * 16 + n_lane, SF_N0 - 1);
+      for (int u = 0; u < SF_U; ++u) {
+        const int gu = g0 + u * SF_WAVES;
+        const int p = min((gu < SF_G0 ? gu : g0) * 16 + n_lane, SF_N0 - 1);
         const int r = p / SF_C0, c = p - r * SF_C0;
         base[u] = regB + (r * SF_CB + c) * 32;
       }
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc[SF_U];
+#pragma unroll
+      for (int u = 0; u < SF_U; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ch = 0; ch < 5; ++ch) {
-        f16x8 ahi[2], alo[2];
+        f16x8 ahi[SF_U], alo[SF_U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < SF_U; ++u) {
           ahi[u] = *reinterpret_cast<const f16x8*>(base[u] + aoff[ch]);
           alo[u] = *reinterpret_cast<const f16x8*>(base[u] + SF_B_PLANE + aoff[ch]);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[u], w[ch][0], acc[u], 0, 0, 0);
+        for (int u = 0; u < SF_U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[u], w[ch][0], acc[u], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][1], acc[u], 0, 0, 0);
+        for (int u = 0; u < SF_U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][1], acc[u], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][0], acc[u], 0, 0, 0);
+        for (int u = 0; u < SF_U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][0], acc[u], 0, 0, 0);
       }
-      ovf |= sf_store_tile(regA, SF_0_PLANE, g0, lane, acc[0], sc, bi, pscale, outside);
-      if (has1) ovf |= sf_store_tile(regA, SF_0_PLANE, g1, lane, acc[1], sc, bi, pscale, outside);
+#pragma unroll
+      for (int u = 0; u < SF_U; ++u) {
+        const int gu = g0 + u * SF_WAVES;
+        if (gu < SF_G0) ovf |= sf_store_tile(regA, SF_0_PLANE, gu, lane, acc[u], sc, bi, pscale, outside);
+      }
     }
   }
 
@@ -273,21 +278,50 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
     }
     __syncthreads();  // level0 tile complete; the base tile is dead
     float* stage = reinterpret_cast<float*>(regB);  // [256 pixels][32 channels] f32
-    for (int g = wave; g < SF_G1; g += SF_WAVES) {
-      const int p = g * 16 + n_lane;
-      const int r = p / SF_TW, c = p - r * SF_TW;
-      const unsigned char* base = regA + (2 * r * SF_C0 + 2 * c) * 32;
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    constexpr int U3 = SF_U >= 4 ? 2 : 1;  // groups per iteration (each has two output-channel halves = two chains)
+    for (int g0 = wave; g0 < SF_G1; g0 += U3 * SF_WAVES) {
+      const unsigned char* base[U3];
+#pragma unroll
+      for (int u = 0; u < U3; ++u) {
+        const int gu = g0 + u * SF_WAVES;
+        const int p = (gu < SF_G1 ? gu : g0) * 16 + n_lane;
+        const int r = p / SF_TW, c = p - r * SF_TW;
+        base[u] = regA + (2 * r * SF_C0 + 2 * c) * 32;
+      }
+      f32x4 acc[U3][2];
+#pragma unroll
+      for (int u = 0; u < U3; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ch = 0; ch < 5; ++ch) {
-        const f16x8 ahi = *reinterpret_cast<const f16x8*>(base + aoff[ch]), alo = *reinterpret_cast<const f16x8*>(base + SF_0_PLANE + aoff[ch]);
+        f16x8 ahi[U3], alo[U3];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[nt] = sf_mfma3(ahi, alo, w[ch][0][nt], w[ch][1][nt], acc[nt]);
+        for (int u = 0; u < U3; ++u) {
+          ahi[u] = *reinterpret_cast<const f16x8*>(base[u] + aoff[ch]);
+          alo[u] = *reinterpret_cast<const f16x8*>(base[u] + SF_0_PLANE + aoff[ch]);
+        }
+        // acc += (hi + lo) x (whi + wlo) without the lo x lo term: lo x hi, hi x lo, hi x hi per chain, the chains interleaved
+#pragma unroll
+        for (int u = 0; u < U3; ++u)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[u], w[ch][0][nt], acc[u][nt], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U3; ++u)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][1][nt], acc[u][nt], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U3; ++u)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[u], w[ch][0][nt], acc[u][nt], 0, 0, 0);
       }
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int u = 0; u < U3; ++u) {
+        const int gu = g0 + u * SF_WAVES;
+        if (gu >= SF_G1) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) stage[(g * 16 + q4 * 4 + e) * 32 + nt * 16 + n_lane] = fmaxf(acc[nt][e] * sc[nt] + bi[nt], 0.f);
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) stage[(gu * 16 + q4 * 4 + e) * 32 + nt * 16 + n_lane] = fmaxf(acc[u][nt][e] * sc[nt] + bi[nt], 0.f);
+      }
     }
     __syncthreads();
     // coalesced write-out: thread -> (pixel, 4 channels): 16 bytes of the f32 row, 8 bytes of each plane row
