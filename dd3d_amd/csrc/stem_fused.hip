@@ -127,15 +127,32 @@ __global__ __launch_bounds__(64 * SF_WAVES) void stem_fused_f16x2_kernel(const S
     const int vh = a.sizes[2 * b], vw = a.sizes[2 * b + 1];
     const long plane = (long)a.Hp * a.Wp;
     const uint8_t* src = a.src + (long)b * 3 * plane;
-    for (int pix = tid; pix < SF_RI * SF_CI; pix += 64 * SF_WAVES) {
+    // Every thread's pixels are LOADED first, then converted: the loop used to wait for each pixel's three byte loads before it issued the
+    // next pixel's (four exposed HBM round trips per block on a CU the block owns alone; round 5, profiles/r05k_stem_patch_loads_ab.txt).
+    constexpr int NT = 64 * SF_WAVES, NPX = (SF_RI * SF_CI + NT - 1) / NT;
+    unsigned char raw[NPX][3];
+    bool in_img[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      const int pix = tid + k * NT;
       const int pr = pix / SF_CI, pc = pix - pr * SF_CI;
       const int ih = ih0 + pr, iw = iw0 + pc;
+      in_img[k] = pix < SF_RI * SF_CI && (unsigned)ih < (unsigned)vh && (unsigned)iw < (unsigned)vw;
+      // UNCONDITIONAL loads (a pixel outside the image reads pixel (0, 0) and is zeroed below): a guarded load compiles to a branch with
+      // its own wait, which is the serialisation this loop exists to remove
+      const uint8_t* p = src + (long)(in_img[k] ? ih : 0) * a.Wp + (in_img[k] ? iw : 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) raw[k][c] = p[c * plane];
+    }
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      const int pix = tid + k * NT;
+      if (pix >= SF_RI * SF_CI) break;
       f16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
-      if ((unsigned)ih < (unsigned)vh && (unsigned)iw < (unsigned)vw) {
-        const uint8_t* p = src + (long)ih * a.Wp + iw;
+      if (in_img[k]) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float x = ((float)p[c * plane] - a.mean[c]) / a.stdv[c];  // the division is kept: torch's (x - mean) / std
+          const float x = ((float)raw[k][c] - a.mean[c]) / a.stdv[c];  // the division is kept: torch's (x - mean) / std
           _Float16 h, l;
           sf_split(x, pscale, h, l);  // |x| < 3: always inside the half range
           hi[c] = h, lo[c] = l;
