@@ -520,3 +520,53 @@ def test_pack_smallc_f16x2_k_order_and_split(cin, cin_p, k, n):
     assert torch.all(dec[want == 0] == 0)  # padding taps / channels carry exact zeros
     hi = val[:, 0] / s.view(1, -1, 1)
     assert float((hi - want).abs().max()) <= 2.0**-10 * float(w.abs().max())  # the hi plane alone is the half rounding of the filter
+
+
+def test_tile_override_spec_wins_over_the_measured_table(monkeypatch):
+    """DD3D_TILE_OVERRIDE (measurement sweeps, tests/tools/issue_sweep.sh): `key=tile:splitk` pairs beat the measured table for that key only."""
+    from dd3d_amd import hip
+    from dd3d_amd.engine import choose_tiling
+    base = choose_tiling([30720], 128, 1152, 1, hip.MATH_F16X2, planes=True)
+    other = choose_tiling([7680], 256, 2304, 1, hip.MATH_F16X2, planes=True)
+    monkeypatch.setenv("DD3D_TILE_OVERRIDE", " 30720,128,1152,1 = 256x128:1 ; 999,1,32,1=64x64w4:2")
+    assert choose_tiling([30720], 128, 1152, 1, hip.MATH_F16X2, planes=True) == (hip.TILE_256x128, 1) != base
+    assert choose_tiling([7680], 256, 2304, 1, hip.MATH_F16X2, planes=True) == other
+    assert choose_tiling([999], 1, 32, 1, hip.MATH_F16X2, planes=True) == (hip.TILE_64x64_W4, 2)
+
+
+def test_parity_report_bars():
+    """tests/parity.py (what bench.py's `parity` object and smoke() assert): identical detections pass; a wrong integer field without any
+    candidate on a cut fails; a float off by more than 1e-3 fails; a flip that sits ON a cut is tolerated, one that does not is not."""
+    import types
+    import torch
+    from dd3d_amd.structures import Boxes, Boxes3D, Instances
+    from tests.parity import parity_pass, parity_report
+    g = torch.Generator().manual_seed(0)
+    n = 6
+    quat = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1)
+    ref = dict(scores=torch.rand(n, generator=g), scores_3d=torch.rand(n, generator=g), pred_classes=torch.arange(n) % 3, fpn_levels=torch.arange(n) % 2,
+               locations=torch.arange(2 * n, dtype=torch.float32).view(n, 2), pred_boxes=torch.rand(n, 4, generator=g) * 100,
+               pred_boxes3d=dict(quat=quat, proj_ctr=torch.rand(n, 2, generator=g) * 300, depth=torch.rand(n, 1, generator=g) * 40 + 5,
+                                 size=torch.rand(n, 3, generator=g) + 1, inv_intrinsics=torch.eye(3)[None].repeat(n, 1, 1) / 700.0))
+
+    def hip_out(mut=None):
+        r = Instances((384, 1280))
+        b = ref["pred_boxes3d"]
+        f = {k: v.clone() for k, v in ref.items() if k != "pred_boxes3d"}
+        b3 = {k: v.clone() for k, v in b.items()}
+        if mut:
+            mut(f, b3)
+        r.pred_boxes, r.scores, r.scores_3d, r.pred_classes = Boxes(f["pred_boxes"]), f["scores"], f["scores_3d"], f["pred_classes"]
+        r.locations, r.fpn_levels = f["locations"], f["fpn_levels"]
+        r.pred_boxes3d = Boxes3D(b3["quat"], b3["proj_ctr"], b3["depth"], b3["size"], b3["inv_intrinsics"])
+        return {"instances": r}
+
+    rep = parity_report(hip_out(), ref)
+    assert rep["pass"] and rep["int_mismatches"] == 0 and rep["matched"] == n and rep["corners_l1"] < 1e-5 and rep["box3d_l1_tvec_size"] < 1e-5
+    bad_int = parity_report(hip_out(lambda f, b: f["pred_classes"].__setitem__(0, 2)), ref)
+    assert bad_int["int_mismatches"] == 1 and not bad_int["pass"]
+    bad_float = parity_report(hip_out(lambda f, b: b["depth"].mul_(1.01)), ref)
+    assert not bad_float["pass"] and bad_float["depth_rel_max"] > 5e-3 and bad_float["corners_l1_rel"] > 1e-3
+    flipped_quat = parity_report(hip_out(lambda f, b: b["quat"].neg_()), ref)
+    assert flipped_quat["pass"]  # q and -q are the same rotation
+    assert parity_pass(dict(rep, int_mismatches=1, on_cut_flips=1)) and not parity_pass(dict(rep, int_mismatches=1, off_cut_flips=1, on_cut_flips=0))

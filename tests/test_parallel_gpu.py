@@ -97,3 +97,29 @@ def test_bench_multi_gpu_command_line(hiplib, pipeline):
     assert c["pipeline_slots"] == (0 if pipeline == "0" else 5)
     assert "NOT RCCL" in c["transport"] and "gloo" in c["transport"]
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+    # round 5: what lets a reader of the line confirm the transport carried N ranks on N devices, and that no rank idled
+    assert c["rccl_nranks"] == 0 and c["exchange_selftest"]["nranks"] == 2 and c["exchange_selftest"]["backend"] == "gloo"  # (0: this run was NOT on RCCL)
+    assert len(c["rank_devices"]) == 2 and all(dv["device"] == 0 and dv["pci_bus_id"] for dv in c["rank_devices"])
+    assert len(c["rank_ms_per_step"]) == 2 and max(c["rank_ms_per_step"]) <= d["ms_per_step"] * 1.001 and c["graph_exchange"] is False
+    assert d["work_verified"]["identical_across_slots"] and d["work_verified"]["detections_per_image"] == [100]
+
+
+def test_bench_single_gpu_line_carries_parity_and_baselines(hiplib):
+    """The driver's N = 1 command (fewer CPU forwards): the ONE JSON line must carry the metric, the roofline object, the CPU baseline,
+    the parity object (the metric's second half: 3D-box L1 vs the oracle, bars met) and the read-back of the timed work."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-forwards", "2", "--repeat-blocks", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "images/s" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    rf, cb, pr = d["roofline"], d["cpu_baseline"], d["parity"]
+    assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["traffic"] and rf["unit"] == "TFLOP/s"
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert pr["pass"] and pr["detections_hip"] == pr["detections_oracle"] == 100 and pr["off_cut_flips"] == 0
+    assert pr["corners_l1_rel"] <= 1e-3 and pr["box3d_l1_tvec_size_rel"] <= 1e-3 and (pr["int_mismatches"] == 0 or pr["on_cut_flips"] > 0)
+    assert d["work_verified"]["slot_positions_checked"] == 20 and d["config"]["f16x2_range"]["overflow_headroom_x"] > 4
+    assert d["config"]["bs1_images_per_s"] > 0 and "DLA34" in d["config"]["workload"]
