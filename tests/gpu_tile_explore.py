@@ -88,11 +88,14 @@ def main():
                     continue
                 if sk == 1 and blocks > max_blocks and cfg_id != cur_cfg:
                     continue
+                n_amax = len(pl.amax_names)
                 try:
                     op = engine.ConvOp(pl, meta, stride, pad, segs, relu, tile=cfg_id, splitk=sk, name=name, math=math, **{k: v for k, v in kw.items() if k != 'math'})
                     us = time_op(pl, op)
+                    del pl.amax_names[n_amax:]  # (every candidate registers a range-guard slot: 512 per plan; ten images per launch ran out of them)
                 except Exception as e:  # noqa: BLE001
                     us = float("nan")
+                    print(f"  !! {name} tile={hip.TILE_NAMES[cfg_id]} splitk={sk}: {type(e).__name__}: {str(e)[:300]}", flush=True)
                 res.append((us, hip.TILE_NAMES[cfg_id], cfg_id, sk, blocks * sk))
         res.sort()
         cur = [r for r in res if r[2] == cur_cfg and r[3] == cur_sk]
