@@ -40,6 +40,11 @@ def pytest_collection_modifyitems(config, items):
     """`gpu` tests are the parity tests proper (they call the HIP library through the C ABI): skipped, not failed, on a box without
     an MI355X, so a plain `pytest` in the build container runs the CPU suite only."""
     import torch
+    # The multi-process tests (gloo ranks spawned from this process) run LAST: after them every torch-CPU-heavy test of the same session
+    # runs 3-10x slower (measured, round 5: the plan-emulation case v99_kitti 4 s alone, 13 s after eight spawn tests, 40-60 s after
+    # thirteen -- the parent comes out of them with freshly created, smaller intra-op thread teams; neither a forked nor a spawned Manager
+    # makes a difference) -- which took the CPU suite from ~8 to 36 minutes when they ran in alphabetical order, ahead of test_plan_emulation.
+    items.sort(key=lambda it: os.path.basename(str(it.fspath)) == "test_parallel_cpu.py")  # (stable: everything else keeps its order)
     if os.environ.get("DD3D_TEST_VARIANTS", "0") != "1":
         opt_in = pytest.mark.skip(reason="out-of-scope backbone spec (SURVEY section 2): DD3D_TEST_VARIANTS=1 runs it")
         for item in items:

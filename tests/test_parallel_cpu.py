@@ -19,6 +19,16 @@ def _free_port():
     return p
 
 
+def _spawn(worker, world, *args):
+    """Run `worker(rank, world, port, *args, ret)` on `world` spawned ranks and return {rank: result}.  The Manager that carries the results is
+    spawned (not a fork of the multi-GB, multi-threaded pytest process) and shut down as soon as the ranks have joined.  (These tests run
+    last in a session: tests/conftest.py.)"""
+    with mp.get_context("spawn").Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(worker, args=(world, _free_port(), *args, ret), nprocs=world, join=True)
+        return dict(ret)
+
+
 def _fill(plan, rank):
     g = torch.Generator().manual_seed(100 + rank)
     plan.cand.copy_(torch.randn(plan.cand.shape, generator=g))
@@ -67,10 +77,7 @@ def _worker(rank, world, port, B, ret):
 
 def test_gather_candidates_gloo_world2():
     world, B = 2, 3
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), B, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert _spawn(_worker, world, B) == {0: True, 1: True}
 
 
 def _rec_off(g, img_first, img_per_rec, rec_stride, per_img):
@@ -130,10 +137,7 @@ def _camera_worker(rank, world, port, B, ret):
 def test_camera_sharded_sample_owner_reads_other_ranks_records(B):
     """NuscenesDD3D with the cameras of a sample on different ranks (B = 3 per rank: rank 0 owns the one sample and reads rank 1's three
     cameras; B = 6: every rank owns the sample it decoded): plan geometry, kernel argument addressing and the delivered records."""
-    world = 2
-    ret = mp.Manager().dict()
-    mp.spawn(_camera_worker, args=(world, _free_port(), B, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert _spawn(_camera_worker, 2, B) == {0: True, 1: True}
 
 
 def test_camera_sharding_needs_whole_samples_and_an_aggregating_model():
@@ -297,9 +301,7 @@ def test_pipelined_forward_keeps_collectives_matched_across_ranks(world, depth, 
     is flushed partly filled, and -- `trip` = (rank, slot run) -- one rank's range guard fires mid-stream, after which every rank rebuilds on
     bf16x3 and re-issues the runs still owing results in submission order.  Every post half must see the same run of every rank, every rank must
     have issued the same sequence of runs, and all of them must end on the same arithmetic."""
-    ret = mp.Manager().dict()
-    mp.spawn(_pipeline_worker, args=(world, _free_port(), depth, microbatch, nreq, trip, ret), nprocs=world, join=True)
-    res = dict(ret)
+    res = _spawn(_pipeline_worker, world, depth, microbatch, nreq, trip)
     assert sorted(res) == list(range(world)) and all(v[0] for v in res.values()), res
     seqs = {tuple(v[1]) for v in res.values()}
     assert len(seqs) == 1, seqs  # the same runs, in the same order, on the same arithmetic, on every rank
@@ -337,7 +339,5 @@ def _selftest_worker(rank, world, port, ret):
 def test_exchange_selftest_fails_fast_when_a_rank_is_missing():
     """Round-4 verdict item 6b: the start-up self-test of the exchange has a deadline -- a transport that cannot carry the all_gather raises
     within seconds, before any graph is captured, instead of hanging the first step."""
-    ret = mp.Manager().dict()
-    mp.spawn(_selftest_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
-    r = dict(ret)
+    r = _spawn(_selftest_worker, 2)
     assert r[0][0] == "raised" and r[0][2] < 7.0, r
