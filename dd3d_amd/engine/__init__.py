@@ -13,6 +13,6 @@ from dd3d_amd.engine.packing import Buf, View, dense_filter, pack_filter, pack_s
 from dd3d_amd.engine.tiling import (BIG_WAVE_TILES, BLOCKS_PER_CU, MATH_NAMES, MATH_TILES, NUM_CU, PLANE_TILE_ALIAS, PLANE_TILE_TABLE, PLANE_TILES, TILE_TABLE,  # noqa: F401
                                     TILE_WAVE_GRID, _tile_overrides, choose_tiling, default_math, kernel_signature, row_rings_default, tile_key)
 from dd3d_amd.engine.ops import CallOp, ConvOp, FusedStemOp, OpList, SmallcConvOp  # noqa: F401
-from dd3d_amd.engine.plan import PlanBase  # noqa: F401
+from dd3d_amd.engine.plan import HalfRangeOverflow, HalfRangeUnderflow, PlanBase, relax_arithmetic  # noqa: F401
 from dd3d_amd.engine.backbones import BackboneLowering  # noqa: F401
 from dd3d_amd.engine.forward import DenseDepthPlan, ForwardPlan  # noqa: F401

@@ -25,7 +25,7 @@ from dd3d_amd.layers import fold_norm
 
 from dd3d_amd.engine.backbones import BackboneLowering
 from dd3d_amd.engine.ops import CallOp, ConvOp
-from dd3d_amd.engine.plan import PlanBase
+from dd3d_amd.engine.plan import HalfRangeOverflow, HalfRangeUnderflow, PlanBase
 from dd3d_amd.engine.tiling import MATH_NAMES
 
 
@@ -47,6 +47,9 @@ class ForwardPlan(PlanBase, BackboneLowering):
         """Static inputs, pre-processing, backbone and FPN (shared with DenseDepthPlan)."""
         if getattr(model, "math", None) is not None:
             self.math = MATH_NAMES[model.math] if isinstance(model.math, str) else int(model.math)
+        if getattr(model, "act_scale", None):  # (the model's own plane scale: set by the range guard's staged fallback, plan.relax_arithmetic)
+            self.act_scale = float(model.act_scale)
+            assert self.act_scale > 0 and math.log2(self.act_scale).is_integer(), "model.act_scale must be a power of two"
         self.model = model
         self.B, self.Hp, self.Wp = B, Hp, Wp
         dev = self.device
@@ -468,7 +471,8 @@ class ForwardPlan(PlanBase, BackboneLowering):
             what = (f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}) on "
                     f"rank(s) {over}" if over else
                     f"convolution outputs sit below the half range's useful part on rank(s) {under} (absolute floor {2.0**-25 / self.act_scale:.2g})")
-            raise FloatingPointError(f"{what}: run this model with math='bf16x3' (every rank sees this verdict on the same step)")
+            raise (HalfRangeOverflow if over else HalfRangeUnderflow)(
+                f"{what}: run this model with math='bf16x3' (every rank sees this verdict on the same step)")
 
     def gather_pairs(self):
         """(local record, gathered buffer [W x record]): the ONE tensor pair the multi-GPU step all-gathers between select/decode and

@@ -18,6 +18,38 @@ from dd3d_amd.engine.tiling import default_math
 
 
 # --------------------------------------------------------------------------------------------- the plan
+class HalfRangeOverflow(FloatingPointError):
+    """DD3D_MATH_F16X2: an activation left the half format's range while being split (|x * plane scale| > 65504, or a NaN / inf)."""
+
+
+class HalfRangeUnderflow(FloatingPointError):
+    """DD3D_MATH_F16X2: a convolution's outputs sit below the useful part of the half pair's range (largest |x * plane scale| < 2^-5)."""
+
+
+def relax_arithmetic(model, err):
+    """What a model on the DEFAULT arithmetic (model.math is None) does after the f16x2 range guard fired -- shared by DD3D.forward,
+    DD3DDenseDepth and the runners of dd3d_amd.parallel.  An OVERFLOW first widens the half range: the plane scale 16 -> 4 -> 1 lifts the
+    largest representable activation 4094 -> 16376 -> 65504 at the f16x2 speed (the pair's absolute floor rises with it; the underflow side
+    of the guard keeps watching); only then -- or on an underflow, which no smaller scale can cure -- the model moves to the three-term bf16
+    split (full f32 exponent range, twice the matrix work).  Returns False when nothing is left to relax (the caller re-raises): an
+    arithmetic that was asked for explicitly is never changed.  With several ranks every rank reads the same verdict out of the exchanged
+    records (ForwardPlan.check_status), so all of them take the same step."""
+    import warnings
+    if model.math is not None or default_math() != hip.MATH_F16X2:
+        return False
+    cur = float(model.act_scale) if getattr(model, "act_scale", None) else float(os.environ.get("DD3D_F16_ACT_SCALE", "16"))
+    steps = int(getattr(model, "_range_relaxations", 0))
+    if isinstance(err, HalfRangeOverflow) and steps < 2 and cur > 1.0:
+        model.act_scale, model._range_relaxations = max(1.0, cur / 4.0), steps + 1
+        warnings.warn(f"dd3d_amd: {err}; keeping f16x2 with the plane scale lowered {cur:g} -> {model.act_scale:g} "
+                      f"(activations up to {65504.0 / model.act_scale:g})")
+    else:
+        model.math = "bf16x3"
+        warnings.warn(f"dd3d_amd: {err}; switching this model to math='bf16x3'")
+    model._plans.clear()
+    return True
+
+
 class PlanBase:
     """Buffer / workspace bookkeeping and op helpers shared by the full forward plan and the kernel unit tests."""
     def __init__(self, device, dry_run=False):
@@ -110,7 +142,7 @@ class PlanBase:
         st = int(self.status.cpu())
         if st & hip.STATUS_F16_OVERFLOW:
             self.status.zero_()
-            raise FloatingPointError(
+            raise HalfRangeOverflow(
                 f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}, or a "
                 "NaN / inf): lower DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
         if self.amax_names:
@@ -118,7 +150,7 @@ class PlanBase:
             low = [(n, float(v)) for n, v in zip(self.amax_names, mx.tolist()) if 0.0 < v < self.AMAX_FLOOR]
             if low:
                 n, v = min(low, key=lambda t: t[1])
-                raise FloatingPointError(
+                raise HalfRangeUnderflow(
                     f"the outputs of {len(low)} convolution(s) sit below the half range's useful part (smallest: {n}, max |x| = "
                     f"{v / self.act_scale:.3g} at plane scale {self.act_scale:g}; the pair (hi, lo) has an absolute floor of {2.0**-25 / self.act_scale:.2g}): "
                     "raise DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
@@ -131,7 +163,8 @@ class PlanBase:
                 self._range_warned = True
                 n = self.amax_names[int(mx.argmax())]
                 warnings.warn(f"dd3d_amd: f16x2 range headroom is {self.HALF_MAX / top:.2f}x (launch {n}: sampled max |x| = {top / self.act_scale:.4g}, "
-                              f"overflow at {self.HALF_MAX / self.act_scale:g}); lower DD3D_F16_ACT_SCALE or expect the bf16x3 fallback")
+                              f"overflow at {self.HALF_MAX / self.act_scale:g}); beyond it a model on the default arithmetic lowers its plane scale (16 -> 4 -> 1) and, "
+                              "past 65504, falls back to bf16x3 at half the throughput")
 
     def adopt_weight_store(self, model):
         """Use the model's weight store (created on first use; dropped by DD3D.invalidate_plans when the weights change)."""

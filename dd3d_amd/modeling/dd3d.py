@@ -54,6 +54,9 @@ class DD3D(nn.Module):
         # None: DD3D_MATH / the default ("f16x2", falling back to "bf16x3" for good if an activation ever leaves the half range); or one
         # of "f16x2" / "bf16x3" / "f32" / "bf16x2" / "bf16" (dd3d_amd.engine.default_math), set before the first forward
         self.math = None
+        # plane scale of the f16x2 arithmetic (a power of two; None: DD3D_F16_ACT_SCALE / 16).  The range guard's staged fallback lowers it
+        # 16 -> 4 -> 1 on an overflow before it gives up the f16x2 speed (dd3d_amd.engine.plan.relax_arithmetic)
+        self.act_scale = None
         self.training = False
 
     @property
@@ -91,7 +94,7 @@ class DD3D(nn.Module):
 
     def get_plan(self, B, Hp, Wp, world_size=1, rank=0, exchange=None, camera_sharded=False):
         exchange = world_size > 1 if exchange is None else bool(exchange)
-        key = (B, Hp, Wp, world_size, rank, exchange, bool(camera_sharded), self.math) + self._sync_flags()
+        key = (B, Hp, Wp, world_size, rank, exchange, bool(camera_sharded), self.math, self.act_scale) + self._sync_flags()
         plan = self._plans.pop(key, None)
         if plan is None:
             plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank, exchange=exchange, camera_sharded=camera_sharded)
@@ -238,20 +241,15 @@ class DD3D(nn.Module):
 
     @torch.no_grad()
     def forward(self, batched_inputs):
-        plan, image_sizes = self.stage_inputs(batched_inputs)
-        plan.run()
-        try:
-            return self.collect(plan, batched_inputs, image_sizes)
-        except FloatingPointError as e:
-            from dd3d_amd import hip
-            if self.math is not None or plan.math != hip.MATH_F16X2:
-                raise  # the mode was asked for explicitly
-            # the default arithmetic met activations outside the half range: this model runs on the three-term bf16 split (same
-            # f32-equivalent products, full f32 exponent range, twice the matrix work) from now on
-            import warnings
-            warnings.warn(f"dd3d_amd: {e}; switching this model to math='bf16x3'")
-            self.math = "bf16x3"
-            self._plans.clear()  # (the weight store is keyed by arithmetic mode: the packed filters stay, the bf16x3 planes are added)
+        from dd3d_amd.engine import relax_arithmetic
+        while True:
             plan, image_sizes = self.stage_inputs(batched_inputs)
             plan.run()
-            return self.collect(plan, batched_inputs, image_sizes)
+            try:
+                return self.collect(plan, batched_inputs, image_sizes)
+            except FloatingPointError as e:
+                # The range guard of the f16x2 arithmetic.  A model on the default arithmetic first widens the half range (plane scale 16 -> 4
+                # -> 1: activations up to 4094 -> 16376 -> 65504 at the same speed), then runs on the three-term bf16 split from now on (same
+                # f32-equivalent products, full f32 exponent range, twice the matrix work); an explicitly chosen arithmetic raises.
+                if not relax_arithmetic(self, e):
+                    raise

@@ -110,18 +110,13 @@ class DD3DDenseDepth(nn.Module):
         padded input resolution, on the model's device.  The default f16x2 arithmetic is guarded exactly as in DD3D.forward: a kernel
         that met an activation outside the half range trips the plan's status word, the maps are NOT returned, and a model on the
         default arithmetic re-runs (from then on) with the three-term bf16 split."""
-        try:
-            return self._predict_dense_depth(batched_inputs)
-        except FloatingPointError as e:
-            from dd3d_amd import hip
-            from dd3d_amd.engine import default_math
-            if self.math is not None or default_math() != hip.MATH_F16X2:
-                raise  # the mode was asked for explicitly
-            import warnings
-            warnings.warn(f"dd3d_amd: {e}; switching this model to math='bf16x3'")
-            self.math = "bf16x3"
-            self._plans.clear()
-            return self._predict_dense_depth(batched_inputs)
+        from dd3d_amd.engine import relax_arithmetic
+        while True:
+            try:
+                return self._predict_dense_depth(batched_inputs)
+            except FloatingPointError as e:
+                if not relax_arithmetic(self, e):  # (plane scale 16 -> 4 -> 1, then bf16x3; an explicitly chosen arithmetic raises)
+                    raise
 
     def _predict_dense_depth(self, batched_inputs):
         images = [x["image"] for x in batched_inputs]

@@ -343,21 +343,18 @@ class DistributedForward:
         `padded_inference_shard`.  A batch shorter than the plan's (the last batch of a shard, or none at all) is completed with the
         images the plan's buffers already hold -- the step still runs in full -- and only the given images are returned; `valid`
         (list of bool, from padded_inference_shard) drops padding images from the result as well."""
-        try:
-            return self._forward(batched_inputs, valid)
-        except FloatingPointError as e:
-            # The range guard of the default f16x2 arithmetic.  With the exchange every rank read the SAME verdict out of the gathered records
-            # (engine.ForwardPlan.check_status), so all ranks arrive here on the same step and repeat it together on the three-term split.
-            from dd3d_amd import hip
-            if self.model.math is not None or self.plan.math != hip.MATH_F16X2 or (self.world > 1 and not self.exchange):
-                raise
-            import warnings
-            warnings.warn(f"dd3d_amd: {e}; switching this model to math='bf16x3'")
-            torch.cuda.synchronize()
-            self.model.math = "bf16x3"
-            self.model._plans.clear()
-            self._build()
-            return self._forward(batched_inputs, valid)
+        from dd3d_amd.engine import relax_arithmetic
+        while True:
+            try:
+                return self._forward(batched_inputs, valid)
+            except FloatingPointError as e:
+                # The range guard of the default f16x2 arithmetic.  With the exchange every rank read the SAME verdict out of the gathered
+                # records (engine.ForwardPlan.check_status), so all ranks arrive here on the same step and repeat it together -- first with
+                # a wider half range (plane scale 16 -> 4 -> 1), then on the three-term split (engine.plan.relax_arithmetic).
+                if (self.world > 1 and not self.exchange) or not relax_arithmetic(self.model, e):
+                    raise
+                torch.cuda.synchronize()
+                self._build()
 
     def _forward(self, batched_inputs, valid):
         image_sizes = []
@@ -474,7 +471,7 @@ class PipelinedForward:
     Every slot's graphs are replayed once at construction, so the first timed step of a caller does not pay a first-launch cost.
 
     Numeric guard (dd3d_amd.engine.PlanBase.check_status): when the default f16x2 arithmetic meets an activation outside the half pair's
-    range, `result()` -- on a model on the default arithmetic -- drains the pipeline, rebuilds every slot on the three-term bf16 split,
+    range, `result()` -- on a model on the default arithmetic -- drains the pipeline, rebuilds every slot -- with a wider half range first (plane scale 16 -> 4 -> 1), then on the three-term bf16 split --,
     re-runs the requests in flight and returns (what `DD3D.forward` does for a single forward).  With several ranks the verdict of every
     rank travels in the exchanged records, so all ranks take this path for the same slot run."""
     def __init__(self, model, B, Hp, Wp, depth=2, force_exchange=False, compute_streams=1, microbatch=1, runtime=None):
@@ -539,20 +536,17 @@ class PipelinedForward:
 
     def _fall_back(self, err):
         """The range guard of the default f16x2 arithmetic fired on a request (DD3D.forward's behaviour, for the runner): on a model on the
-        default arithmetic, drain the pipeline, rebuild every slot on the three-term bf16 split and re-run the requests that were in flight
+        default arithmetic, drain the pipeline, rebuild every slot on the next arithmetic of engine.plan.relax_arithmetic (plane scale 16 -> 4 -> 1, then the
+        three-term bf16 split) and re-run the requests that were in flight
         (their inputs are still referenced by their slots).  Several ranks: the verdict travels in the exchanged records
         (engine.ForwardPlan.check_status), so every rank raises for the same slot run and all of them rebuild and re-run together, issuing
         the same collectives in the same order -- provided every rank collects its results in the same order, as a data-parallel loop does."""
-        from dd3d_amd import hip
-        if self.model.math is not None or self.plan.math != hip.MATH_F16X2:
-            raise err
-        import warnings
-        warnings.warn(f"dd3d_amd: {err}; switching this model and its pipeline to math='bf16x3'")
+        from dd3d_amd.engine import relax_arithmetic
         for cs in self.compute_streams:
             cs.synchronize()
         self.post_stream.synchronize()
-        self.model.math = "bf16x3"
-        self.model._plans.clear()
+        if not relax_arithmetic(self.model, err):  # plane scale 16 -> 4 -> 1, then bf16x3; an explicitly chosen arithmetic raises
+            raise err
         self._build_plans()
         # Only slots that still owe a result are re-run (a slot whose requests were all collected would only add a collective), and in
         # SUBMISSION order -- the order in which their collectives were first issued, which every rank shares (round-3 advisor: slot-index
@@ -647,12 +641,13 @@ class PipelinedForward:
             self.flush()
         slot.post_done.synchronize()
         inputs, image_sizes = slot.requests[j]
-        try:
-            out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
-        except FloatingPointError as e:
-            self._fall_back(e)  # (raises unless this is one rank on the default arithmetic)
-            slot.post_done.synchronize()
-            out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
+        while True:
+            try:
+                out = self.model.collect(slot.plan, inputs, image_sizes, first=j * self.B)
+                break
+            except FloatingPointError as e:
+                self._fall_back(e)  # (raises once nothing is left to relax; each round re-runs the requests in flight)
+                slot.post_done.synchronize()
         slot.collected[j] = True
         slot.released.record()  # the copies out of the detection buffer are enqueued: later steps of this slot order after them
         return out

@@ -142,7 +142,7 @@ def _guard_worker(rank, world, port, ret):
     cfg = get_cfg("dd3d_kitti_dla34")
     sd = make_state_dict(build_model(cfg), calib=load_calib("dla34_kitti"))
     if rank == 1:
-        a, b, f = "backbone.bottom_up.level3.tree1.tree1.conv1.norm", "backbone.bottom_up.level3.tree1.tree1.conv2.norm", 1.0e4
+        a, b, f = "backbone.bottom_up.level3.tree1.tree1.conv1.norm", "backbone.bottom_up.level3.tree1.tree1.conv2.norm", 1.0e6  # (beyond 65504 at any plane scale: the staged fallback must end on bf16x3)
         sd = {k: v.clone() for k, v in sd.items()}
         sd[a + ".weight"] *= f
         sd[a + ".bias"] *= f

@@ -255,7 +255,8 @@ def test_half_range_guard_with_realistic_statistics(hiplib, kitti_dla34, monkeyp
     scale.  One mid-network activation (DLA level3, between the two norms of a BasicBlock) is scaled so that its largest entry is
       ~2000+  (inside the range, 4094 at plane scale 16)  -> no flag, parity with the oracle on the same weights;
       ~6000   (outside)                                   -> the overflow bit: explicit f16x2 raises BEFORE results are returned, the
-                                                            default arithmetic falls back to bf16x3 and agrees with the oracle;
+                                                            default arithmetic lowers its plane scale to 4 (range 16376), STAYS on f16x2 and
+                                                            agrees with the oracle; ~40000 -> plane scale 1; ~2e5 -> bf16x3;
       ~1e-6   (far below the pair's absolute floor's useful range) -> the per-tensor maximum trips the underflow side of the guard:
                                                             explicit f16x2 raises, the default falls back and agrees with the oracle."""
     from dd3d_amd.synthetic import make_inputs
@@ -288,16 +289,25 @@ def test_half_range_guard_with_realistic_statistics(hiplib, kitti_dla34, monkeyp
     check(m, sd_in)
     p = next(iter(m._plans.values()))
     assert 1800.0 < float(p.amax_values()[slot]) / p.act_scale < 2200.0
-    # ~6000: overflow, and ~1e-6: underflow -- explicit mode raises, default mode falls back
-    for factor, what in ((6000.0 / a0, "half range"), (1e-6 / a0, "useful part")):
-        sd_x = _scaled_between(sd, bn_a, bn_b, factor)
+    # Beyond 4094 the explicit mode raises; the DEFAULT arithmetic first widens the half range -- plane scale 16 -> 4 -> 1, i.e. activations up to
+    # 16376 -> 65504, still f16x2 (engine.plan.relax_arithmetic) -- and only then, or on an underflow, moves to bf16x3; every outcome agrees with
+    # the oracle on the same weights.   (target, error text, plane scale the default ends on or None = bf16x3)
+    for target, what, end_scale in ((6000.0, "half range", 4.0), (40000.0, "half range", 1.0), (2.0e5, "half range", None), (1e-6, "useful part", None)):
+        sd_x = _scaled_between(sd, bn_a, bn_b, target / a0)
         with pytest.raises(FloatingPointError, match=what):
             gpu_model(cfg, sd_x, use_graph=False, math="f16x2")(inputs)
         dflt = gpu_model(cfg, sd_x, use_graph=True, math=None)
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             check(dflt, sd_x)
-        assert any("bf16x3" in str(x.message) for x in w) and dflt.math == "bf16x3"
+        msgs = [str(x.message) for x in w]
+        p = next(iter(dflt._plans.values()))
+        if end_scale is None:
+            assert any("bf16x3" in m for m in msgs) and dflt.math == "bf16x3", (target, msgs)
+        else:
+            assert dflt.math is None and dflt.act_scale == end_scale and p.act_scale == end_scale, (target, dflt.math, dflt.act_scale)
+            assert any("plane scale lowered" in m for m in msgs) and not any("switching this model" in m for m in msgs), msgs
+            assert 0.8 * target < float(p.amax_values()[slot]) / p.act_scale < 1.2 * target  # the activation is really there, inside the wider range
 
 
 def _fpn_outlier(sd, level, channel, factor):
@@ -313,8 +323,8 @@ def _fpn_outlier(sd, level, channel, factor):
 def test_heavy_tailed_fpn_statistics_at_full_size(hiplib, kitti_dla34, monkeypatch):
     """Round-4 verdict item 9: the f16x2 default on activation statistics a real checkpoint may have and the synthetic weights do not -- a
     50x outlier channel in the FPN (384 x 1280).  The forward stays on f16x2, agrees with the oracle on the same weights, and REPORTS how
-    near the range guard it came (PlanBase.range_headroom, the warning below DD3D_RANGE_WARN_X); a 3000x outlier leaves the half range:
-    the default arithmetic falls back to bf16x3 and still agrees."""
+    near the range guard it came (PlanBase.range_headroom, the warning below DD3D_RANGE_WARN_X); a 3000x outlier leaves the half range at the default
+    plane scale: the default arithmetic lowers the scale and stays on f16x2; a 60000x outlier leaves every half range: bf16x3; both agree."""
     from dd3d_amd.synthetic import make_inputs
     cfg, _, sd = kitti_dla34
     monkeypatch.delenv("DD3D_MATH", raising=False)
@@ -345,6 +355,7 @@ def test_heavy_tailed_fpn_statistics_at_full_size(hiplib, kitti_dla34, monkeypat
     assert all(mg <= MARGIN_EPS for mg in margins), margins
     assert len(out[0]["instances"]) > 0
 
+    # x 3000: ~6000 leaves the half range at plane scale 16 -- explicit f16x2 raises; the default lowers the plane scale to 4 and stays on f16x2
     sd3k = _fpn_outlier(sd, 4, 5, 3000.0)
     _, st3 = _oracle(cfg, sd3k, inputs)
     with pytest.raises(FloatingPointError, match="half range"):
@@ -353,5 +364,14 @@ def test_heavy_tailed_fpn_statistics_at_full_size(hiplib, kitti_dla34, monkeypat
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         d(inputs)
-    assert any("bf16x3" in str(x.message) for x in w) and d.math == "bf16x3"
+    assert d.math is None and d.act_scale == 4.0 and any("plane scale lowered" in str(x.message) for x in w)
     _check_head_maps(next(iter(d._plans.values())), st3, C)
+    # x 60000: beyond 65504 whatever the plane scale -- the default ends on bf16x3 and still agrees
+    sd60k = _fpn_outlier(sd, 4, 5, 60000.0)
+    _, st60 = _oracle(cfg, sd60k, inputs)
+    e = gpu_model(cfg, sd60k, use_graph=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        e(inputs)
+    assert any("bf16x3" in str(x.message) for x in w) and e.math == "bf16x3"
+    _check_head_maps(next(iter(e._plans.values())), st60, C)
