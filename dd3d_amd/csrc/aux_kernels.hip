@@ -362,6 +362,40 @@ extern "C" int dd3d_fold_range_flags(const int32_t* status, const float* amax, i
   return check_launch("fold_range_flags_kernel");
 }
 
+namespace dd3d {
+// Everything the host reads after a forward in ONE contiguous run of 4-byte words (one D2H instead of a blocking read per field):
+//   out[0] = *status, out[1] = G, out[2] = n_launches, out[3] = n_flag_recs, out[4 .. 4 + G) = det_count,
+//   then n_launches floats = every watched launch's maximum (over its 16 sub-maxima), then 2 words per exchanged record (the ranks'
+//   range-guard verdicts as dd3d_fold_range_flags wrote them: flags + r * flag_stride).
+__global__ __launch_bounds__(256) void pack_readback_kernel(const int32_t* det_count, int G, const int32_t* status, const float* amax, int n,
+                                                            const int32_t* flags, int nrec, long flag_stride, int32_t* out) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    out[0] = status ? *status : 0;
+    out[1] = G, out[2] = n, out[3] = nrec;
+  }
+  for (int i = t; i < G; i += 256) out[4 + i] = det_count[i];
+  float* fo = reinterpret_cast<float*>(out + 4 + G);
+  for (int i = t; i < n; i += 256) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, amax[((long)i * 16 + j) * 32]);
+    fo[i] = m;
+  }
+  for (int i = t; i < 2 * nrec; i += 256) out[4 + G + n + i] = flags[(long)(i >> 1) * flag_stride + (i & 1)];
+}
+}  // namespace dd3d
+
+extern "C" int dd3d_pack_readback(const int32_t* det_count, int32_t G, const int32_t* status, const float* amax, int32_t n_launches,
+                                  const int32_t* flags, int32_t n_flag_recs, int64_t flag_stride, int32_t* out, void* stream) {
+  using namespace dd3d;
+  DD3D_REQUIRE(out && G >= 0 && n_launches >= 0 && n_flag_recs >= 0 && (G == 0 || det_count) && (n_launches == 0 || amax) && (n_flag_recs == 0 || flags),
+               "dd3d_pack_readback: bad arguments");
+  hipLaunchKernelGGL(pack_readback_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), det_count, G, status, amax, n_launches, flags,
+                     n_flag_recs, (long)flag_stride, out);
+  return check_launch("pack_readback_kernel");
+}
+
 extern "C" int dd3d_invert_intrinsics(const float* K, float* inv_K, int32_t B, void* stream) {
   using namespace dd3d;
   DD3D_REQUIRE(K && inv_K && B > 0, "dd3d_invert_intrinsics: bad arguments");

@@ -832,6 +832,7 @@ struct BevK {
   dd3d_bev_args a;
   int ncap;   // round_up(G*det_cap, 64)
   int ncap2;  // LDS sort capacity (power of two)
+  int mw;     // 64-bit words per mask row = min(ncap, NCAP_MAX) / 64: rows and columns are SORTED positions, and the sorter holds <= NCAP_MAX boxes
 };
 
 struct V2 {
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(64 * MASK_WAVES) void bev_mask_kernel(const BevK P)
       unsigned long long v = part[0][lane];
 #pragma unroll
       for (int w = 1; w < MASK_WAVES; ++w) v |= part[w][lane];
-      a.mask[(long)me * (P.ncap / 64) + cb] = v;
+      a.mask[(long)me * P.mw + cb] = v;
     }
   }
 }
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(PT) void bev_finalize_kernel(const BevK P) {
   const dd3d_bev_args& a = P.a;
   const int tid = threadIdx.x;
   const int n = a.meta[0];
-  const int nw = P.ncap / 64;
+  const int nw = P.mw;
   const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(a.mask);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   unsigned long long* removed = reinterpret_cast<unsigned long long*>(dyn_lds);          // [NCAP_MAX/64]
@@ -1257,6 +1258,7 @@ extern "C" int dd3d_bev_nms_aggregate(const dd3d_bev_args* args, void* stream) {
   P.ncap = (int)((ntot + 63) / 64 * 64);
   P.ncap2 = 64;
   while (P.ncap2 < ntot && P.ncap2 < NCAP_MAX) P.ncap2 <<= 1;
+  P.mw = (P.ncap < NCAP_MAX ? P.ncap : NCAP_MAX) / 64;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds_prep = (size_t)P.ncap2 * 8;
   const size_t lds_fin = (size_t)NCAP_MAX / 64 * 8 + (size_t)P.ncap2 * 4;

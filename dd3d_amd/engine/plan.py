@@ -28,24 +28,38 @@ class HalfRangeUnderflow(FloatingPointError):
 
 def relax_arithmetic(model, err):
     """What a model on the DEFAULT arithmetic (model.math is None) does after the f16x2 range guard fired -- shared by DD3D.forward,
-    DD3DDenseDepth and the runners of dd3d_amd.parallel.  An OVERFLOW first widens the half range: the plane scale 16 -> 4 -> 1 lifts the
-    largest representable activation 4094 -> 16376 -> 65504 at the f16x2 speed (the pair's absolute floor rises with it; the underflow side
-    of the guard keeps watching); only then -- or on an underflow, which no smaller scale can cure -- the model moves to the three-term bf16
-    split (full f32 exponent range, twice the matrix work).  Returns False when nothing is left to relax (the caller re-raises): an
-    arithmetic that was asked for explicitly is never changed.  With several ranks every rank reads the same verdict out of the exchanged
-    records (ForwardPlan.check_status), so all of them take the same step."""
+    DD3DDenseDepth and the runners of dd3d_amd.parallel.  An OVERFLOW first widens the half range: a plane scale of 16 / 4 / 1 holds
+    activations up to 4094 / 16376 / 65504 at the f16x2 speed (the pair's absolute floor rises with it; the underflow side of the guard
+    keeps watching); only beyond that -- or on an underflow, which no smaller scale can cure -- the model moves to the three-term bf16
+    split (full f32 exponent range, twice the matrix work).  The target scale is chosen in ONE step from the largest activation the guard
+    sampled (`err.sampled_max_abs`, a lower bound of the true maximum: the scale must leave it a factor of two; round-5 advisor: stepping
+    16 -> 4 -> 1 -> bf16x3 blindly cost a corrupted frame three plan rebuilds per pipeline slot), by factors of four down to 1; a
+    NON-FINITE maximum (a NaN / inf input frame trips the overflow bit too) goes straight to bf16x3, as does a maximum no half can hold.
+    Without a sample (the verdict came from another rank's record) the scale goes down one factor of four per call.  Returns False when
+    nothing is left to relax (the caller re-raises): an arithmetic that was asked for explicitly is never changed.  With several ranks
+    every rank reads the same verdict out of the exchanged records (ForwardPlan.check_status), so all of them rebuild on the same step."""
     import warnings
     if model.math is not None or default_math() != hip.MATH_F16X2:
         return False
     cur = float(model.act_scale) if getattr(model, "act_scale", None) else float(os.environ.get("DD3D_F16_ACT_SCALE", "16"))
-    steps = int(getattr(model, "_range_relaxations", 0))
-    if isinstance(err, HalfRangeOverflow) and steps < 2 and cur > 1.0:
-        model.act_scale, model._range_relaxations = max(1.0, cur / 4.0), steps + 1
+    amax = getattr(err, "sampled_max_abs", None)
+    finite = amax is None or math.isfinite(amax)
+    new = None
+    if isinstance(err, HalfRangeOverflow) and cur > 1.0 and finite:
+        new = max(1.0, cur / 4.0)
+        if amax:
+            while new > 1.0 and amax * new >= PlanBase.HALF_MAX / 2.0:
+                new = max(1.0, new / 4.0)
+            if amax * new >= PlanBase.HALF_MAX:
+                new = None  # no half holds it at any scale
+    if new is not None:
+        model.act_scale = new
+        model._range_relaxations = int(getattr(model, "_range_relaxations", 0)) + 1
         warnings.warn(f"dd3d_amd: {err}; keeping f16x2 with the plane scale lowered {cur:g} -> {model.act_scale:g} "
-                      f"(activations up to {65504.0 / model.act_scale:g})")
+                      f"(activations up to {65504.0 / model.act_scale:g}" + (f"; largest sampled |x| = {amax:.4g})" if amax else ")"))
     else:
         model.math = "bf16x3"
-        warnings.warn(f"dd3d_amd: {err}; switching this model to math='bf16x3'")
+        warnings.warn(f"dd3d_amd: {err}; switching this model to math='bf16x3'" + ("" if finite else " (non-finite activations)"))
     model._plans.clear()
     return True
 
@@ -92,6 +106,86 @@ class PlanBase:
         self.amax = torch.zeros((512, 16, 32), dtype=torch.float32, device=self.device)  # [launch][sub-maximum][128-byte line]
         self.amax_names = []
 
+    # ------------------------------------------------------------------ host <-> device hand-over
+    def host_buf(self, shape, dtype):
+        """Host staging memory: pinned where there is a device (asynchronous copies), plain for dry-run plans."""
+        pin = self.device.type == "cuda" and not self.dry_run
+        return torch.zeros(shape, dtype=dtype, pin_memory=pin)
+
+    def inputs_writable(self):
+        """Call before rewriting the host mirrors of the per-image scalars: the previous forward's copy out of them must have run."""
+        if getattr(self, "_inputs_event", None) is not None:
+            self._inputs_event.synchronize()
+
+    def flush_inputs(self):
+        """Ship the per-image scalars `stage_inputs` wrote into the pinned host mirrors: ONE asynchronous copy for sizes + intrinsics, one
+        for the resize targets (they live in the exchange record), two more for plans with BEV stages (poses, sample ids) -- per FORWARD,
+        however many requests share the plan."""
+        nb = not self.dry_run
+        self.in_meta.copy_(self.host_meta, non_blocking=nb)
+        self.in_outsize.copy_(self.host_outsize, non_blocking=nb)
+        if getattr(self, "has_bev_inputs", False) and self.host_pose is not None:
+            self.in_pose.copy_(self.host_pose, non_blocking=nb)
+            if not getattr(self, "camera_sharded", False):
+                self.in_group.copy_(self.host_group, non_blocking=nb)
+        if nb:
+            if self._inputs_event is None:
+                self._inputs_event = torch.cuda.Event()
+            self._inputs_event.record()
+
+    def _ensure_readback(self):
+        """Buffers of dd3d_pack_readback (allocated at the first launch, i.e. outside any capture: every runner warms a plan up first)."""
+        if getattr(self, "_rb_dev", None) is not None:
+            return
+        det_count = getattr(self, "det_count", None)
+        self._rb_G = int(det_count.numel()) if det_count is not None else 0
+        self._rb_n = len(self.amax_names) if self.math == hip.MATH_F16X2 else 0
+        gathered = getattr(self, "gathered", None)
+        self._rb_nrec = int(self.world_size) if (gathered is not None and getattr(self, "exchange", False) and self.math == hip.MATH_F16X2) else 0
+        words = 4 + self._rb_G + self._rb_n + 2 * self._rb_nrec
+        self._rb_dev = torch.zeros(words, dtype=torch.int32, device=self.device)
+        self._rb_host = self.host_buf(words, torch.int32)
+        self._rb_event = torch.cuda.Event()
+        self._rb_pending, self._rb_cache = False, None
+
+    def _launch_readback(self, st):
+        """Last launch of a forward: everything the host reads afterwards, packed for one copy (include/dd3d_hip.h, dd3d_pack_readback)."""
+        flags = None
+        if self._rb_nrec:
+            flags = self.gathered.data_ptr() + 4 * self.flags_off
+        hip.check(self.lib.dd3d_pack_readback(self.det_count.data_ptr() if self._rb_G else None, self._rb_G, self.status.data_ptr(),
+                                              self.amax.data_ptr() if self._rb_n else None, self._rb_n, flags, self._rb_nrec,
+                                              int(getattr(self, "record_len", 0)), self._rb_dev.data_ptr(), st), "pack_readback")
+
+    def fetch(self):
+        """Enqueue, behind the forward just issued on the current stream, the ONE asynchronous device-to-host copy of its read-back words
+        (detection counts, status, range-guard maxima, exchanged verdicts) into pinned memory.  `readback()` waits for it."""
+        if self.dry_run:
+            return
+        self._ensure_readback()
+        self._rb_host.copy_(self._rb_dev, non_blocking=True)
+        self._rb_event.record()
+        self._rb_pending, self._rb_cache = True, None
+
+    def readback(self):
+        """Host view of the last forward's read-back words: waits for the copy `fetch()` enqueued (or, when the forward was issued without
+        one -- a test replaying launches by hand -- packs and copies now, on the current stream)."""
+        from types import SimpleNamespace
+        self._ensure_readback()
+        if self._rb_cache is not None:
+            return self._rb_cache
+        if not self._rb_pending:
+            self._launch_readback(hip.current_stream())
+            self.fetch()
+        self._rb_event.synchronize()
+        self._rb_pending = False
+        w = self._rb_host
+        G, n, nrec = self._rb_G, self._rb_n, self._rb_nrec
+        assert (int(w[1]), int(w[2]), int(w[3])) == (G, n, nrec), "read-back record does not match the plan"
+        self._rb_cache = SimpleNamespace(status=int(w[0]), counts=w[4:4 + G].clone(), amax=w[4 + G:4 + G + n].view(torch.float32).clone(),
+                                         flags=w[4 + G + n:4 + G + n + 2 * nrec].view(nrec, 2).clone())
+        return self._rb_cache
+
     @property
     def use_planes(self):
         """Convolutions hand their outputs to the next convolution as split planes (csrc/conv_planes.hip) -- always in the reduced
@@ -134,19 +228,23 @@ class PlanBase:
                 "largest_activation": hi / self.act_scale, "overflow_at": self.HALF_MAX / self.act_scale,
                 "smallest_launch_maximum_scaled": lo, "smallest_in": lo_n, "underflow_headroom_x": lo / self.AMAX_FLOOR}
 
-    def check_status(self):
+    def check_status(self, rb=None):
         """Raise if a kernel flagged a numeric fault (reads one int32 and the per-launch maxima from the device; call after the forward
-        has been waited for).  DD3D_MATH_F16X2 keeps activations as two IEEE halves of value * plane scale: exact to 2^-24 relative
+        has been waited for; `rb`: the forward's `readback()` -- nothing is read from the device then).  DD3D_MATH_F16X2 keeps activations as two IEEE halves of value * plane scale: exact to 2^-24 relative
         between 2^-1 and 65504, with an ABSOLUTE floor of 2^-25 below.  Overflow is flagged per element (status bit); underflow per
         tensor: a convolution whose LARGEST output, scaled, stayed below 2^-5 has lost more than four of its 24 bits."""
-        st = int(self.status.cpu())
+        st = int(self.status.cpu()) if rb is None else rb.status
+        mx = None
+        if self.amax_names and (rb is None or rb.amax.numel() == len(self.amax_names)):
+            mx = self.amax_values() if rb is None else rb.amax
         if st & hip.STATUS_F16_OVERFLOW:
             self.status.zero_()
-            raise HalfRangeOverflow(
+            e = HalfRangeOverflow(
                 f"an activation left the half range while being split (|x| > {65504.0 / self.act_scale:g} at plane scale {self.act_scale:g}, or a "
                 "NaN / inf): lower DD3D_F16_ACT_SCALE or run this model with math='bf16x3'")
-        if self.amax_names:
-            mx = self.amax_values()
+            e.sampled_max_abs = self._sampled_max_abs(mx)  # (what relax_arithmetic sizes the next plane scale by)
+            raise e
+        if mx is not None:
             low = [(n, float(v)) for n, v in zip(self.amax_names, mx.tolist()) if 0.0 < v < self.AMAX_FLOOR]
             if low:
                 n, v = min(low, key=lambda t: t[1])
@@ -165,6 +263,20 @@ class PlanBase:
                 warnings.warn(f"dd3d_amd: f16x2 range headroom is {self.HALF_MAX / top:.2f}x (launch {n}: sampled max |x| = {top / self.act_scale:.4g}, "
                               f"overflow at {self.HALF_MAX / self.act_scale:g}); beyond it a model on the default arithmetic lowers its plane scale (16 -> 4 -> 1) and, "
                               "past 65504, falls back to bf16x3 at half the throughput")
+
+    def _sampled_max_abs(self, mx):
+        """Largest sampled |activation| (value units) behind an overflow verdict, from the per-launch maxima `mx` (launch order): the FIRST
+        launch whose sampled maximum left the half range is the culprit -- everything downstream of it computed on infinities, so later
+        maxima say nothing.  inf when the culprit's own maximum is not finite (non-finite INPUT); when no sample caught the overflowing
+        element, the largest finite sample (a lower bound); None without samples."""
+        if mx is None or not mx.numel():
+            return None
+        vals = [float(v) for v in mx.tolist()]
+        for v in vals:
+            if not (v < self.HALF_MAX):  # (>= the largest half, or NaN)
+                return v / float(self.act_scale) if math.isfinite(v) else float("inf")
+        top = max(vals)
+        return top / float(self.act_scale) if top > 0.0 else None
 
     def adopt_weight_store(self, model):
         """Use the model's weight store (created on first use; dropped by DD3D.invalidate_plans when the weights change)."""
@@ -377,6 +489,8 @@ class PlanBase:
     def launch(self, first=0, last=None):
         if self.dry_run:
             raise RuntimeError("dry-run plan: there is no CPU execution path")
+        self._ensure_readback()
+        self._rb_pending, self._rb_cache = False, None  # (a new forward: what an earlier fetch delivered is stale)
         main = torch.cuda.current_stream()
         st = hip.current_stream()
         ahead = set()  # side branches holding work the main stream has not waited for yet
@@ -398,6 +512,8 @@ class PlanBase:
                 op(self.lib, hip.current_stream())
         for j in ahead:
             main.wait_stream(self._side_streams[j])
+        if last is None:  # the forward's tail: pack what the host reads afterwards (captured with the rest)
+            self._launch_readback(st)
 
     def capture(self):
         """Capture the whole launch sequence into one hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture)."""
@@ -415,6 +531,7 @@ class PlanBase:
             self.graph.replay()
         else:
             self.launch()
+        self.fetch()  # the read-back copy rides behind the forward: collect() finds counts / status in pinned memory
 
     @property
     def conv_macs(self):

@@ -16,7 +16,7 @@ _lib = None
 MAX_LEVELS = 8
 MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16, MATH_F16X2 = 0, 1, 2, 3, 4
 MATH_PLANES = {MATH_F32: 0, MATH_BF16X3: 3, MATH_BF16X2: 2, MATH_BF16: 1, MATH_F16X2: 2}  # 16-bit terms per value (dd3d_math_planes)
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATUS_F16_OVERFLOW = 1
 CAND_FIELDS = 22
 DET_FIELDS = 32
@@ -127,7 +127,7 @@ EXPORTS = [
     "dd3d_abi_version", "dd3d_last_error", "dd3d_arch", "dd3d_build_flags", "dd3d_conv_tile_shape", "dd3d_conv_row_rings", "dd3d_conv2d_igemm_f32",
     "dd3d_preprocess_u8_nhwc4", "dd3d_maxpool2x2_nhwc", "dd3d_maxpool3x3s2_ceil_nhwc", "dd3d_ese_nhwc", "dd3d_upsample2x_add_nhwc", "dd3d_fcos_select_decode",
     "dd3d_invert_intrinsics", "dd3d_nms_finalize", "dd3d_bev_nms_aggregate", "dd3d_conv2d_smallc_supported", "dd3d_conv2d_smallc_bf16x3", "dd3d_rotate_iou_eval", "dd3d_d3_box_overlap", "dd3d_image_box_overlap", "dd3d_aligned_bilinear_scale", "dd3d_resize_bilinear_u8",
-    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_maxpool2x2_planes_in", "dd3d_upsample2x_add_planes", "dd3d_ese_fused", "dd3d_stem_fused_f16x2", "dd3d_fold_range_flags"
+    "dd3d_format_boxes3d", "dd3d_math_planes", "dd3d_split_planes", "dd3d_maxpool2x2_planes", "dd3d_maxpool2x2_planes_in", "dd3d_upsample2x_add_planes", "dd3d_ese_fused", "dd3d_stem_fused_f16x2", "dd3d_fold_range_flags", "dd3d_pack_readback"
 ]
 
 
@@ -179,6 +179,7 @@ def lib():
     L.dd3d_conv2d_smallc_bf16x3.argtypes = [C.POINTER(SmallcArgs), C.c_void_p]
     L.dd3d_stem_fused_f16x2.argtypes = [C.POINTER(StemArgs), C.c_void_p]
     L.dd3d_fold_range_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+    L.dd3d_pack_readback.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
     L.dd3d_rotate_iou_eval.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p]
     L.dd3d_d3_box_overlap.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p]
     L.dd3d_image_box_overlap.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p]

@@ -112,11 +112,16 @@ class DD3D(nn.Module):
             self._plans.pop(next(iter(self._plans)))
 
     # ------------------------------------------------------------------ host side of forward
-    def stage_inputs(self, batched_inputs, plan=None, first=0, partial=False):
+    def stage_inputs(self, batched_inputs, plan=None, first=0, partial=False, flush=True):
         """core.py:65-72: gather images/intrinsics; the padded canvas geometry is ImageList.from_tensors'
         (image_list.py:120-142).  Returns (plan, image_sizes).  `first` (with a fixed `plan` only): the batch goes to positions
         [first, first + len(batch)) of a plan; `partial` allows a batch shorter than the plan's (PipelinedForward micro-batches, the
-        short last batch of a shard): the other positions keep what they held and their outputs are the caller's to ignore."""
+        short last batch of a shard): the other positions keep what they held and their outputs are the caller's to ignore.
+
+        Host cost per request (round 6): the image goes by ONE asynchronous copy per image (a pinned source never blocks the host); sizes,
+        intrinsics, resize targets (and poses / sample ids of a model with BEV stages) are plain stores into the plan's pinned host mirrors,
+        shipped by `plan.flush_inputs()` -- here when `flush`, or once per slot run by a runner that stages several requests into one plan
+        (`flush=False`; PipelinedForward._enqueue)."""
         images = [x["image"] for x in batched_inputs]
         image_sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         div = self.backbone.size_divisibility
@@ -145,21 +150,22 @@ class DD3D(nn.Module):
         sl = slice(first, first + B)
         for i, im in enumerate(images):
             assert im.dtype == torch.uint8 and im.shape[0] == 3, "expected uint8 (3,H,W) images (dataset_mapper.py:127)"
-            plan.in_u8[first + i, :, :im.shape[1], :im.shape[2]].copy_(im, non_blocking=True)
-        sizes = torch.tensor(image_sizes, dtype=torch.int32)
-        outsz = torch.tensor(
-            [[s[0], s[1], x.get("height", s[0]), x.get("width", s[1])] for s, x in zip(image_sizes, batched_inputs)],
-            dtype=torch.float32
-        )
-        plan.in_sizes[sl].copy_(sizes, non_blocking=True)
-        plan.in_K[sl].copy_(K.reshape(B, 9), non_blocking=True)
-        plan.in_outsize[sl].copy_(outsz, non_blocking=True)
+            if im.shape[1] == plan.Hp and im.shape[2] == plan.Wp:
+                plan.in_u8[first + i].copy_(im, non_blocking=True)  # whole canvas: one contiguous copy
+            else:
+                plan.in_u8[first + i, :, :im.shape[1], :im.shape[2]].copy_(im, non_blocking=True)
+        plan.inputs_writable()  # (the previous forward's copy out of the host mirrors has run: normally long ago)
+        plan.host_sizes[sl] = torch.tensor(image_sizes, dtype=torch.int32)
+        plan.host_K[sl] = K.reshape(B, 9)
+        plan.host_outsize[sl] = torch.tensor(
+            [[s[0], s[1], x.get("height", s[0]), x.get("width", s[1])] for s, x in zip(image_sizes, batched_inputs)], dtype=torch.float32)
         if plan.has_bev_inputs:  # BEV stages need camera->global poses and sample membership
-            plan.in_pose[sl].copy_(torch.tensor([self._pose_vec(x) for x in batched_inputs], dtype=torch.float32), non_blocking=True)
+            plan.host_pose[sl] = torch.tensor([self._pose_vec(x) for x in batched_inputs], dtype=torch.float32)
             if not getattr(plan, "camera_sharded", False):  # (camera-sharded: membership is positional in the global image order)
                 # sample ids are per request: offset by the position so that requests sharing a plan never merge their samples
-                groups = torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32) + first
-                plan.in_group[sl].copy_(groups, non_blocking=True)
+                plan.host_group[sl] = torch.tensor(self._sample_groups(batched_inputs), dtype=torch.int32) + first
+        if flush:
+            plan.flush_inputs()
         return plan, image_sizes
 
     @staticmethod
@@ -172,10 +178,12 @@ class DD3D(nn.Module):
         return list(range(len(batched_inputs)))
 
     def _counts(self, plan):
-        """Detection counts of the plan's last forward (this is the host's wait for the forward), with the device-side faults checked."""
-        counts = plan.det_count.cpu()
-        if getattr(plan, "check_status", None) is not None:
-            plan.check_status()  # a numeric fault flagged by a kernel (half-range overflow of the f16x2 mode) fails the forward loudly
+        """Detection counts of the plan's last forward (this is the host's wait for the forward), with the device-side faults checked --
+        all out of the forward's read-back record (engine.PlanBase.readback: one asynchronous copy into pinned memory, enqueued behind the
+        forward; round 5 read counts, status word and range-guard maxima with one blocking copy each, per request)."""
+        rb = plan.readback()
+        plan.check_status(rb)  # a numeric fault flagged by a kernel (half-range overflow of the f16x2 mode) fails the forward loudly
+        counts = rb.counts
         if counts.numel() and int(counts.min()) < 0:
             raise RuntimeError("more than 8192 detections met in one BEV NMS problem (the capacity of its LDS sorter): feed fewer images per step")
         n_max = int(counts.max()) if counts.numel() else 0
@@ -184,36 +192,35 @@ class DD3D(nn.Module):
         return counts, n_max
 
     def _instances(self, plan, d, size, inv_K):
-        """Rows of the detection buffer (a private copy) -> Instances with the reference's fields (core.py:153-164)."""
+        """Rows of the detection buffer (a PRIVATE copy: the fields below are views of it, no further copies) -> Instances with the
+        reference's fields (core.py:153-164)."""
         n = d.shape[0]
         r = Instances(size)
-        r.pred_boxes = Boxes(d[:, 0:4].contiguous())
-        r.scores = d[:, 4].contiguous()
-        r.pred_classes = d[:, 6].to(torch.int64)
-        r.locations = d[:, 8:10].contiguous()
-        r.fpn_levels = d[:, 7].to(torch.int64)
+        r.pred_boxes = Boxes(d[:, 0:4])
+        r.scores = d[:, 4]
+        ints = d[:, 6:8].to(torch.int64)  # [class, level]
+        r.pred_classes = ints[:, 0]
+        r.locations = d[:, 8:10]
+        r.fpn_levels = ints[:, 1]
         if not self.only_box2d:
-            r.pred_boxes3d = Boxes3D(
-                d[:, 10:14].contiguous(), d[:, 14:16].contiguous(), d[:, 16:17].contiguous(), d[:, 17:20].contiguous(),
-                inv_K[None].expand(n, 3, 3)
-            )
-            r.scores_3d = d[:, 5].contiguous()
+            r.pred_boxes3d = Boxes3D(d[:, 10:14], d[:, 14:16], d[:, 16:17], d[:, 17:20], inv_K[None].expand(n, 3, 3))
+            r.scores_3d = d[:, 5]
         self._collect_extra(r, d, plan)
         return r
 
     def collect(self, plan, batched_inputs, image_sizes, first=0):
-        """Detection buffer -> List[{"instances": Instances}] for the images at positions [first, first + len(batch)) of the plan."""
+        """Detection buffer -> List[{"instances": Instances}] for the images at positions [first, first + len(batch)) of the plan.  Per image:
+        one device copy of its detection rows (the results must not alias a buffer the next forward overwrites) and one integer cast;
+        every field is a view of that copy."""
         counts, n_max = self._counts(plan)
-        det = plan.det[:, :max(n_max, 1)]
-        inv_K = plan.inv_K.view(-1, 3, 3).clone()  # the results must not alias a buffer the next forward overwrites
+        B = len(batched_inputs)
+        inv_K = plan.inv_K.view(-1, 3, 3)[first:first + B].clone()
         results = []
         for i, (inp, isz) in enumerate(zip(batched_inputs, image_sizes)):
             g = first + i
-            # one private copy per image: a (1, k) slice of the detection buffer is "contiguous" whatever its row stride, so
-            # .contiguous() on such a slice would return a VIEW of the plan buffer that the next forward overwrites
-            d = det[g, :int(counts[g])].clone()
+            d = plan.det[g, :int(counts[g])].clone()
             size = (int(inp.get("height", isz[0])), int(inp.get("width", isz[1]))) if self.postprocess_in_inference else isz
-            results.append({"instances": self._instances(plan, d, size, inv_K[g])})
+            results.append({"instances": self._instances(plan, d, size, inv_K[i])})
         return results
 
     def collect_owned(self, plan):
@@ -225,7 +232,7 @@ class DD3D(nn.Module):
             torch.cuda.current_stream().synchronize()
             return []
         counts, n_max = self._counts(plan)
-        det = plan.det[:, :max(n_max, 1)]
+        det = plan.det
         sl = slice(plan.img_first, plan.img_first + plan.G)
         osz = plan.gathered_field("outsize")[sl].cpu()
         inv_K = plan.gathered_field("inv_K")[sl].reshape(-1, 3, 3).clone()

@@ -60,6 +60,6 @@ class NuscenesDD3D(DD3D):
 
     def _collect_extra(self, r, d, plan):
         r.pred_attributes = d[:, 20].to(torch.int64)
-        r.pred_speeds = d[:, 21].contiguous()
+        r.pred_speeds = d[:, 21]  # (views of the image's private copy of its detection rows, like every other field: DD3D._instances)
         if plan.has_global_boxes:
-            r.pred_boxes3d_global = GenericBoxes3D(d[:, 22:26].contiguous(), d[:, 26:29].contiguous(), d[:, 17:20].contiguous())
+            r.pred_boxes3d_global = GenericBoxes3D(d[:, 22:26], d[:, 26:29], d[:, 17:20])

@@ -135,43 +135,68 @@ def graph_exchange_probe(group=None, timeout_s=20.0):
     ok = False
     if dist.is_initialized() and dist.get_backend(group) == "nccl" and torch.cuda.is_available():
         import time
+        import warnings
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def agree(flag):  # AND over the ranks on the step's own (working) communicator: every rank takes the same branch below
+            v = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(v.item()))
+
+        # Every rank issues the SAME sequence of collectives whatever fails locally (round-5 advisor: a rank that threw before / inside
+        # new_group or the first all_gather left its peers blocked in them): the probe communicator is created unconditionally, each stage
+        # records its local outcome, and the ranks agree on it before the next stage -- nobody replays a graph some rank failed to capture.
+        pg = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group), backend="nccl")
+        side = torch.cuda.Stream()
+        src = torch.zeros(64, dtype=torch.float32, device=dev)
+        dst = torch.zeros(64 * world, dtype=torch.float32, device=dev)
+        why, g = None, None
         try:
-            pg = dist.new_group(ranks=list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group), backend="nccl")
-            dev = torch.device("cuda", torch.cuda.current_device())
-            src = torch.zeros(64, dtype=torch.float32, device=dev)
-            dst = torch.zeros(64 * world, dtype=torch.float32, device=dev)
-            side = torch.cuda.Stream()
             with torch.cuda.stream(side):
                 src.fill_(float(rank) + 0.25)
                 dist.all_gather_into_tensor(dst, src, group=pg)  # eager first: creates the communicator outside the capture
                 side.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=side):
-                    dist.all_gather_into_tensor(dst, src, group=pg)
+        except Exception as e:
+            why = f"eager all_gather on the probe communicator: {type(e).__name__}: {e}"
+        if agree(why is None):
+            try:
+                with torch.cuda.stream(side):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        dist.all_gather_into_tensor(dst, src, group=pg)
+            except Exception as e:
+                why = f"capture: {type(e).__name__}: {e}"
+            if agree(why is None):
                 good = True
-                for it in range(2):
-                    src.fill_(1000.0 * (it + 1) + rank)
-                    dst.zero_()
-                    g.replay()
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    t0 = time.perf_counter()
-                    while not ev.query():
-                        if time.perf_counter() - t0 > timeout_s:
-                            raise TimeoutError("captured all_gather did not complete")
-                        time.sleep(0.001)
-                    want = torch.arange(world, dtype=torch.float32, device=dev).repeat_interleave(64) + 1000.0 * (it + 1)
-                    good = good and bool(torch.equal(dst, want))
-            ok = good
-        except Exception as e:  # capture not supported by this RCCL build / timeout: the eager exchange stays
-            import warnings
-            warnings.warn(f"dd3d_amd: the all_gather cannot be captured in a hipGraph on this transport ({type(e).__name__}: {e}); "
+                try:
+                    with torch.cuda.stream(side):
+                        for it in range(2):
+                            src.fill_(1000.0 * (it + 1) + rank)
+                            dst.zero_()
+                            g.replay()
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            t0 = time.perf_counter()
+                            while not ev.query():
+                                if time.perf_counter() - t0 > timeout_s:
+                                    raise TimeoutError("captured all_gather did not complete")
+                                time.sleep(0.001)
+                            want = torch.arange(world, dtype=torch.float32, device=dev).repeat_interleave(64) + 1000.0 * (it + 1)
+                            good = good and bool(torch.equal(dst, want))
+                    if not good:
+                        why = "replay delivered wrong data"
+                except Exception as e:  # (a timed-out replay: the probe's stream and communicator are abandoned, not destroyed)
+                    why = f"replay: {type(e).__name__}: {e}"
+                ok = agree(why is None)
+        if why is not None:
+            warnings.warn(f"dd3d_amd: the all_gather cannot be captured in a hipGraph on this transport ({why}); "
                           "the exchange runs eagerly between the two graph halves")
-            ok = False
-        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
-        ok = bool(int(verdict.item()))
+        if why is None or not why.startswith("replay: TimeoutError"):
+            try:
+                dist.destroy_process_group(pg)  # (the probe's communicator is not needed again; a hung one is left alone)
+            except Exception:
+                pass
     _PROBE_RESULT[key] = ok
     return ok
 
@@ -327,6 +352,7 @@ class DistributedForward:
             return
         if self.step_graph is not None:
             self.step_graph.replay()  # pre half, RCCL all_gather and post half in one captured graph
+            p.fetch()
             return
         if self.pre_graph is not None:
             self.pre_graph.replay()
@@ -337,6 +363,7 @@ class DistributedForward:
             self.post_graph.replay()
         else:
             p.launch(p.num_pre_nms_ops)
+        p.fetch()  # (every path that issues a forward ends with the read-back copy: what an earlier one delivered is stale from here on)
 
     def forward(self, batched_inputs, valid=None):
         """One step.  Every rank must call this the same number of times (each call holds the step's collective): feed the ranks with
@@ -496,6 +523,7 @@ class PipelinedForward:
             slot.released.record()
             slot.requests = [None] * self.microbatch  # (inputs, image_sizes) of the requests staged into the slot
             slot.fill, slot.enqueued, slot.generation = 0, True, 0
+            slot.dirty_inputs = False  # host mirrors of the per-image scalars hold something `flush_inputs` has not shipped yet
             slot.seq = -1  # order of acquisition (submission order of the slot's requests)
             slot.collected = [False] * self.microbatch  # requests whose result the caller already holds
             slot.compute_stream = self.compute_streams[i % compute_streams]
@@ -557,13 +585,17 @@ class PipelinedForward:
                 continue
             with self.rt.on(slot.compute_stream):
                 for j, (inputs, _) in staged:
-                    self.model.stage_inputs(inputs, plan=slot.plan, first=j * self.B, partial=True)
+                    self.model.stage_inputs(inputs, plan=slot.plan, first=j * self.B, partial=True, flush=False)
+            slot.dirty_inputs = True
             if slot.enqueued:
                 self._enqueue(slot)
 
     def _enqueue(self, slot):
         cs, ps = slot.compute_stream, self.post_stream
         with self.rt.on(cs):
+            if slot.dirty_inputs:  # sizes / intrinsics / resize targets of every request staged into the slot: one hand-over per slot run
+                slot.plan.flush_inputs()
+                slot.dirty_inputs = False
             slot.pre_graph.replay()
             slot.pre_done.record(cs)
         ps.wait_event(slot.pre_done)
@@ -572,6 +604,7 @@ class PipelinedForward:
             if self.exchange:
                 gather_candidates(slot.plan.gather_pairs())
             slot.post_graph.replay()
+            slot.plan.fetch()  # counts / status / range-guard words -> pinned memory, behind the post half (result() reads them there)
             slot.post_done.record(ps)
         slot.enqueued = True
         if self._filling is slot:
@@ -613,10 +646,15 @@ class PipelinedForward:
             self._enqueue(self._filling)
 
     def stage_all(self, batched_inputs):
-        """The same B inputs into every position of every slot (bench: inputs resident before the timed region)."""
+        """Inputs resident before a timed region (bench): `batched_inputs` is one request's B inputs -- staged into every position of every
+        slot -- or a list of `microbatch` requests: request j goes to position j of every slot."""
+        per_pos = batched_inputs if isinstance(batched_inputs[0], (list, tuple)) else [batched_inputs] * self.microbatch
+        assert len(per_pos) == self.microbatch
         for slot in self.slots:
-            for j in range(self.microbatch):
-                self.model.stage_inputs(batched_inputs, plan=slot.plan, first=j * self.B, partial=True)
+            with self.rt.on(slot.compute_stream):
+                for j, inp in enumerate(per_pos):
+                    self.model.stage_inputs(inp, plan=slot.plan, first=j * self.B, partial=True, flush=False)
+                slot.plan.flush_inputs()
         self.rt.synchronize()
 
     def submit(self, batched_inputs):
@@ -628,7 +666,8 @@ class PipelinedForward:
             if x["image"].is_cuda:
                 x["image"].record_stream(slot.compute_stream)
         with self.rt.on(slot.compute_stream):
-            _, image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan, first=j * self.B, partial=True)
+            _, image_sizes = self.model.stage_inputs(batched_inputs, plan=slot.plan, first=j * self.B, partial=True, flush=False)
+        slot.dirty_inputs = True
         slot.requests[j] = (batched_inputs, image_sizes)
         if slot.fill == self.microbatch:
             self._enqueue(slot)

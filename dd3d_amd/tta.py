@@ -145,7 +145,7 @@ class _MergeNMS:
             group = torch.zeros((1, ), dtype=torch.int32, device=dev)
             ncapb = ncap
             work = dict(work=torch.zeros((n, 16), dtype=torch.float32, device=dev), sbox=torch.zeros((n, 8), dtype=torch.float32, device=dev),
-                        mask=torch.zeros((ncapb, ncapb // 64), dtype=torch.int64, device=dev), meta=torch.zeros((4, ), dtype=torch.int32, device=dev),
+                        mask=torch.zeros((min(ncapb, 8192), min(ncapb, 8192) // 64), dtype=torch.int64, device=dev), meta=torch.zeros((4, ), dtype=torch.int32, device=dev),
                         det_out=torch.zeros_like(det), count_out=torch.zeros_like(det_count), invK=inv_K.reshape(1, 9).contiguous().to(dev))
             b.det_in, b.count_in, b.inv_K, b.pose, b.group = det.data_ptr(), det_count.data_ptr(), work["invK"].data_ptr(), pose.data_ptr(), group.data_ptr()
             b.out_size, b.G, b.det_cap, b.num_classes = keep["out_size"].data_ptr(), 1, n, int(num_classes)
@@ -302,7 +302,7 @@ class NuscenesDD3DWithTTA(DD3DWithTTA):
         group = torch.tensor(group_of, dtype=torch.int32, device=dev)
         ncap = (G * cap + 63) // 64 * 64
         work = dict(work=torch.zeros((G * cap, 16), dtype=torch.float32, device=dev), sbox=torch.zeros((G * cap, 8), dtype=torch.float32, device=dev),
-                    mask=torch.zeros((ncap, ncap // 64), dtype=torch.int64, device=dev), meta=torch.zeros((4, ), dtype=torch.int32, device=dev),
+                    mask=torch.zeros((min(ncap, 8192), min(ncap, 8192) // 64), dtype=torch.int64, device=dev), meta=torch.zeros((4, ), dtype=torch.int32, device=dev),
                     det_out=torch.zeros_like(det_in), count_out=torch.zeros_like(count_in), out_size=torch.ones((G, 4), dtype=torch.float32, device=dev))
         b = hip.BevArgs()
         b.det_in, b.count_in, b.inv_K, b.pose, b.group = det_in.data_ptr(), count_in.data_ptr(), inv_K.data_ptr(), pose.data_ptr(), group.data_ptr()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DD3D_ABI_VERSION 5
+#define DD3D_ABI_VERSION 6
 
 #define DD3D_OK 0
 #define DD3D_E_INVALID (-1)  /* bad argument (shape / alignment / enum) */
@@ -156,6 +156,15 @@ typedef struct dd3d_conv_launch {  /* host memory */
  * watched launches stored a nonzero sampled maximum below `floor` (amax: [n_launches][16][32] floats, see dd3d_conv_launch.amax).  The
  * two words travel in a rank's record; after the all_gather every rank sees every rank's verdict and all act on the same step. */
 int dd3d_fold_range_flags(const int32_t* status, const float* amax, int32_t n_launches, float floor, int32_t* out, void* stream);
+/* What the host reads after a forward, packed into ONE contiguous run of 4-byte words so that a single asynchronous device-to-host
+ * copy (into pinned memory, enqueued behind the forward) replaces one blocking read per field -- the reference's forward ends by
+ * returning Instances (tridet/modeling/dd3d/core.py:153-164), which needs the detection counts on the host:
+ *   out[0] = *status (NULL: 0), out[1] = G, out[2] = n_launches, out[3] = n_flag_recs, out[4 .. 4 + G) = det_count[0 .. G),
+ *   then n_launches floats: max over the 16 sub-maxima of every watched launch (amax as in dd3d_conv_launch.amax),
+ *   then 2 * n_flag_recs words: flags[r * flag_stride + {0, 1}] (every rank's dd3d_fold_range_flags words inside the gathered records).
+ * `out` holds 4 + G + n_launches + 2 * n_flag_recs words.  One block; ordered on `stream` behind the forward's last launch. */
+int dd3d_pack_readback(const int32_t* det_count, int32_t G, const int32_t* status, const float* amax, int32_t n_launches,
+                       const int32_t* flags, int32_t n_flag_recs, int64_t flag_stride, int32_t* out, void* stream);
 /* planes per value of a math mode (0 for DD3D_MATH_F32) */
 int dd3d_math_planes(int32_t math_mode);
 
@@ -426,8 +435,9 @@ int dd3d_nms_finalize(const dd3d_nms_args* args, void* stream);
  *   max_dets: cap on the batch-global, score-ordered keep list (0 = none; the reference truncates the whole batch,
  *   postprocessing.py:93-94).  det_out / count_out: survivors per image in their original order, fields 22-28 = the
  *   global-frame box when write_global.  count_out = -1 everywhere if more than 8192 boxes arrive.
- * Workspaces (device): work float [G*det_cap][16], sbox float [G*det_cap][8], mask uint64 [ncap][ncap/64]
- *   (ncap = round_up(G*det_cap, 64)), meta int32 [4].
+ * Workspaces (device): work float [G*det_cap][16], sbox float [G*det_cap][8], mask uint64 [mcap][mcap/64]
+ *   (mcap = min(round_up(G*det_cap, 64), 8192): rows and columns are positions in the SORTED list, which never holds more than the
+ *   8192 boxes of the LDS sorter -- ABI 6; ABI 5 strode the rows by round_up(G*det_cap, 64)/64 words), meta int32 [4].
  * ------------------------------------------------------------------------------------------------ */
 typedef struct dd3d_bev_args {  /* host memory */
   const float* det_in;

@@ -3,6 +3,10 @@ reference's own DD3D, on CPU, on top of the third-party shims of ref_shims.py (d
 
     python tests/golden/make_tta_golden.py        ->  tests/golden/tta_dla34.npz            (toy scales, seconds)
     python tests/golden/make_tta_golden.py nusc   ->  tests/golden/tta_nusc_dla34.npz       (toy scales)
+    python tests/golden/make_tta_golden.py nusc full -> tests/golden/tta_nusc_dla34_scales.npz
+        the nuScenes experiment's own TTA (configs/experiments/dd3d_nusc_dla34.yaml:55-62: MIN_SIZES [640, 768, 896, 1024, 1152] x flip,
+        IMS_PER_BATCH 96) on one 6-camera sample of raw 900 x 1600 frames: per camera ten copies forwarded as ONE batch on a 1152 x 2048
+        canvas (nuscenes_dd3d_tta.py:21-178), then the sample-level aggregation (~10 min of CPU, ~25 GB)
     python tests/golden/make_tta_golden.py full   ->  tests/golden/tta_dla34_kitti_scales.npz
         the experiment's own TTA (configs/experiments/dd3d_kitti_dla34.yaml:44-53: MIN_SIZES [320, 384, 448, 512, 576] x flip, IMS_PER_BATCH 80)
         on one raw-KITTI-sized 370 x 1224 frame: ten augmented copies forwarded as ONE batch on a 640 x 1920 canvas (~2 min of CPU)
@@ -64,11 +68,23 @@ def nusc_tta_case():
     return [dict(x, intrinsics=K.clone(), height=100, width=178) for x in base]
 
 
-def nusc_main():
+# The nuScenes experiment as it is run: only what do_test flips (postprocess_in_inference = False, scripts/train.py:206-209) and the
+# input format; MIN_SIZES [640 .. 1152] x flip, IMS_PER_BATCH 96, thresholds and the per-sample cap are the experiment's.
+NUSC_FULL_TTA_OVERRIDES = {"DD3D": {"INFERENCE": {"DO_POSTPROCESS": False}}, "INPUT": {"FORMAT": "BGR"}}
+
+
+def nusc_full_tta_case():
+    """One 6-camera sample of raw nuScenes-sized 900 x 1600 frames with the CAM_FRONT intrinsics and the synthetic camera poses."""
+    from dd3d_amd.synthetic import NUSC_K, make_inputs
+    base = make_inputs(6, 900, 1600, dataset="nusc", seed=2100)
+    return [dict(x, intrinsics=torch.tensor(NUSC_K), height=900, width=1600) for x in base]
+
+
+def nusc_main(full=False):
     import dd3d_amd.modeling  # noqa: F401
     from dd3d_amd import META_ARCH_REGISTRY, get_cfg
     from dd3d_amd.synthetic import load_calib, make_state_dict
-    cfg = get_cfg("dd3d_nusc_dla34", _merge(TRAINING_ONLY_KEYS, NUSC_TTA_OVERRIDES))
+    cfg = get_cfg("dd3d_nusc_dla34", _merge(TRAINING_ONLY_KEYS, NUSC_FULL_TTA_OVERRIDES if full else NUSC_TTA_OVERRIDES))
     sd = make_state_dict(META_ARCH_REGISTRY.get("NuscenesDD3D")(cfg), calib=load_calib("dla34_nusc"))
     ref_shims.install()
     for pkg in ("tridet.data", "tridet.data.augmentations"):
@@ -83,12 +99,32 @@ def nusc_main():
     ref = NuscenesDD3D(cfg)
     ref.load_state_dict(sd, strict=True)
     ref.eval()
-    xs = nusc_tta_case()
+    xs = nusc_full_tta_case() if full else nusc_tta_case()
     for x in xs:
         x["pose"] = RefPose(wxyz=x["pose"].quat.elements, tvec=x["pose"].tvec)
-    with torch.no_grad():
-        res = NuscenesDD3DWithTTA(cfg, ref)(xs)
+    import time
+    t0 = time.perf_counter()
     out = {}
+    with torch.no_grad():
+        wrapper = NuscenesDD3DWithTTA(cfg, ref)
+        if full:  # what went INTO the per-camera merge: the augmented copies' shapes and detection counts (the wrapper's own mapper / _batch_inference)
+            aug = wrapper.tta_mapper(dict(xs[0]))
+            out["copy_shapes"] = np.array([tuple(a["image"].shape[1:]) for a in aug])
+            out["batch_size"] = np.array(wrapper.batch_size)
+            merged_per_image = []
+            inner = wrapper._inference_one_image
+
+            def _counting(x, inner=inner):
+                r = inner(x)
+                merged_per_image.append(len(r))
+                print(f"  camera {len(merged_per_image) - 1}: {len(r)} merged detections, {time.perf_counter() - t0:.0f} s", flush=True)
+                return r
+
+            wrapper._inference_one_image = _counting
+        res = wrapper(xs)
+        if full:
+            out["merged_per_image"] = np.array(merged_per_image)
+    print(f"reference NuscenesDD3DWithTTA: {time.perf_counter() - t0:.1f} s")
     for i, r in enumerate(res):
         inst = r["instances"]
         out[f"n{i}"] = np.array(len(inst))
@@ -97,7 +133,7 @@ def nusc_main():
         out[f"boxes{i}"], out[f"scores_3d{i}"] = inst.pred_boxes.tensor.numpy(), inst.scores_3d.numpy()
         out[f"classes{i}"], out[f"attributes{i}"], out[f"speeds{i}"] = inst.pred_classes.numpy(), inst.pred_attributes.numpy(), inst.pred_speeds.numpy()
         out[f"vectorize{i}"], out[f"global{i}"] = inst.pred_boxes3d.vectorize().numpy(), inst.pred_boxes3d_global.vectorize().numpy()
-    path = os.path.join(HERE, "tta_nusc_dla34.npz")
+    path = os.path.join(HERE, "tta_nusc_dla34_scales.npz" if full else "tta_nusc_dla34.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, [int(out[f"n{i}"]) for i in range(len(res))])
 
@@ -146,6 +182,6 @@ def main(full=False):
 
 if __name__ == "__main__":
     if "nusc" in sys.argv[1:]:
-        nusc_main()
+        nusc_main(full="full" in sys.argv[1:])
     else:
         main(full="full" in sys.argv[1:])

@@ -6,7 +6,8 @@ bench times (outside the clock): the quantities are the reference's own -- Gener
 vectorised box [quat | tvec | size] (boxes3d.py:142-144) -- evaluated on the HIP detections and on the oracle's for the same uint8 image.
 
   int_mismatches   detections whose integer fields (class, FPN level, location) differ from the oracle's at the same rank -- bar: 0,
-                   unless every differing candidate sits ON a selection cut (on_cut_flips, see tests/util.py::candidate_margins)
+                   unless every differing candidate sits ON a selection cut (on_cut_flips, see tests/util.py::candidate_margins) or the
+                   difference is a swap of two detections whose oracle scores tie within SWAP_GAP_REL (rank_swaps, rank_swap_gap_rel_max)
   box3d_l1         mean |[tvec | size] difference| over the matched detections (metres), and the same relative to mean |[tvec | size]|
   corners_l1       mean |corner difference| over the 8 corners of the matched boxes (metres), and relative
   depth / size / box2d / score relative errors: the north star's "floats within 1e-3 rel"
@@ -15,6 +16,7 @@ import torch
 
 REL_TOL = 1e-3     # north star: box / depth floats within 1e-3 relative
 MARGIN_EPS = 2e-6  # |oracle score - cut| of a candidate only one side selected
+SWAP_GAP_REL = 1e-4  # two detections may change places in the score-ordered result only over an oracle score gap below this (relative)
 
 
 def _key(levels, locs, classes):
@@ -28,9 +30,10 @@ def _rel(a, b, floor=1e-3):
     return float(((a - b).abs() / den).max())
 
 
-def parity_report(out, ref, plan=None, stages=None, cfg=None, image=0):
+def parity_report(out, ref, plan=None, stages=None, cfg=None, image=0, ref_image=None):
     """`out`: {"instances": Instances} of the HIP path; `ref`: the oracle's result dict of the same image; `plan` + `stages` (oracle) + `cfg`:
-    also count the candidates only one side selected and how far from a selection cut the oracle's score of each sits."""
+    also count the candidates only one side selected and how far from a selection cut the oracle's score of each sits (`image`: its
+    position in the plan, `ref_image`: in the oracle's batch, default the same)."""
     from oracle import dd3d_oracle as O
     o = out["instances"]
     n_hip, n_ref = len(o), len(ref["scores"])
@@ -42,11 +45,20 @@ def parity_report(out, ref, plan=None, stages=None, cfg=None, image=0):
     pos = {k: i for i, k in enumerate(kr)}
     pairs = [(i, pos[k]) for i, k in enumerate(ko) if k in pos]
     rep["matched"] = len(pairs)
+    # Rank swaps: matched detections that sit at another rank than the oracle's.  The final list is ordered by score, the two sides' scores
+    # agree to ~1e-5 relative, so two detections whose ORACLE scores are closer than that may legitimately change places; the report
+    # carries the largest oracle score gap such a swap jumped over (bar: SWAP_GAP_REL).
+    swaps = [(i, j) for i, j in pairs if i != j]
+    rep["rank_swaps"] = len(swaps)
+    if swaps:
+        key = ref["scores_3d"] if ("scores_3d" in ref and bool((ref["scores_3d"][:-1] >= ref["scores_3d"][1:]).all())) else ref["scores"]
+        rep["rank_swap_gap_rel_max"] = max(abs(float(key[min(i, n_ref - 1)]) - float(key[j])) / max(abs(float(key[j])), 1e-30) for i, j in swaps)
     if pairs:
         ih = torch.tensor([p[0] for p in pairs])
         ir = torch.tensor([p[1] for p in pairs])
         has3d = "pred_boxes3d" in ref and o.has("pred_boxes3d")
         rep["box2d_abs_max"] = float((o.pred_boxes.tensor.cpu()[ih] - ref["pred_boxes"][ir]).abs().max())
+        rep["box2d_rel_max"] = _rel(o.pred_boxes.tensor.cpu()[ih], ref["pred_boxes"][ir])
         rep["score_rel_max"] = _rel(o.scores.cpu()[ih], ref["scores"][ir])
         if has3d:
             b = {k: v[ir] for k, v in ref["pred_boxes3d"].items()}
@@ -69,7 +81,7 @@ def parity_report(out, ref, plan=None, stages=None, cfg=None, image=0):
             rep["score3d_rel_max"] = _rel(o.scores_3d.cpu()[ih], ref["scores_3d"][ir])
     if plan is not None and stages is not None and cfg is not None:
         from tests.util import candidate_margins
-        nh, nr, margins = candidate_margins(plan, stages, cfg, image)
+        nh, nr, margins = candidate_margins(plan, stages, cfg, image, ref_image)
         rep["candidates_hip"], rep["candidates_oracle"] = nh, nr
         rep["on_cut_flips"] = sum(m <= MARGIN_EPS for m in margins)
         rep["off_cut_flips"] = sum(m > MARGIN_EPS for m in margins)
@@ -84,10 +96,20 @@ def parity_pass(rep):
     flips = rep.get("on_cut_flips", 0) + rep.get("off_cut_flips", 0)
     if rep.get("off_cut_flips", 0):
         return False
-    if flips == 0 and (rep["int_mismatches"] or rep["detections_hip"] != rep["detections_oracle"]):
-        return False  # nothing sat on a cut: the integer fields must be identical
+    if flips == 0:
+        # nothing sat on a cut: the same detections with the same integer fields -- at the same ranks, except where two of them tie
+        # within the float tolerance of the scores (rank_swaps, each over an oracle score gap <= SWAP_GAP_REL)
+        if rep["detections_hip"] != rep["detections_oracle"] or rep.get("matched", 0) != rep["detections_oracle"]:
+            return False
+        if rep["int_mismatches"] and (rep["int_mismatches"] != rep.get("rank_swaps", 0) or rep.get("rank_swap_gap_rel_max", 0.0) > SWAP_GAP_REL):
+            return False
+    # The float bars only say something about MATCHED detections: a report in which (nearly) nothing matched must not pass on the
+    # absence of numbers (round-5 advisor).  A candidate flipped on a cut can add / remove / displace at most a detection or two.
+    if rep.get("matched", 0) < min(rep["detections_hip"], rep["detections_oracle"]) - 2 * flips:
+        return False
     ok = True
-    for k in ("box3d_l1_tvec_size_rel", "corners_l1_rel", "depth_rel_max", "size_rel_max", "score_rel_max", "score3d_rel_max", "quat_abs_max_up_to_sign"):
+    for k in ("box3d_l1_tvec_size_rel", "corners_l1_rel", "depth_rel_max", "size_rel_max", "score_rel_max", "score3d_rel_max", "quat_abs_max_up_to_sign",
+              "box2d_rel_max"):
         if k in rep:
             ok = ok and rep[k] <= REL_TOL
     return bool(ok)

@@ -51,6 +51,61 @@ def test_v99_kitti_bs16_full_size_matches_oracle(hiplib):
 
 
 @pytest.mark.timeout(900)
+def test_dla34_kitti_four_image_plan_matches_oracle(hiplib):
+    """The launch plan bench.py's `value` is measured on (round-5 verdict): DD3D-DLA34 384x1280 with FOUR images per launch -- the
+    4-image entries of the shipped tile table (the 8-wave 256 x 256 tower tile, the split-K choices of the backbone) -- on four DIFFERENT
+    images (one of raw KITTI size inside the padded batch), captured as a hipGraph like a pipeline slot's: backbone features and every head
+    map vs the oracle, candidate flips only ON a selection cut, then -- on identical head maps -- integer exactness and <= 1e-3 relative
+    floats of the final detections; and end to end through `PipelinedForward(microbatch=4)` (four single-image requests sharing one plan),
+    whose results must equal the one-plan forward's bit for bit."""
+    from dd3d_amd.parallel import PipelinedForward
+    from dd3d_amd.synthetic import make_inputs
+    from tests.parity import parity_report
+    cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti")
+    model = gpu_model(cfg, sd, use_graph=True)
+    B = 4
+    inputs = [make_inputs(1, 384, 1280, seed=1000 + j)[0] for j in range(B)]  # (the bench's request images)
+    inputs[2]["image"] = inputs[2]["image"][:, :370, :1224].contiguous()
+    inputs[2]["height"], inputs[2]["width"] = 370, 1224
+    ref, st = _oracle(cfg, sd, inputs)
+    plan, image_sizes = model.stage_inputs(inputs)
+    assert (plan.B, plan.Hp, plan.Wp) == (4, 384, 1280) and plan.graph is not None
+    towers = [op for op in plan.ops if op.name.startswith("towers.")]
+    assert towers and all(op.info["tile_name"] == "256x256w8" for op in towers), [op.info["tile_name"] for op in towers]
+    plan.run()
+    torch.cuda.synchronize()
+    plan.check_status()
+    C = cfg.DD3D.NUM_CLASSES
+    for k, v in st["bottom_up"].items():
+        assert max_abs(plan.bottom_up[k].nchw(), v) < 1e-4 * max(1.0, float(v.abs().max())), k
+    _check_head_maps(plan, st, C)
+    out_e2e = model.collect(plan, inputs, image_sizes)
+    flips = 0
+    for i in range(B):
+        rep = parity_report(out_e2e[i], ref[i], plan=plan, stages=st, cfg=cfg, image=i)
+        assert rep["off_cut_flips"] == 0 and rep["pass"], (i, rep)
+        flips += rep["on_cut_flips"]
+    print(f"[margin] DLA-34 four-image plan: {sum(len(c['scores']) for c in st['candidates'])} oracle candidates, {flips} on-the-cut flips")
+    # four single-image requests through one pipeline slot: the same plan geometry, the same detections
+    runner = PipelinedForward(model, 1, 384, 1280, depth=2, compute_streams=2, microbatch=4)
+    assert towers[0].info["tile_name"] == [op for op in runner.plan.ops if op.name.startswith("towers.")][0].info["tile_name"]
+    handles = [runner.submit([x]) for x in inputs]  # (the raw-KITTI-sized frame lands on the plan's 384 x 1280 canvas like in the batch above)
+    for i, h in enumerate(handles):
+        o = runner.result(h)[0]["instances"]
+        e = out_e2e[i]["instances"]
+        assert tuple(o.image_size) == tuple(e.image_size)
+        assert len(o) == len(e) and torch.equal(o.pred_boxes.tensor, e.pred_boxes.tensor) and torch.equal(o.scores_3d, e.scores_3d)
+        assert torch.equal(o.pred_classes, e.pred_classes) and torch.equal(o.pred_boxes3d.depth, e.pred_boxes3d.depth)
+    # identical head maps -> identical integers, floats within 1e-3
+    oracle_heads_to_plan(plan, st, C)
+    plan.launch(first=plan.num_pre_nms_ops - 1)
+    torch.cuda.synchronize()
+    out = model.collect(plan, inputs, image_sizes)
+    for i in range(B):
+        _check_final(out[i], ref[i])
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("name", ["dla34_kitti_384x1280_b1_dets", "v99_kitti_384x1280_b1_dets", "dla34_nusc_896x1600_b6_dets",
                                   "v99_nusc_896x1600_b6_dets"])
 def test_full_size_detections_match_the_reference_itself(hiplib, name):

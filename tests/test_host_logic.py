@@ -178,7 +178,7 @@ def test_cabi_exports_match_header(hiplib):
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert getattr(hiplib, name) is not None
-    assert hiplib.dd3d_abi_version() == hip.ABI_VERSION == 5 and hiplib.dd3d_arch() == b"gfx950"
+    assert hiplib.dd3d_abi_version() == hip.ABI_VERSION == 6 and hiplib.dd3d_arch() == b"gfx950"
     # the product library is built with no -DDD3D_... knob (csrc/build_flags.h); hip.lib() refuses one that was, unless chosen explicitly
     assert hiplib.dd3d_build_flags() == b"" and hip.build_flags() == ""
     import ctypes as C
@@ -484,12 +484,20 @@ def test_collect_reports_a_bev_sorter_overflow(kitti_dla34):
     detections then (round 2 silently relied on a build-time capacity check instead)."""
     import torch
     cfg, model, sd = kitti_dla34
-    fake = type("P", (), dict(det_count=torch.tensor([-1, -1], dtype=torch.int32), det_cap=256, check_status=lambda self: None))()
+    from types import SimpleNamespace
+
+    def plan_with(counts):  # what DD3D._counts reads of a plan: the forward's read-back record (engine.PlanBase.readback) and det_cap
+        rb = SimpleNamespace(status=0, counts=torch.tensor(counts, dtype=torch.int32), amax=torch.zeros(0), flags=torch.zeros((0, 2), dtype=torch.int32))
+        seen = []
+        return type("P", (), dict(det_cap=256, readback=lambda self: rb, check_status=lambda self, r=None: seen.append(r)))(), rb, seen
+
+    fake, _, _ = plan_with([-1, -1])
     with pytest.raises(RuntimeError, match="8192 detections"):
         model._counts(fake)
-    ok = type("P", (), dict(det_count=torch.tensor([3, 7], dtype=torch.int32), det_cap=256, check_status=lambda self: None))()
+    ok, rb, seen = plan_with([3, 7])
     counts, n_max = model._counts(ok)
     assert counts.tolist() == [3, 7] and n_max == 7
+    assert seen == [rb]  # the numeric verdict is read from the same record: nothing else is fetched from the device
 
 
 @pytest.mark.parametrize("cin,cin_p,k,n", [(3, 4, 7, 16), (16, 16, 3, 16), (16, 16, 3, 32)])

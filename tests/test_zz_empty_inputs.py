@@ -9,6 +9,13 @@ import torch
 EMPTY = {"DD3D": {"FCOS2D": {"INFERENCE": {"PRE_NMS_THRESH": 0.9999}}}}
 
 
+def _host_plan(det_count, **fields):
+    """What DD3D.collect reads of a plan, on the host: the detection buffer, K^-1 and the forward's read-back record
+    (engine.PlanBase.readback: counts + status words in one copy)."""
+    rb = types.SimpleNamespace(status=0, counts=det_count, amax=torch.zeros(0), flags=torch.zeros((0, 2), dtype=torch.int32))
+    return types.SimpleNamespace(det_count=det_count, readback=lambda: rb, check_status=lambda rb=None: None, **fields)
+
+
 def test_oracle_returns_empty_results():
     from dd3d_amd.synthetic import make_inputs
     from oracle import dd3d_oracle as O
@@ -28,8 +35,8 @@ def test_collect_of_an_empty_detection_buffer(kitti_dla34):
     from dd3d_amd.synthetic import make_inputs
     _, model, _ = kitti_dla34
     B, cap = 2, 8
-    plan = types.SimpleNamespace(det_count=torch.zeros(B, dtype=torch.int32), det_cap=cap, det=torch.zeros(B, cap, hip.DET_FIELDS),
-                                 inv_K=torch.eye(3).reshape(1, 9).repeat(B, 1), has_global_boxes=False)
+    plan = _host_plan(torch.zeros(B, dtype=torch.int32), det_cap=cap, det=torch.zeros(B, cap, hip.DET_FIELDS),
+                      inv_K=torch.eye(3).reshape(1, 9).repeat(B, 1), has_global_boxes=False)
     inputs = make_inputs(B, 128, 256, out_hw=(99, 201))
     out = model.collect(plan, inputs, [(128, 256)] * B)
     for o in out:
@@ -67,8 +74,8 @@ def test_collect_does_not_alias_the_detection_buffer(kitti_dla34):
     _, model, _ = kitti_dla34
     B, cap = 2, 8
     det = torch.arange(B * cap * hip.DET_FIELDS, dtype=torch.float32).reshape(B, cap, hip.DET_FIELDS)
-    plan = types.SimpleNamespace(det_count=torch.tensor([1, 3], dtype=torch.int32), det_cap=cap, det=det,
-                                 inv_K=torch.eye(3).reshape(1, 9).repeat(B, 1), has_global_boxes=False)
+    plan = _host_plan(torch.tensor([1, 3], dtype=torch.int32), det_cap=cap, det=det,
+                      inv_K=torch.eye(3).reshape(1, 9).repeat(B, 1), has_global_boxes=False)
     inputs = make_inputs(B, 128, 256)
     out = model.collect(plan, inputs, [(128, 256)] * B)
     snap = [(o["instances"].pred_boxes.tensor.clone(), o["instances"].scores.clone(), o["instances"].scores_3d.clone(),

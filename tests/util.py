@@ -82,8 +82,9 @@ def candidates_from_plan(plan, b=0):
     )
 
 
-def candidate_margins(plan, st, cfg, b=0):
-    """End-to-end candidate membership of image b: HIP (plan.cand, from its own head maps) vs oracle (st).  Selection is a hard
+def candidate_margins(plan, st, cfg, b=0, ref_b=None):
+    """End-to-end candidate membership of image b: HIP (plan.cand, from its own head maps) vs oracle (st; image `ref_b` of the oracle's
+    batch, default b -- the bench compares position j of a slot's plan with a one-image oracle forward).  Selection is a hard
     threshold on sigma(cls)*sigma(ctr) (fcos2d.py:280-283) followed by a per-level top-k (fcos2d.py:309-317), so a ~1e-7 relative
     difference in a logit may flip a candidate that sits ON a cut.  Returns (n_hip, n_ref, margins): `margins` holds, for every
     candidate only one side selected, the distance of the ORACLE's score from the cut that decided it (PRE_NMS_THRESH, or the
@@ -91,6 +92,7 @@ def candidate_margins(plan, st, cfg, b=0):
     inf = cfg.DD3D.FCOS2D.INFERENCE
     C, topk, thr = int(cfg.DD3D.NUM_CLASSES), int(inf.PRE_NMS_TOPK), float(inf.PRE_NMS_THRESH)
     c = candidates_from_plan(plan, b)
+    b = b if ref_b is None else ref_b  # (from here on: the oracle's image)
     hip_keys = set(zip(c["fpn_levels"].tolist(), c["flat_index"].tolist()))
     ref_keys, margins = set(), []
     dense = []
