@@ -361,7 +361,9 @@ def main():
                 traffic = None
         np_ = hip.MATH_PLANES[plan.math]
         m_rows = towers[0].info["M"]
-        alg_bytes = (m_rows * 256 * 2 * np_ * 2 + 3 * 2304 * 256 * 2 * np_) if plan.use_planes else None  # planes in + planes out + split filters
+        layers = len(getattr(towers[0], "parts", None) or [0])  # (a chain launch covers all four tower layers: dd3d_conv_launch.chain)
+        m_rows = m_rows // layers
+        alg_bytes = (m_rows * 256 * 2 * np_ * 2 + 3 * 2304 * 256 * 2 * np_) * layers if plan.use_planes else None  # per layer: planes in + planes out + split filters
         # What the matrix pipe sustains on REAL operand bits (dd3d_tools_mfma_probe, timed here; stand-alone: tests/tools/src/mfma_power_bench.hip,
         # profiles/r03_mfma_power_bench.txt, r03l_*): the same v_mfma_f32_32x32x16_f16 stream from registers, no memory traffic, reaches
         # 2.45 PFLOP/s on zeros / constants and 1.45-1.77 PFLOP/s (chip and thermal state) on the two-half-term planes of gaussian data
@@ -371,7 +373,8 @@ def main():
         except Exception:  # (a library without the probe: nothing was measured in this run, and nothing is reported as if it had been)
             measured_mfma_ceiling_tflops = None
         out["roofline"] = {
-            "kernel": kname + " (head towers, 15 segments / launch)", "bound": "mfma",
+            "kernel": kname + (f" (head towers: {layers} layers x 15 segments in ONE chain launch)" if layers > 1 else " (head towers, 15 segments / launch)"), "bound": "mfma",
+            "tower_layers_per_launch": layers,
             "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "peak_basis": ("157.3 TFLOP/s dense f32-input MFMA" if math_name == "f32" else
                            f"2500 TFLOP/s dense 16-bit MFMA / {PRODUCTS[math_name]} matrix products per f32 product ({math_name}); f32-equivalent FLOP/s. "
@@ -529,7 +532,7 @@ def e2e_leg(model, runner, args, pinned=True):
             for x in req:
                 x["image"] = x["image"].pin_memory()
     lag = max(1, (depth - 1) * mb)  # (the largest lag the runner allows: a slot's results must be taken before the slot is filled again)
-    host = {"stage": 0.0, "collect": 0.0}
+    host = {"stage": 0.0, "collect": 0.0, "submit": 0.0, "result": 0.0}
     stage_inputs, collect = model.stage_inputs, model.collect
 
     def timed(name, fn):
@@ -544,17 +547,19 @@ def e2e_leg(model, runner, args, pinned=True):
     try:
         def run(n):
             q, ndet = deque(), 0
+            submit, result = timed("submit", runner.submit), timed("result", runner.result)
             for i in range(n):
-                q.append(runner.submit(pool[i % n_pool]))
+                q.append(submit(pool[i % n_pool]))
                 if len(q) > lag:
-                    ndet += sum(len(o["instances"]) for o in runner.result(q.popleft()))
+                    ndet += sum(len(o["instances"]) for o in result(q.popleft()))
             while q:
-                ndet += sum(len(o["instances"]) for o in runner.result(q.popleft()))
+                ndet += sum(len(o["instances"]) for o in result(q.popleft()))
             return ndet
 
         run(2 * depth * mb)  # warm-up: every slot twice
         torch.cuda.synchronize()
-        host["stage"] = host["collect"] = 0.0
+        for k in host:
+            host[k] = 0.0
         n = max(args.e2e_requests // mb, 1) * mb
         t0 = time.perf_counter()
         ndet = run(n)
@@ -564,6 +569,10 @@ def e2e_leg(model, runner, args, pinned=True):
         model.stage_inputs, model.collect = stage_inputs, collect
     return {"images_per_s": round(n * B / dt, 2), "ms_per_request": round(dt / n * 1e3, 4), "requests": n, "detections_returned": ndet,
             "host_us_per_request_stage_inputs": round(host["stage"] / n * 1e6, 1), "host_us_per_request_collect": round(host["collect"] / n * 1e6, 1),
+            # submit() = stage_inputs + slot bookkeeping + (every microbatch-th request) the slot's graph launches; result() = waiting for the
+            # slot's post half + collect: what is left of a request's wall time after these two is the loop itself
+            "host_us_per_request_submit": round(host["submit"] / n * 1e6, 1), "host_us_per_request_result": round(host["result"] / n * 1e6, 1),
+            "host_us_per_request_waiting_for_gpu": round((host["result"] - host["collect"]) / n * 1e6, 1),
             "source": "pinned host memory" if pinned else "pageable host memory", "collect_lag_requests": lag,
             "covers": "H2D of a distinct uint8 image per request + stage_inputs + the slot's hipGraphs + collect -> Instances (core.py:65 ... :153-164)"}
 

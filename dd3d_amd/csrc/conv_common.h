@@ -36,6 +36,12 @@ struct ConvKArgs {
   float out_plane_scale;  // F16X2: split-plane outputs hold value * this (power of two)
   int* status;            // OR-ed with DD3D_STATUS_* bits, or null
   float* amax;            // F16X2: atomic max of |stored plane value| (scaled), or null
+  // Dependent segments in ONE launch (dd3d_conv_launch.chain; conv_planes_row.hip, CHAIN instantiations): chain_sync[0] counts the
+  // blocks that have finished a tile, chain_sync[1 + mt] the finished n-tiles of m-tile mt (index into tiles[]); all zero between
+  // launches (the last finisher clears them).  seg_tile0[i] = index in tiles[] of segment i's first m-tile (device).
+  int chain;
+  int* chain_sync;
+  const int* seg_tile0;
   dd3d_conv_seg seg0;
 };
 
@@ -88,11 +94,11 @@ __device__ __forceinline__ f32x4 ld_sc1(const float* p) {
 
 // returns true when this block has to finish the tile (acc then holds the full sum)
 template <int TM, int TN, int NT = 256>
-__device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int tile_id, int tid) {
+__device__ __forceinline__ bool splitk_exchange(const ConvKArgs& a, f32x16 (&acc)[TM][TN], int tile_id, int tid, int kslice) {
   constexpr int Q = TM * TN * 4;  // 16-byte quads per thread
   constexpr int QS = NT * 4;      // floats between consecutive quads of one thread
   const long slab = (long)a.ntiles * a.nn * Q * QS;  // floats per slice
-  float* mine = a.ws + (long)blockIdx.y * slab + ((long)tile_id * Q * NT + tid) * 4;
+  float* mine = a.ws + (long)kslice * slab + ((long)tile_id * Q * NT + tid) * 4;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -321,6 +327,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const dd3d_con
 __device__ __forceinline__ int chan_of_row(int rho) { return ((rho >> 2) & 1) * 16 + (rho >> 3) * 4 + (rho & 3); }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// agent-coherent 16-byte accesses of the in-launch hand-over between dependent segments (same forms as the split-K exchange above)
+__device__ __forceinline__ void st_sc1_u4(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u32x4 ld_sc1_u4(const void* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
 typedef const u32x4 __attribute__((address_space(1))) * gcu4p;
 typedef u32x4 __attribute__((address_space(1))) * gu4p;
 typedef f32x4 __attribute__((address_space(1))) * gf4p;
@@ -385,7 +398,9 @@ __device__ __forceinline__ void unpack_terms(const u32x4 (&w)[Planes<MODE>::NP][
 template <int TM, int TN, int WM, int WN>
 constexpr bool epi_residual_ok() { return !(TM * TN >= 8 && WM * WN >= 8); }
 
-template <int TM, int TN, int MODE, int WM, int WN>
+// CHAIN: the launch holds dependent segments (ConvKArgs.chain) -- plane stores are write-through (sc1) and a split-plane residual is read
+// with sc1 loads, so that blocks on other XCDs (their L2s are not coherent with this one's) see / read what memory holds.
+template <int TM, int TN, int MODE, int WM, int WN, bool CHAIN = false>
 __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
                                                 int wn, int lane, const unsigned char* evec, unsigned char* scratch) {
   constexpr int NP = Planes<MODE>::NP;
@@ -454,7 +469,22 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-              for (int q = 0; q < 2; ++q) raw[ii][2 * pl + q] = mv ? *(gcu4p)(p + pl * 64 + q * 16) : u32x4{0u, 0u, 0u, 0u};
+              for (int q = 0; q < 2; ++q) {
+                if constexpr (CHAIN) raw[ii][2 * pl + q] = ld_sc1_u4((const void*)(p + pl * 64 + q * 16));  // (row 0 when m >= M: read, never used)
+                else raw[ii][2 * pl + q] = mv ? *(gcu4p)(p + pl * 64 + q * 16) : u32x4{0u, 0u, 0u, 0u};
+              }
+          }
+          if constexpr (CHAIN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ii = 0; ii < IG; ++ii) {
+              const bool mv = mbase + (i0 + ii) * 32 < s.M;
+#pragma unroll
+              for (int k = 0; k < 2 * NP; ++k) {
+                asm volatile("" : "+v"(raw[ii][k]));  // uses below depend on the wait above
+                if (!mv) raw[ii][k] = u32x4{0u, 0u, 0u, 0u};
+              }
+            }
           }
         }
       }
@@ -534,14 +564,22 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
               const int pp = U / UP, u = U - pp * UP;
               const int us = NP == 2 ? (u ^ (pp & 7)) : ((u & ~3) + ((u & 3) ^ (pp & 3)));
               const u32x4 val = *reinterpret_cast<const u32x4*>(scratch + (pp * UP + us) * 16);
-              if (mblk + pp < s.M) *(gu4p)(dst + (long)U * 16) = val;
+              if (mblk + pp < s.M) {
+                if constexpr (CHAIN) st_sc1_u4((void*)(dst + (long)U * 16), val);
+                else *(gu4p)(dst + (long)U * 16) = val;
+              }
             }
           } else if (mv) {
             const gbp dst = (gbp)s.out_planes + (long)(nb >> 5) * cstride + (long)m * (NP * 64) + h * 32;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-              *(gu4p)(dst + p * 64) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
-              *(gu4p)(dst + p * 64 + 16) = u32x4{w[4][p], w[5][p], w[6][p], w[7][p]};
+              if constexpr (CHAIN) {
+                st_sc1_u4((void*)(dst + p * 64), u32x4{w[0][p], w[1][p], w[2][p], w[3][p]});
+                st_sc1_u4((void*)(dst + p * 64 + 16), u32x4{w[4][p], w[5][p], w[6][p], w[7][p]});
+              } else {
+                *(gu4p)(dst + p * 64) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
+                *(gu4p)(dst + p * 64 + 16) = u32x4{w[4][p], w[5][p], w[6][p], w[7][p]};
+              }
             }
           }
         }

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a) 
   }
 
   if constexpr (SK) {  // separate instantiation: the exchange must not cost the plain kernel registers
-    if (!splitk_exchange<TM, TN>(a, acc, bid, tid)) return;
+    if (!splitk_exchange<TM, TN>(a, acc, bid, tid, blockIdx.y)) return;
   }
   conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
 }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256 * WK) void conv_igemm_f32_dma_kernel(const Conv
 
   // (WK == 2: the kg == 1 waves have exited, tid < 256 here)
   if constexpr (SK) {  // separate instantiation: the exchange must not cost the plain kernel registers
-    if (!splitk_exchange<TM, TN>(a, acc, bid, tid)) return;
+    if (!splitk_exchange<TM, TN>(a, acc, bid, tid, blockIdx.y)) return;
   }
   conv_epilogue<TM, TN>(a, s, acc, m0, n0, wm, wn, lane);
 }
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(const C
   }
 
   if constexpr (SK) {
-    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
+    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid, blockIdx.y)) return;
   }
   conv_epilogue<TM, TN, DD3D_MATH_BF16X3, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);  // f32 NHWC and / or split planes for the next conv
 }
@@ -903,6 +903,26 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
   ka.out_plane_scale = L->out_plane_scale > 0.f ? L->out_plane_scale : 1.f;
   ka.status = L->status;
   ka.amax = L->amax;
+  ka.chain = L->chain ? 1 : 0;
+  ka.chain_sync = L->chain_sync;
+  ka.seg_tile0 = L->chain_tile0;
+  if (L->chain) {
+    DD3D_REQUIRE(L->chain_sync && L->chain_tile0 && L->seg0_host && L->nsegs >= 2 && L->in_planes && L->KH == 3 && L->KW == 3 && L->stride == 1 && L->pad == 1,
+                 "dd3d_conv2d_igemm_f32: a chain launch needs chain_sync, chain_tile0, seg0_host, >= 2 segments and 3x3 / stride 1 / pad 1 on split-plane input");
+    for (int i = 0; i < L->nsegs; ++i) {
+      const dd3d_conv_seg& sg = L->seg0_host[i];
+      DD3D_REQUIRE(sg.Ho == sg.H && sg.Wo == sg.W && sg.M == sg.B * sg.H * sg.W, "dd3d_conv2d_igemm_f32: chain segment %d is not a same-size convolution", i);
+      DD3D_REQUIRE(sg.out == nullptr && sg.out_planes != nullptr && (sg.res_mode == 0 || sg.res_mode == 2) && sg.n_limit == 0,
+                   "dd3d_conv2d_igemm_f32: chain segment %d: split-plane outputs only, res_mode 0 or 2, no n_limit", i);
+      DD3D_REQUIRE(sg.reserved >= 0 && sg.reserved <= i, "dd3d_conv2d_igemm_f32: chain segment %d names producer %d (must be an earlier segment)", i,
+                   sg.reserved - 1);
+      if (sg.reserved > 0) {
+        const dd3d_conv_seg& pr = L->seg0_host[sg.reserved - 1];
+        DD3D_REQUIRE(pr.B == sg.B && pr.H == sg.H && pr.W == sg.W && pr.out_planes == sg.in_planes,
+                     "dd3d_conv2d_igemm_f32: chain segment %d does not read what its producer %d writes (geometry / in_planes)", i, sg.reserved - 1);
+      }
+    }
+  }
   if (L->seg0_host != nullptr) {  // a host copy of the descriptors: every segment's residual contract is checked (without one the caller vouches)
     for (int i = 0; i < L->nsegs; ++i) {
       const dd3d_conv_seg& sg = L->seg0_host[i];
@@ -926,6 +946,7 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
     // 3x3 / stride 1: the three taps of a filter row share one A stage (conv_planes_row.hip); DD3D_CONV_ROW=0 keeps the per-tap gather
     const int use_row = env_int("DD3D_CONV_ROW", 1);  // (read per call: the tests drive both kernels in one process)
     if (use_row && conv_planes_row_applicable(ka)) return launch_conv_planes_row(ka, L->math_mode, L->tile_cfg, st);
+    DD3D_REQUIRE(!L->chain, "dd3d_conv2d_igemm_f32: a chain launch runs on the row-shared kernels only (K slices must start on a filter row; DD3D_CONV_ROW=0 disables them)");
     return launch_conv_planes(ka, L->math_mode, L->tile_cfg, st);
   }
   DD3D_REQUIRE(L->math_mode == DD3D_MATH_F32 || L->math_mode == DD3D_MATH_BF16X3,

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_planes_kernel(
   }
 
   if constexpr (SK) {
-    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
+    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid, blockIdx.y)) return;
   }
 #if DD3D_EPI_T
 #if DD3D_EPI_LDS

@@ -36,7 +36,21 @@ DD3D_NOTE_BUILD_FLAGS
 
 namespace dd3d {
 
-template <int TM, int TN, int WM, int WN, int NSB, int MODE, bool SK, int NSA>
+// CHAIN (dd3d_conv_launch.chain): the launch's segments DEPEND on each other -- segment i reads, as its input (and possibly as its
+// residual), what segments < i of the same launch write: the stride-1 3 x 3 convolutions of a DLA level (dla.py:50-62, conv1 -> conv2 +
+// residual -> the next block's conv1 ...) become ONE launch instead of one per convolution.  Blocks take their items
+// in launch order -- item = blockIdx.x = (m-tile, n-tile, K slice), slice fastest, the m-tiles in tiles[] order = dependency order, no
+// XCD remap -- so a block's producers always have LOWER block indices.  A block streams its filter stages first, then waits (one lane
+// polling, everybody else parked at the barrier) until the producer segment's m-tiles that cover its input rows have all their n-tiles
+// finished (chain_sync), and only then issues its activation stages.  The hand-over crosses XCDs whose L2s are not coherent: producers
+// store their planes write-through (sc1), wait for the acknowledgements (vmcnt(0)) and only then count their arrival with an agent-scope
+// atomic; consumers read activations (LDS-DMA, aux = sc1) and residual planes with sc1 loads (MI355X_MICROARCH.md, inter-workgroup
+// visibility: "16 B sc1 stores AND sc1 loads" -- the form the split-K exchange of this file already uses).
+// Progress: the hardware dispatches a grid's workgroups in index order per XCD, so the lowest unfinished block is always resident and
+// never waits on anything that is not resident or done.  That order is observed behaviour, not a HIP guarantee -- so the poll is
+// BOUNDED: a block that has polled ~2 s gives up waiting, sets DD3D_STATUS_CHAIN_TIMEOUT and runs on (its results are then wrong and the
+// host raises on the status word): a broken assumption ends in an error, never in a hung GPU.
+template <int TM, int TN, int WM, int WN, int NSB, int MODE, bool SK, int NSA, bool CHAIN = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(const ConvKArgs a) {
   constexpr int NP = Planes<MODE>::NP;
   constexpr int BM = TM * 32 * WM;
@@ -62,7 +76,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   const int wm = wave / WN;
   const int wn = wave - wm * WN;
 
-  const int bid = remap_block(blockIdx.x, a.ntiles * a.nn);
+  int bid, kslice;
+  if constexpr (CHAIN) {  // launch order = dependency order; the K slices of a tile are neighbours (a 2-D grid would dispatch ALL items' slice 1 last)
+    kslice = SK ? (int)(blockIdx.x % (unsigned)a.splitk) : 0;
+    bid = SK ? (int)(blockIdx.x / (unsigned)a.splitk) : (int)blockIdx.x;
+  } else {
+    bid = remap_block(blockIdx.x, a.ntiles * a.nn);
+    kslice = blockIdx.y;
+  }
   const int mt = bid / a.nn;
   const int nt = bid - mt * a.nn;
   int m0 = mt * BM;
@@ -79,7 +100,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   const int nk = a.Kpad / BK;  // 9 * chunks
   int kt_begin = 0, kt_end = nk;
   if (SK) {  // (the host only picks this kernel when kt_per_split is a multiple of 3: slices start on a filter row)
-    kt_begin = blockIdx.y * a.kt_per_split;
+    kt_begin = kslice * a.kt_per_split;
     kt_end = min(nk, kt_begin + a.kt_per_split);
   }
   const int ngroup = (kt_end - kt_begin) / 3;
@@ -135,7 +156,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   auto emit_a = [&](int stage) {
 #pragma unroll
     for (int q = 0; q < PA; ++q)
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)nxt_a[q], (ldsbp)(lds + stage * A_STAGE + a_dst[q]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)nxt_a[q], (ldsbp)(lds + stage * A_STAGE + a_dst[q]), 16, 0,
+                                       CHAIN ? 16 : 0);  // (cache policy bits: 16 = sc1, agent-coherent: another XCD may have written these rows in this launch)
   };
   auto emit_b = [&](int stage) {  // K-tile ld_kt, then advance
     const long koff = (long)ld_kt * (NP * 64);
@@ -257,6 +279,45 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     //   NSB = 5, NSA = 3:                       A(0) | B(0) B(1) | A(1) | B(2) B(3) B(4) | A(2)    (virtual steps -4 and -1 have dw == 2)
     // Then wait for A(0) and B(0): everything issued after the later of the two may stay in flight.
     constexpr int UPFRONT = (1 <= NSA && 1 > NSB) + (2 <= NSA && 4 > NSB) + (3 <= NSA && 7 > NSB) + (4 <= NSA && 10 > NSB);  // k: 3 k - 2 > NSB
+    if constexpr (CHAIN) {
+      // The filter stages do not depend on anybody: they stream while the block waits for its producers.  Then every A group, oldest
+      // first -- the issue order becomes B(0 .. NSB-1) | A(0 .. NSA-1): everything the loop's counted waits need is at least as OLD as
+      // in the steady-state order they were derived for (the B stages moved to the front, A(NSA-1) is still the youngest), so the waits
+      // stay sufficient; the first one below leaves only the younger A groups in flight.
+#pragma unroll
+      for (int d = 0; d < NSB; ++d) emit_b(d);
+      const int dep = s.reserved;  // 1 + index of the segment of this launch that writes this segment's input; 0: nobody does
+      if (dep > 0) {
+        if (tid == 0) {
+          // rows this block's A stages LOAD (valid taps or not: a row loaded before its producer wrote it could leave a stale line where a
+          // later block of this XCD looks for it): q = m0 - 1 + j + (dh - 1) W, j = 0 .. AROWS - 1, clipped to the map
+          const long npix_l = (long)s.B * s.H * s.W;
+          long lo = (long)m0 - 1 - s.W, hi = (long)m0 - 1 + (AROWS - 1) + s.W;
+          lo = lo < 0 ? 0 : lo;
+          hi = hi > npix_l - 1 ? npix_l - 1 : hi;
+          const int tb = a.seg_tile0[dep - 1];  // the producer has this segment's geometry: its m-tile of row r is tb + r / BM
+          const int t0 = tb + (int)(lo / BM), t1 = tb + (int)(hi / BM);
+          unsigned spins = 0;
+          for (int t = t0; t <= t1; ++t) {
+            while (__hip_atomic_load(a.chain_sync + 1 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.nn) {
+              __builtin_amdgcn_s_sleep(16);
+              if (++spins > (1u << 21)) {  // ~2 s: the dispatch-order assumption failed (see the kernel's header): error out, do not hang
+                if (a.status) atomicOr(a.status, DD3D_STATUS_CHAIN_TIMEOUT);
+                break;
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+#pragma unroll
+      for (int u = 0; u < NSA; ++u) {
+        prepare_a();
+        emit_a(u);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSA - 1) * PA) : "memory");
+    } else {
     int next_a = 0;
 #pragma unroll
     for (int u = 0; u < UPFRONT; ++u) {
@@ -275,6 +336,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     constexpr int DA0 = NSB + 2 - 3 * NSA;  // (UPFRONT == 0) A(0) follows B(DA0)
     constexpr int PRO_WAIT = UPFRONT > 0 ? (NSB - 1) * PB + (NSA - UPFRONT) * PA : (NSB - 1 - DA0) * PB + (NSA - 1) * PA;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRO_WAIT) : "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #if DD3D_EPI_T
@@ -337,7 +399,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   }
 
   if constexpr (SK) {
-    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid)) return;
+    if (!splitk_exchange<TM, TN, NTHR>(a, acc, bid, tid, kslice)) return;
   }
 #if DD3D_EPI_T
 #if DD3D_EPI_LDS
@@ -348,13 +410,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     __syncthreads();
     scratch = lds + wave * (NP * 2048);
   }
-  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, scratch);
+  conv_epilogue_t<TM, TN, MODE, WM, WN, CHAIN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, scratch);
 #else
-  conv_epilogue_t<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, nullptr);
+  conv_epilogue_t<TM, TN, MODE, WM, WN, CHAIN>(a, s, acc, m0, n0, wm, wn, lane, lds + EV_OFF, nullptr);
 #endif
 #else
+  static_assert(!CHAIN, "dependent segments need the transposed epilogue (write-through plane stores)");
   conv_epilogue<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);
 #endif
+  if constexpr (CHAIN) {
+    // this tile is in memory: every wave has its write-through stores acknowledged, then ONE agent-scope arrival on the m-tile's counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int sh_all_done;
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(a.chain_sync + 1 + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int total = a.ntiles * a.nn;  // tiles finished by exactly one block each (with split-K: the slice that arrives last)
+      sh_all_done = __hip_atomic_fetch_add(a.chain_sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1;
+    }
+    __syncthreads();
+    if (sh_all_done) {  // the launch's last tile: nobody polls any more -- leave the counters zero for the next launch / graph replay
+      for (int i = tid; i < a.ntiles + 1; i += NTHR) __hip_atomic_store(a.chain_sync + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ host
@@ -411,6 +489,31 @@ static int launch_row_tile(const ConvKArgs& ka, hipStream_t st) {
     lds_opt_in_done(attr_done);  // (every opt-in of this call site succeeded on this device)
   }
   if constexpr (!ALLOW_SK) DD3D_REQUIRE(ka.splitk == 1, "dd3d_conv2d_igemm_f32: this tile has no split-K form (its accumulators fill the register file)");
+  if (ka.chain) {
+    // dependent segments: items in launch order along x (m-tile, n-tile, K slice; see the kernel's header)
+    if constexpr (NSA == 2) {
+      static unsigned long long chain_attr_done[4];
+      if (lds_opt_in_needed(chain_attr_done)) {
+        if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false, NSA, true>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+        if constexpr (ALLOW_SK)
+          if (lds_opt_in(reinterpret_cast<const void*>(conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true, NSA, true>), (size_t)(lds), "dynamic LDS opt-in") != DD3D_OK) return DD3D_E_LAUNCH;
+        lds_opt_in_done(chain_attr_done);
+      }
+      const long nblk = (long)ka.ntiles * ka.nn * ka.splitk;
+      DD3D_REQUIRE(nblk < (1l << 31), "dd3d_conv2d_igemm_f32: chain launch of %ld blocks", nblk);
+      dim3 cgrid((unsigned)nblk, 1, 1);
+      if constexpr (ALLOW_SK) {
+        if (ka.splitk > 1) {
+          hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true, NSA, true>), cgrid, dim3(NTHR), lds, st, ka);
+          return check_launch("conv_igemm_planes_row chain split-K kernel");
+        }
+      }
+      hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, false, NSA, true>), cgrid, dim3(NTHR), lds, st, ka);
+      return check_launch("conv_igemm_planes_row chain kernel");
+    } else {
+      DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: this tile has no form for dependent segments (chain)");
+    }
+  }
   if constexpr (ALLOW_SK) {
     if (ka.splitk > 1) {
       hipLaunchKernelGGL((conv_igemm_planes_row_kernel<TM, TN, WM, WN, NSB, MODE, true, NSA>), grid, dim3(NTHR), lds, st, ka);

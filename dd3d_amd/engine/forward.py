@@ -41,6 +41,7 @@ class ForwardPlan(PlanBase, BackboneLowering):
         self._trunk(model, B, Hp, Wp)
         # ---- heads + post-processing
         self._heads(model, self.features)
+        self.merge_chains()  # (before the ops are counted: dependent 3 x 3 convolutions of the trunk / the tower layers become chain launches)
         self._postprocess(model, world_size, rank)
 
     def _trunk(self, model, B, Hp, Wp):
@@ -69,6 +70,7 @@ class ForwardPlan(PlanBase, BackboneLowering):
         self.host_K = self.host_meta[2 * B:].view(B, 9)
         self.host_outsize = self.host_buf((B, 4), torch.float32)
         self.host_pose = self.host_group = None  # (plans with BEV stages: _postprocess)
+        self.host_np = {"sizes": self.host_sizes.numpy(), "K": self.host_K.numpy(), "outsize": self.host_outsize.numpy()}  # (share the pinned memory)
         self._inputs_event = None
 
         # ---- preprocess.  With the fused stem (DLA, two-half-term arithmetic: FusedStemOp) the normalised image exists only inside
@@ -403,6 +405,7 @@ class ForwardPlan(PlanBase, BackboneLowering):
             self.host_pose = self.host_buf((B, 7), torch.float32)
             self.host_pose[:, 0] = 1.0  # identity rotation until stage_inputs fills it
             self.host_group = self.host_buf((B, ), torch.int32)
+            self.host_np.update(pose=self.host_pose.numpy(), group=self.host_group.numpy())
         if G == 0:
             return  # a camera-sharded rank that owns no sample of the step: it only contributes its record
         ncap = (NS + 63) // 64 * 64
@@ -477,6 +480,8 @@ class ForwardPlan(PlanBase, BackboneLowering):
         # (DenseDepthPlan shares this class without the post-processing half: no exchange, no gathered buffer)
         if not (getattr(self, "exchange", False) and self.math == hip.MATH_F16X2 and getattr(self, "gathered", None) is not None):
             return super().check_status(rb)
+        if (int(self.status.cpu()) if rb is None else rb.status) & hip.STATUS_CHAIN_TIMEOUT:
+            return super().check_status(rb)  # (raises: a rank-local launch fault, not a numeric verdict the ranks share)
         if rb is not None and rb.flags.shape[0] == self.world_size:
             fl = rb.flags
         else:

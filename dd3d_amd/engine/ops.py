@@ -93,9 +93,12 @@ class ConvOp:
     """One dd3d_conv2d_igemm_f32 launch (possibly many segments).  Input form: the split planes of the input buffers when they have
     them (plan.use_planes), else f32 NHWC.  Output form per segment: every storage its output buffer has (f32 NHWC and / or split
     planes), unless the segment says `write_f32=False` / `write_planes=False`."""
-    def __init__(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name="", math=None, in_relu=False):
+    def __init__(self, plan, meta, stride, pad, segs, relu, tile=None, splitk=None, name="", math=None, in_relu=False, chain=False):
+        """`chain`: the segments DEPEND on each other (include/dd3d_hip.h, dd3d_conv_launch.chain): a segment whose dict carries
+        "dep" = index of an earlier segment reads that segment's output as its input; residuals may come from any earlier segment."""
         dev = plan.device
         self.name = name
+        self.chain = bool(chain)
         m_list = [s["out"].B * s["out"].H * s["out"].W for s in segs]
         if math is None:
             math = plan.math
@@ -178,10 +181,17 @@ class ConvOp:
             self.res_forms.append(res_form)
             a["n_limit"] = int(s.get("n_limit", 0))
             assert a["n_limit"] <= meta["N"]
+            if chain:
+                dep = s.get("dep")
+                assert dep is None or (0 <= dep < i and segs[dep]["out"].c0 == vin.c0 and segs[dep]["out"].C == vin.C and segs[dep]["out"].buf is vin.buf), (name, i, dep)
+                assert in_planes and wp and not wf and res_form in (None, "planes") and (stride, pad, meta["KH"], meta["KW"]) == (1, 1, 3, 3), (name, i)
+                a["reserved"] = 0 if dep is None else dep + 1
+                self.seg_tile0 = getattr(self, "seg_tile0", []) + [len(tiles)]
             tiles += [(i, m0) for m0 in range(0, m_list[i], bm)]
             self.keep += [w, scale_vec, s["bias"], s.get("lo")]  # (what the launch reads; kept alive here)
         self.desc = dict(kind="conv", segs=segs, meta=meta, stride=stride, pad=pad, relu=bool(relu), in_relu=bool(in_relu),
-                         in_form="planes" if in_planes else "f32", out_forms=self.out_forms, res_forms=self.res_forms)
+                         in_form="planes" if in_planes else "f32", out_forms=self.out_forms, res_forms=self.res_forms, chain=self.chain)
+        self.ctor = dict(meta=meta, stride=stride, pad=pad, relu=bool(relu), tile=cfg, splitk=sk, math=math, in_relu=bool(in_relu))  # (merge_chains)
         self.segs_host = arr  # kept alive: the library reads the host copy at every launch (seg0_host)
         self.segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
         self.tiles_dev = torch.tensor(tiles, dtype=torch.int32).to(dev)
@@ -207,6 +217,12 @@ class ConvOp:
         L.out_plane_scale = float(plan.act_scale)
         L.status = plan.status.data_ptr() if plan.status is not None else None
         # underflow side of the f16x2 range guard: only launches that hand planes to a following convolution are watched
+        self.chain_sync = self.chain_tile0 = None
+        if chain:
+            assert len(segs) >= 2 and not (cfg == hip.TILE_256x256_W8 and sk > 1)
+            self.chain_sync = torch.zeros(1 + len(tiles), dtype=torch.int32, device=dev)  # zero between launches (the last tile clears it)
+            self.chain_tile0 = torch.tensor(self.seg_tile0, dtype=torch.int32).to(dev)
+            L.chain, L.chain_sync, L.chain_tile0 = 1, self.chain_sync.data_ptr(), self.chain_tile0.data_ptr()
         L.amax = plan.amax_slot(name) if (math == hip.MATH_F16X2 and any(wp for _, wp in self.out_forms) and not plan.dry_run
                                           and os.environ.get("DD3D_AMAX", "1") != "0") else None  # DD3D_AMAX=0: A/B measurements only
         self.L = L
@@ -214,7 +230,7 @@ class ConvOp:
         # (a segment that repeats another's products -- relu(p6) beside p6 -- is marked `algorithmic=False` and not counted)
         self.macs = sum(m * (sg.get("n_limit") or meta["N"]) for m, sg in zip(m_list, segs) if sg.get("algorithmic", True)) * meta["KH"] * meta["KW"] * meta["Cin"]
         self.info = dict(name=name, M=sum(m_list), N=meta["N"], K=meta["Kpad"], tile=(bm, bn), tile_name=hip.TILE_NAMES[cfg], splitk=sk, math=math,
-                         blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs), in_form="planes" if in_planes else "f32")
+                         blocks=len(tiles) * -(-meta["N"] // bn) * sk, nsegs=len(segs), in_form="planes" if in_planes else "f32", chain=self.chain)
 
     def __call__(self, lib, stream):
         hip.check(lib.dd3d_conv2d_igemm_f32(C.byref(self.L), stream), "conv " + self.name)

@@ -237,6 +237,11 @@ class PlanBase:
         mx = None
         if self.amax_names and (rb is None or rb.amax.numel() == len(self.amax_names)):
             mx = self.amax_values() if rb is None else rb.amax
+        if st & hip.STATUS_CHAIN_TIMEOUT:
+            self.status.zero_()
+            raise RuntimeError("a block of a chain launch (dd3d_conv_launch.chain) gave up waiting for its producer tiles: the results of this forward are "
+                               "invalid.  Set DD3D_CHAIN=0 (one launch per convolution) and report this: the launch relies on workgroups being "
+                               "dispatched in index order")
         if st & hip.STATUS_F16_OVERFLOW:
             self.status.zero_()
             e = HalfRangeOverflow(
@@ -461,6 +466,77 @@ class PlanBase:
         self.ops.append(op)
         if out.np and not planes:
             self.f32_written(out, name)
+
+    # ------------------------------------------------------------------ dependent convolutions in one launch
+    def merge_chains(self, first=0):
+        """Fuse runs of CONSECUTIVE convolution launches that feed each other into chain launches (include/dd3d_hip.h,
+        dd3d_conv_launch.chain; csrc/conv_planes_row.hip): op[i + 1] reads op[i]'s output, same filter geometry / tile / split-K / flags,
+        3 x 3 / stride 1 / pad 1 on split planes, planes-only outputs, residuals (if any) read from planes.  That is: conv2 of a DLA block
+        with the following block's conv1 -> conv2 (dla.py:50-62, 233-247) -- the roots (1 x 1) and the strided first convolutions stay
+        launches of their own -- and the four layers of the head towers (fcos2d.py:137-152, fcos3d.py:163-180), whose later layers then
+        start on the CUs the previous layer's last round leaves idle.  DD3D_CHAIN=0 keeps one launch per convolution (A/B);
+        DD3D_CHAIN=backbone / towers restricts the fusion to one of the two."""
+        mode = os.environ.get("DD3D_CHAIN", "1").strip().lower()
+        if mode in ("0", "off") or not self.use_planes or os.environ.get("DD3D_CONV_ROW", "1") == "0":
+            return
+        ops = self.ops
+
+        def chainable(op):
+            if not isinstance(op, ConvOp) or op.chain or op.branch != 0 or op.joins:
+                return False
+            c = op.ctor
+            m = c["meta"]
+            if (m["KH"], m["KW"], c["stride"], c["pad"]) != (3, 3, 1, 1) or not op.in_planes or c["in_relu"] or c["math"] == hip.MATH_F32:
+                return False
+            if c["tile"] == hip.TILE_256x256_W8 and c["splitk"] > 1:
+                return False
+            tower = op.name.startswith("towers.")
+            if (mode == "backbone" and tower) or (mode == "towers" and not tower):
+                return False
+            ok_out = all(wp and not wf for wf, wp in op.out_forms)
+            ok_res = all(r in (None, "planes") for r in op.res_forms)
+            return ok_out and ok_res and not any(sg.get("n_limit") for sg in op.desc["segs"])
+
+        def feeds(prev, op):
+            """segment k of `op` reads segment k of `prev` (same count), or a one-segment op reads the one-segment prev"""
+            a, b = prev.desc["segs"], op.desc["segs"]
+            if len(a) != len(b):
+                return False
+            return all(sb["in"].buf is sa["out"].buf and sb["in"].c0 == sa["out"].c0 and sb["in"].C == sa["out"].C for sa, sb in zip(a, b))
+
+        def same_launch(x, y):
+            cx, cy = x.ctor, y.ctor
+            keys = ("N", "Cin", "KH", "KW", "Kpad", "Npad")
+            return (all(cx["meta"][k] == cy["meta"][k] for k in keys) and cx["relu"] == cy["relu"] and cx["tile"] == cy["tile"]
+                    and cx["splitk"] == cy["splitk"] and cx["math"] == cy["math"])
+
+        i = first
+        while i < len(ops):
+            if not chainable(ops[i]):
+                i += 1
+                continue
+            j = i
+            while j + 1 < len(ops) and chainable(ops[j + 1]) and same_launch(ops[i], ops[j + 1]) and feeds(ops[j], ops[j + 1]):
+                j += 1
+            if j == i:
+                i += 1
+                continue
+            run = ops[i:j + 1]
+            segs, base = [], 0
+            for k, op in enumerate(run):
+                n = len(op.desc["segs"])
+                for q, sg in enumerate(op.desc["segs"]):
+                    segs.append(dict(sg, dep=(base - n + q) if k > 0 else None))
+                base += n
+            c = run[0].ctor
+            names = [op.name for op in run]
+            pre = os.path.commonprefix(names)
+            name = names[0] + "".join("+" + nm[len(pre):] for nm in names[1:]) if pre else "+".join(names)
+            merged = ConvOp(self, c["meta"], 1, 1, segs, c["relu"], tile=c["tile"], splitk=c["splitk"], name=name, math=c["math"], chain=True)
+            merged.branch, merged.joins = run[0].branch, run[0].joins
+            merged.parts = names  # the launches this one replaces (tools, profiles)
+            ops[i:j + 1] = [merged]
+            i += 1
 
     # ------------------------------------------------------------------ side branches
     def branch(self, b):

@@ -18,6 +18,7 @@ MATH_F32, MATH_BF16X3, MATH_BF16X2, MATH_BF16, MATH_F16X2 = 0, 1, 2, 3, 4
 MATH_PLANES = {MATH_F32: 0, MATH_BF16X3: 3, MATH_BF16X2: 2, MATH_BF16: 1, MATH_F16X2: 2}  # 16-bit terms per value (dd3d_math_planes)
 ABI_VERSION = 6
 STATUS_F16_OVERFLOW = 1
+STATUS_CHAIN_TIMEOUT = 2  # a block of a chain launch (dd3d_conv_launch.chain) gave up waiting for its producers
 CAND_FIELDS = 22
 DET_FIELDS = 32
 
@@ -49,7 +50,8 @@ class ConvLaunch(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("Cin", C.c_int32), ("N", C.c_int32),
         ("Kpad", C.c_int32), ("Npad", C.c_int32), ("relu", C.c_int32), ("splitk", C.c_int32), ("math_mode", C.c_int32),
         ("tile_cfg", C.c_int32), ("zero_page", C.c_void_p), ("tile_counters", C.c_void_p), ("seg0_host", C.c_void_p), ("in_relu", C.c_int32),
-        ("in_planes", C.c_int32), ("out_plane_scale", C.c_float), ("status", C.c_void_p), ("amax", C.c_void_p)
+        ("in_planes", C.c_int32), ("out_plane_scale", C.c_float), ("status", C.c_void_p), ("amax", C.c_void_p), ("chain", C.c_int32),
+        ("chain_sync", C.c_void_p), ("chain_tile0", C.c_void_p)
     ]
 
 

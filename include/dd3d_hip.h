@@ -89,7 +89,8 @@ typedef struct dd3d_conv_seg {  /* array lives in DEVICE memory */
   const void* in_planes; /* split-plane input [Cin/32][B*H*W][NP][32], first chunk of the slice; read instead of `in` when
                             dd3d_conv_launch.in_planes is set                                    */
   int32_t n_limit;     /* > 0: this segment stores only output channels < n_limit (<= launch N); 0: all N  */
-  int32_t reserved;
+  int32_t reserved;    /* ABI 6, chain launches (dd3d_conv_launch.chain): 1 + index of the segment of THIS launch whose output is this
+                          segment's input (in_planes), 0 when the input comes from an earlier launch.  0 in every other launch. */
   void* out_planes;    /* split-plane output [ceil(N/32)][M][NP][32] (first chunk of the slice) or NULL; `out` may then be NULL.
                           Channels N .. 32*ceil(N/32)-1 of the last chunk are written as zeros.  Split-operand modes only. */
 } dd3d_conv_seg;
@@ -129,6 +130,21 @@ typedef struct dd3d_conv_launch {  /* host memory */
                             them (atomic max; non-negative floats compare like their bit patterns).  The caller zeroes them before a forward
                             and reads their maximum afterwards: a tensor whose LARGEST scaled entry is below 2^-5 has lost more than four
                             of its 24 bits to the absolute floor 2^-25 of the half pair (the "underflow" side of the range guard). */
+  /* ABI 6 -- dependent segments in ONE launch: the stride-1 3 x 3 convolutions of a DLA level (tridet/modeling/feature_extractor/dla.py:50-62:
+   * conv1 -> conv2 + residual -> the next block's conv1 ...; dla.py:233-247 chains the blocks) and the four layers of the head towers
+   * (tridet/modeling/dd3d/fcos2d.py:137-152, fcos3d.py:163-180: every (tower, level) is a chain of four convolutions) without launch
+   * boundaries between them -- a later layer's first tiles start on the CUs the previous layer's last round leaves idle.
+   *   chain = 1: segment i may read, as its input (dd3d_conv_seg.reserved names the producing segment) and as a split-plane residual
+   *   (res_mode 2), what segments < i of this launch write.  Requirements (validated): 3 x 3 / stride 1 / pad 1 on split-plane input (the
+   *   row-shared kernels), split-plane outputs only (out == NULL), res_mode 0 or 2, no n_limit, producers before consumers in `tiles`
+   *   (segment-major), a consumer has its producer's B, H, W and reads the producer's out_planes as in_planes, seg0_host given.
+   *   chain_sync: device int32 [1 + ntiles], ZERO on entry; the launch leaves it zero.  [0] counts finished tiles, [1 + t] the finished
+   *   n-tiles of m-tile t (index into `tiles`).  chain_tile0: device int32 [nsegs], index in `tiles` of every segment's first m-tile.
+   *   A consumer block polls its producer's m-tiles that cover the rows it loads (bounded: DD3D_STATUS_CHAIN_TIMEOUT in *status instead
+   *   of a hang); the hand-over uses write-through stores and agent-coherent loads, no cache-wide fences. */
+  int32_t chain;
+  int32_t* chain_sync;
+  const int32_t* chain_tile0;
 } dd3d_conv_launch;
 
 /* Arithmetic of the implicit GEMM (results agree to f32 rounding level; both accumulate in f32):
@@ -152,6 +168,7 @@ typedef struct dd3d_conv_launch {  /* host memory */
  *                     scaled per output row by the caller, who divides the products of the scales out of `scale[n]`. */
 #define DD3D_MATH_F16X2 4
 #define DD3D_STATUS_F16_OVERFLOW 1 /* bit set in *status when a value left the half range while being split */
+#define DD3D_STATUS_CHAIN_TIMEOUT 2 /* bit set when a block of a chain launch (dd3d_conv_launch.chain) gave up waiting for its producers */
 /* DD3D_MATH_F16X2 range guard, for the multi-GPU exchange: out[0] = *status (may be NULL: 0), out[1] = 1 when one of the n_launches
  * watched launches stored a nonzero sampled maximum below `floor` (amax: [n_launches][16][32] floats, see dd3d_conv_launch.amax).  The
  * two words travel in a rank's record; after the all_gather every rank sees every rank's verdict and all act on the same step. */

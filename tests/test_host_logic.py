@@ -75,9 +75,59 @@ def test_plan_construction_dry_run(kitti_dla34, hiplib):
     assert not unfused.fused_stem and abs(unfused.conv_macs / 1e9 - (110.384 + 0.3853)) < 0.01
     assert [f.H * f.W for f in plan.features] == [7680, 1920, 480, 120, 30]
     towers = [c for c in convs if c.name.startswith("towers.")]
-    assert len(towers) == 4 and all(c.info["nsegs"] == 15 for c in towers)
+    assert len(towers) == 1 and towers[0].chain and towers[0].info["nsegs"] == 60 and towers[0].parts == [f"towers.{i}" for i in range(4)]
     with pytest.raises(RuntimeError):
         plan.launch()  # no CPU execution path exists
+
+
+def test_dependent_convolutions_become_chain_launches(kitti_dla34, hiplib, monkeypatch):
+    """Round 6 (engine.PlanBase.merge_chains): consecutive stride-1 3 x 3 convolutions that feed each other -- conv2 of a
+    DLA block with the next block's conv1 -> conv2 (dla.py:50-62, 233-247), the four tower layers (fcos2d.py:137-152, fcos3d.py:163-180) --
+    are ONE launch with dependent segments (include/dd3d_hip.h, dd3d_conv_launch.chain): producers named per segment, residuals read from
+    earlier segments' planes, one counter per m-tile; the conv work and the buffers are those of the one-launch-per-convolution plan."""
+    import numpy as np
+    from dd3d_amd import hip
+    from dd3d_amd.engine import ConvOp, ForwardPlan
+    cfg, model, sd = kitti_dla34
+    model.load_state_dict(sd)
+    plan = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)
+    monkeypatch.setenv("DD3D_CHAIN", "0")
+    flat = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)
+    monkeypatch.delenv("DD3D_CHAIN")
+    assert len(flat.ops) == 54 and len(plan.ops) == len(flat.ops) - 17  # (dry-run plans keep the preprocess op) 24 launches become 7
+    assert abs(plan.conv_macs - flat.conv_macs) == 0 and sorted(plan.bufs) == sorted(flat.bufs)
+    chains = [op for op in plan.ops if isinstance(op, ConvOp) and op.chain]
+    assert [len(op.parts) for op in chains] == [3, 3, 4, 3, 4, 3, 4]
+    assert chains[1].parts == ["level3.tree1.tree1.conv2", "level3.tree1.tree2.conv1", "level3.tree1.tree2.conv2"]
+    by_name = {op.name: op for op in flat.ops if isinstance(op, ConvOp)}
+    for op in chains:
+        segs, arr = op.desc["segs"], op.segs_host
+        assert op.L.chain == 1 and op.chain_sync.numel() == 1 + op.L.ntiles and op.chain_tile0.tolist() == op.seg_tile0
+        n = len(segs) // len(op.parts)
+        bm = op.info["tile"][0]
+        for i, sg in enumerate(segs):
+            dep = int(arr[i]["reserved"]) - 1
+            assert dep == (i - n if i >= n else -1)  # layer k's segment reads layer k - 1's segment of the same (tower, level) / the block before
+            if dep >= 0:  # (a dry-run plan has no device storage: the views tell who reads whom)
+                vi, vo = sg["in"], segs[dep]["out"]
+                assert vi.buf is vo.buf and (vi.c0, vi.C) == (vo.c0, vo.C) and (arr[i]["B"], arr[i]["H"], arr[i]["W"]) == (arr[dep]["B"], arr[dep]["H"], arr[dep]["W"])
+            assert op.out_forms[i] == (False, True) and int(arr[i]["res_mode"]) in (0, 2)
+            assert op.seg_tile0[i] == sum(-(-int(arr[q]["M"]) // bm) for q in range(i))
+        # the same tile / split-K as the launches it replaces, and their segments in order
+        for part, k in zip(op.parts, range(len(op.parts))):
+            single = by_name[part]
+            assert (single.L.tile_cfg, single.L.splitk, single.L.relu) == (op.L.tile_cfg, op.L.splitk, op.L.relu)
+            assert [int(x) for x in single.segs_host["w"]] == [int(x) for x in arr["w"][k * n:(k + 1) * n]]
+    # a BasicBlock's residual inside a chain is an EARLIER segment's output (dla.py:59-60 `out += residual`)
+    c = chains[2]  # level3.tree2: tree1.conv1 -> tree1.conv2 (+ x) -> tree2.conv1 -> tree2.conv2 (+ tree1's output)
+    sg = c.desc["segs"]
+    assert sg[3]["res"].buf is sg[1]["out"].buf and sg[3]["res"].c0 == sg[1]["out"].c0 and all(sg[1]["res"].buf is not q["out"].buf or sg[1]["res"].c0 != q["out"].c0 for q in sg)
+    from dd3d_amd.engine import kernel_signature
+    assert kernel_signature(chains[-1]).endswith("false, 2, true>") and kernel_signature(by_name["towers.0"]).endswith("false, 2>")
+    for mode, want in (("backbone", 6), ("towers", 1)):
+        monkeypatch.setenv("DD3D_CHAIN", mode)
+        p = ForwardPlan(model, 1, 128, 256, device="cpu", dry_run=True)
+        assert sum(1 for op in p.ops if isinstance(op, ConvOp) and op.chain) == want
 
 
 def test_planes_only_data_flow_of_the_default_plan(kitti_dla34, hiplib, monkeypatch):
@@ -86,6 +136,7 @@ def test_planes_only_data_flow_of_the_default_plan(kitti_dla34, hiplib, monkeypa
     from dd3d_amd.engine import ConvOp, ForwardPlan
     cfg, model, sd = kitti_dla34
     model.load_state_dict(sd)
+    monkeypatch.setenv("DD3D_CHAIN", "0")  # (one launch per convolution: this test reads the data flow off the per-convolution ops)
     plan = ForwardPlan(model, 2, 128, 256, device="cpu", dry_run=True)
     inner = {n: b for n, b in plan.bufs.items() if n.startswith(("level", "fpn_lateral", "p", "tower"))}
     assert len(inner) > 40 and all(b.np == 2 and not b.has_f32 for b in inner.values()), [n for n, b in inner.items() if b.has_f32]
@@ -186,7 +237,7 @@ def test_cabi_exports_match_header(hiplib):
     for cfg_id, shape in hip.TILE_SHAPES.items():
         assert hiplib.dd3d_conv_tile_shape(cfg_id, C.byref(bm), C.byref(bn)) == 0 and (bm.value, bn.value) == shape
     assert hiplib.dd3d_conv_tile_shape(99, C.byref(bm), C.byref(bn)) < 0 and b"tile_cfg" in hiplib.dd3d_last_error()
-    assert C.sizeof(hip.ConvLaunch) == 136 and hip.CONV_SEG_DTYPE.itemsize == 120
+    assert C.sizeof(hip.ConvLaunch) == 160 and hip.CONV_SEG_DTYPE.itemsize == 120
 
 
 def test_product_sources_hold_no_wrong_result_variants():
