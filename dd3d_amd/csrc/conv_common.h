@@ -328,7 +328,19 @@ __device__ __forceinline__ int chan_of_row(int rho) { return ((rho >> 2) & 1) * 
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // agent-coherent 16-byte accesses of the in-launch hand-over between dependent segments (same forms as the split-K exchange above)
-__device__ __forceinline__ void st_sc1_u4(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+#ifndef DD3D_CHAIN_PLAIN_STORES
+#define DD3D_CHAIN_PLAIN_STORES 0
+#endif
+__device__ __forceinline__ void st_sc1_u4(void* p, u32x4 v) {
+#if DD3D_CHAIN_PLAIN_STORES
+  *(u32x4 __attribute__((address_space(1)))*)p = v;
+#else
+  // (s_nop 1: a VMEM store of more than 8 bytes must be followed by two wait states before a VALU instruction overwrites its data registers
+  // -- gfx940+; the compiler inserts them behind stores it knows, it cannot see inside this statement.  Without them the first dwords of a
+  // 16-byte unit were now and then the NEXT unit's address arithmetic: profiles/r06_chain_bringup.txt)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
 __device__ __forceinline__ u32x4 ld_sc1_u4(const void* p) {
   u32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
@@ -400,6 +412,9 @@ constexpr bool epi_residual_ok() { return !(TM * TN >= 8 && WM * WN >= 8); }
 
 // CHAIN: the launch holds dependent segments (ConvKArgs.chain) -- plane stores are write-through (sc1) and a split-plane residual is read
 // with sc1 loads, so that blocks on other XCDs (their L2s are not coherent with this one's) see / read what memory holds.
+#ifndef DD3D_CHAIN_RES_SC1
+#define DD3D_CHAIN_RES_SC1 1  // 1: a chain launch reads split-plane residuals with sc1 loads (0: default policy; the consumer block's acquire covers them)
+#endif
 template <int TM, int TN, int MODE, int WM, int WN, bool CHAIN = false>
 __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_conv_seg& s, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
                                                 int wn, int lane, const unsigned char* evec, unsigned char* scratch) {
@@ -470,11 +485,11 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
             for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
-                if constexpr (CHAIN) raw[ii][2 * pl + q] = ld_sc1_u4((const void*)(p + pl * 64 + q * 16));  // (row 0 when m >= M: read, never used)
+                if constexpr (CHAIN && DD3D_CHAIN_RES_SC1) raw[ii][2 * pl + q] = ld_sc1_u4((const void*)(p + pl * 64 + q * 16));  // (row 0 when m >= M: read, never used)
                 else raw[ii][2 * pl + q] = mv ? *(gcu4p)(p + pl * 64 + q * 16) : u32x4{0u, 0u, 0u, 0u};
               }
           }
-          if constexpr (CHAIN) {
+          if constexpr (CHAIN && DD3D_CHAIN_RES_SC1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int ii = 0; ii < IG; ++ii) {
@@ -558,16 +573,34 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
               }
             const int mblk = m0 + (wm * TM + i) * 32;  // first pixel of the block
             const gbp dst = (gbp)s.out_planes + (long)(nb >> 5) * cstride + (long)mblk * (NP * 64);
+            if constexpr (CHAIN) {
+              // write-through stores are inline assembly: the compiler's wait-count pass does not see them read `vals`, so the LDS reads are
+              // waited for explicitly (found the hard way: without it a store instruction now and then wrote 1 KiB of not-yet-landed registers)
+              u32x4 vals[2 * NP];
+#pragma unroll
+              for (int k = 0; k < 2 * NP; ++k) {
+                const int U = 64 * k + lane;
+                const int pp = U / UP, u = U - pp * UP;
+                const int us = NP == 2 ? (u ^ (pp & 7)) : ((u & ~3) + ((u & 3) ^ (pp & 3)));
+                vals[k] = *reinterpret_cast<const u32x4*>(scratch + (pp * UP + us) * 16);
+              }
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+              for (int k = 0; k < 2 * NP; ++k) asm volatile("" : "+v"(vals[k]));
+#pragma unroll
+              for (int k = 0; k < 2 * NP; ++k) {
+                const int U = 64 * k + lane;
+                if (mblk + U / UP < s.M) st_sc1_u4((void*)(dst + (long)U * 16), vals[k]);
+              }
+            } else {
 #pragma unroll
             for (int k = 0; k < 2 * NP; ++k) {
               const int U = 64 * k + lane;  // linear 16-byte unit of the block's run
               const int pp = U / UP, u = U - pp * UP;
               const int us = NP == 2 ? (u ^ (pp & 7)) : ((u & ~3) + ((u & 3) ^ (pp & 3)));
               const u32x4 val = *reinterpret_cast<const u32x4*>(scratch + (pp * UP + us) * 16);
-              if (mblk + pp < s.M) {
-                if constexpr (CHAIN) st_sc1_u4((void*)(dst + (long)U * 16), val);
-                else *(gu4p)(dst + (long)U * 16) = val;
-              }
+              if (mblk + pp < s.M) *(gu4p)(dst + (long)U * 16) = val;
+            }
             }
           } else if (mv) {
             const gbp dst = (gbp)s.out_planes + (long)(nb >> 5) * cstride + (long)m * (NP * 64) + h * 32;

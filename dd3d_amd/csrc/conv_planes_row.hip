@@ -30,6 +30,15 @@ DD3D_NOTE_BUILD_FLAGS
 #ifndef DD3D_EPI_LDS
 #define DD3D_EPI_LDS 1  // 1: the transposed epilogue stages its plane stores through LDS (1 KiB of consecutive bytes per store instruction); 0: straight from the registers (A/B)
 #endif
+#ifndef DD3D_CHAIN_A_AUX
+#define DD3D_CHAIN_A_AUX 16  // cache-policy bits of the activation LDS-DMA of a chain launch (16 = sc1, 2 = nt, 0 = default policy behind an agent acquire)
+#endif
+#ifndef DD3D_CHAIN_ACQUIRE
+#define DD3D_CHAIN_ACQUIRE 0  // 1: a consumer block's polling lane issues an agent-scope acquire (invalidates the CU's L1) before the block reads its producers' rows
+#endif
+#ifndef DD3D_CHAIN_B_FIRST
+#define DD3D_CHAIN_B_FIRST 1  // 1: a chain block issues its filter stages before it waits for its producers
+#endif
 #ifndef DD3D_EPI_T
 #define DD3D_EPI_T 1  // 1: transposed accumulators + the 16-bytes-per-lane epilogue (conv_common.h::conv_epilogue_t); 0: round-3 form (A/B)
 #endif
@@ -80,6 +89,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if constexpr (CHAIN) {  // launch order = dependency order; the K slices of a tile are neighbours (a 2-D grid would dispatch ALL items' slice 1 last)
     kslice = SK ? (int)(blockIdx.x % (unsigned)a.splitk) : 0;
     bid = SK ? (int)(blockIdx.x / (unsigned)a.splitk) : (int)blockIdx.x;
+#ifdef DD3D_CHAIN_REMAP
+    bid = remap_block(bid, a.ntiles * a.nn);
+#endif
   } else {
     bid = remap_block(blockIdx.x, a.ntiles * a.nn);
     kslice = blockIdx.y;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 #pragma unroll
     for (int q = 0; q < PA; ++q)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)nxt_a[q], (ldsbp)(lds + stage * A_STAGE + a_dst[q]), 16, 0,
-                                       CHAIN ? 16 : 0);  // (cache policy bits: 16 = sc1, agent-coherent: another XCD may have written these rows in this launch)
+                                       CHAIN ? DD3D_CHAIN_A_AUX : 0);
   };
   auto emit_b = [&](int stage) {  // K-tile ld_kt, then advance
     const long koff = (long)ld_kt * (NP * 64);
@@ -280,17 +292,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     // Then wait for A(0) and B(0): everything issued after the later of the two may stay in flight.
     constexpr int UPFRONT = (1 <= NSA && 1 > NSB) + (2 <= NSA && 4 > NSB) + (3 <= NSA && 7 > NSB) + (4 <= NSA && 10 > NSB);  // k: 3 k - 2 > NSB
     if constexpr (CHAIN) {
-      // The filter stages do not depend on anybody: they stream while the block waits for its producers.  Then every A group, oldest
-      // first -- the issue order becomes B(0 .. NSB-1) | A(0 .. NSA-1): everything the loop's counted waits need is at least as OLD as
-      // in the steady-state order they were derived for (the B stages moved to the front, A(NSA-1) is still the youngest), so the waits
-      // stay sufficient; the first one below leaves only the younger A groups in flight.
+      // The filter stages depend on nobody: they stream while the block waits for its producers (DD3D_CHAIN_B_FIRST, default).  The issue
+      // order then is B(0 .. NSB-1) | A groups as usual: everything the loop's counted waits need is at least as OLD as in the order
+      // they were derived for (the B stages only moved to the front), so the waits stay sufficient.
+      const int dep = s.reserved;  // 1 + index of the segment of this launch that writes this segment's input; 0: nobody does
+#if DD3D_CHAIN_B_FIRST
 #pragma unroll
       for (int d = 0; d < NSB; ++d) emit_b(d);
-      const int dep = s.reserved;  // 1 + index of the segment of this launch that writes this segment's input; 0: nobody does
+#endif
       if (dep > 0) {
         if (tid == 0) {
           // rows this block's A stages LOAD (valid taps or not: a row loaded before its producer wrote it could leave a stale line where a
-          // later block of this XCD looks for it): q = m0 - 1 + j + (dh - 1) W, j = 0 .. AROWS - 1, clipped to the map
+          // later block of this CU / XCD looks for it): q = m0 - 1 + j + (dh - 1) W, j = 0 .. AROWS - 1, clipped to the map
           const long npix_l = (long)s.B * s.H * s.W;
           long lo = (long)m0 - 1 - s.W, hi = (long)m0 - 1 + (AROWS - 1) + s.W;
           lo = lo < 0 ? 0 : lo;
@@ -298,25 +311,34 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
           const int tb = a.seg_tile0[dep - 1];  // the producer has this segment's geometry: its m-tile of row r is tb + r / BM
           const int t0 = tb + (int)(lo / BM), t1 = tb + (int)(hi / BM);
           unsigned spins = 0;
-          for (int t = t0; t <= t1; ++t) {
+          // newest producer first: tiles finish roughly in launch order, so when the LAST one is there the others need one look each
+          for (int t = t1; t >= t0; --t) {
             while (__hip_atomic_load(a.chain_sync + 1 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.nn) {
-              __builtin_amdgcn_s_sleep(16);
-              if (++spins > (1u << 21)) {  // ~2 s: the dispatch-order assumption failed (see the kernel's header): error out, do not hang
+              // back off: hundreds of parked blocks polling every half microsecond load the fabric the producers store through
+              if (spins < 8) __builtin_amdgcn_s_sleep(8);
+              else if (spins < 64) __builtin_amdgcn_s_sleep(32);
+              else __builtin_amdgcn_s_sleep(127);
+              if (++spins > (1u << 19)) {  // ~2 s: the dispatch-order assumption failed (see the kernel's header): error out, do not hang
                 if (a.status) atomicOr(a.status, DD3D_STATUS_CHAIN_TIMEOUT);
                 break;
               }
             }
           }
+#if DD3D_CHAIN_ACQUIRE
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1: lines this CU cached in an earlier launch / replay are not served again
+#endif
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
+    }
+    if constexpr (CHAIN && DD3D_CHAIN_B_FIRST) {
 #pragma unroll
       for (int u = 0; u < NSA; ++u) {
         prepare_a();
         emit_a(u);
       }
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSA - 1) * PA) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSA - 1) * PA) : "memory");  // A(0) and every B stage landed; the younger A groups may be in flight
     } else {
     int next_a = 0;
 #pragma unroll

@@ -474,9 +474,15 @@ class PlanBase:
         3 x 3 / stride 1 / pad 1 on split planes, planes-only outputs, residuals (if any) read from planes.  That is: conv2 of a DLA block
         with the following block's conv1 -> conv2 (dla.py:50-62, 233-247) -- the roots (1 x 1) and the strided first convolutions stay
         launches of their own -- and the four layers of the head towers (fcos2d.py:137-152, fcos3d.py:163-180), whose later layers then
-        start on the CUs the previous layer's last round leaves idle.  DD3D_CHAIN=0 keeps one launch per convolution (A/B);
-        DD3D_CHAIN=backbone / towers restricts the fusion to one of the two."""
-        mode = os.environ.get("DD3D_CHAIN", "1").strip().lower()
+        start on the CUs the previous layer's last round leaves idle.
+
+        OFF by default (DD3D_CHAIN=1 turns it on, =backbone / =towers one of the two): bit-exact against the one-launch-per-convolution plan
+        (tests/test_chain_gpu.py, also with five slots in flight), but MEASURED SLOWER on MI355X -- a dependent layer inside a launch costs
+        5-9 us (write-through acknowledgement + arrival atomic + the consumer's poll + its first activation fetch past the L2) where a
+        kernel boundary costs 1.5-2 us: one image 1.18 -> 1.27 ms, the driver command 1621 -> 1569 img/s, the four tower layers as one
+        launch 1280 -> 1294 us per four images (the tail-round fill is eaten by the activations' three filter-row passes no longer hitting
+        the L2): profiles/r06e_chain_prefix_*.txt, r06d_chain_ab.txt; DESIGN section 4, round 6."""
+        mode = os.environ.get("DD3D_CHAIN", "0").strip().lower()
         if mode in ("0", "off") or not self.use_planes or os.environ.get("DD3D_CONV_ROW", "1") == "0":
             return
         ops = self.ops
@@ -490,6 +496,8 @@ class PlanBase:
                 return False
             if c["tile"] == hip.TILE_256x256_W8 and c["splitk"] > 1:
                 return False
+            if c["splitk"] > 1 and -(-(m["Kpad"] // 32) // c["splitk"]) % 3:
+                return False  # (K slices that do not start on a filter row run on the per-tap kernel, which has no chain form)
             tower = op.name.startswith("towers.")
             if (mode == "backbone" and tower) or (mode == "towers" and not tower):
                 return False

@@ -75,7 +75,7 @@ def test_plan_construction_dry_run(kitti_dla34, hiplib):
     assert not unfused.fused_stem and abs(unfused.conv_macs / 1e9 - (110.384 + 0.3853)) < 0.01
     assert [f.H * f.W for f in plan.features] == [7680, 1920, 480, 120, 30]
     towers = [c for c in convs if c.name.startswith("towers.")]
-    assert len(towers) == 1 and towers[0].chain and towers[0].info["nsegs"] == 60 and towers[0].parts == [f"towers.{i}" for i in range(4)]
+    assert len(towers) == 4 and all(c.info["nsegs"] == 15 and not c.chain for c in towers)
     with pytest.raises(RuntimeError):
         plan.launch()  # no CPU execution path exists
 
@@ -90,10 +90,10 @@ def test_dependent_convolutions_become_chain_launches(kitti_dla34, hiplib, monke
     from dd3d_amd.engine import ConvOp, ForwardPlan
     cfg, model, sd = kitti_dla34
     model.load_state_dict(sd)
+    flat = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)  # the default: one launch per convolution (chains measured slower)
+    assert not any(isinstance(op, ConvOp) and op.chain for op in flat.ops)
+    monkeypatch.setenv("DD3D_CHAIN", "1")
     plan = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)
-    monkeypatch.setenv("DD3D_CHAIN", "0")
-    flat = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)
-    monkeypatch.delenv("DD3D_CHAIN")
     assert len(flat.ops) == 54 and len(plan.ops) == len(flat.ops) - 17  # (dry-run plans keep the preprocess op) 24 launches become 7
     assert abs(plan.conv_macs - flat.conv_macs) == 0 and sorted(plan.bufs) == sorted(flat.bufs)
     chains = [op for op in plan.ops if isinstance(op, ConvOp) and op.chain]
@@ -136,7 +136,7 @@ def test_planes_only_data_flow_of_the_default_plan(kitti_dla34, hiplib, monkeypa
     from dd3d_amd.engine import ConvOp, ForwardPlan
     cfg, model, sd = kitti_dla34
     model.load_state_dict(sd)
-    monkeypatch.setenv("DD3D_CHAIN", "0")  # (one launch per convolution: this test reads the data flow off the per-convolution ops)
+    monkeypatch.setenv("DD3D_CHAIN", "0")  # (one launch per convolution -- the default: this test reads the data flow off the per-convolution ops)
     plan = ForwardPlan(model, 2, 128, 256, device="cpu", dry_run=True)
     inner = {n: b for n, b in plan.bufs.items() if n.startswith(("level", "fpn_lateral", "p", "tower"))}
     assert len(inner) > 40 and all(b.np == 2 and not b.has_f32 for b in inner.values()), [n for n, b in inner.items() if b.has_f32]
