@@ -126,8 +126,14 @@ def test_dependent_convolutions_become_chain_launches(kitti_dla34, hiplib, monke
     assert kernel_signature(chains[-1]).endswith("false, 2, true>") and kernel_signature(by_name["towers.0"]).endswith("false, 2>")
     for mode, want in (("backbone", 6), ("towers", 1)):
         monkeypatch.setenv("DD3D_CHAIN", mode)
-        p = ForwardPlan(model, 1, 128, 256, device="cpu", dry_run=True)
+        p = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)
         assert sum(1 for op in p.ops if isinstance(op, ConvOp) and op.chain) == want
+    # split-K slices that do not start on a filter row run on the per-tap kernel: such convolutions stay launches of their own
+    monkeypatch.setenv("DD3D_CHAIN", "1")
+    small = ForwardPlan(model, 1, 128, 256, device="cpu", dry_run=True)
+    for op in small.ops:
+        if isinstance(op, ConvOp) and op.chain and op.L.splitk > 1:
+            assert -(-(op.L.Kpad // 32) // op.L.splitk) % 3 == 0, op.name
 
 
 def test_planes_only_data_flow_of_the_default_plan(kitti_dla34, hiplib, monkeypatch):
