@@ -81,4 +81,24 @@
 #else
 #define DD3D_BF_13 ""
 #endif
-#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13
+#ifdef DD3D_CHAIN_A_AUX
+#define DD3D_BF_14 " DD3D_CHAIN_A_AUX=" DD3D_BF_STR(DD3D_CHAIN_A_AUX)
+#else
+#define DD3D_BF_14 ""
+#endif
+#ifdef DD3D_CHAIN_ACQUIRE
+#define DD3D_BF_15 " DD3D_CHAIN_ACQUIRE=" DD3D_BF_STR(DD3D_CHAIN_ACQUIRE)
+#else
+#define DD3D_BF_15 ""
+#endif
+#ifdef DD3D_CHAIN_RES_SC1
+#define DD3D_BF_16 " DD3D_CHAIN_RES_SC1=" DD3D_BF_STR(DD3D_CHAIN_RES_SC1)
+#else
+#define DD3D_BF_16 ""
+#endif
+#ifdef DD3D_CHAIN_B_FIRST
+#define DD3D_BF_17 " DD3D_CHAIN_B_FIRST=" DD3D_BF_STR(DD3D_CHAIN_B_FIRST)
+#else
+#define DD3D_BF_17 ""
+#endif
+#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13 DD3D_BF_14 DD3D_BF_15 DD3D_BF_16 DD3D_BF_17

@@ -328,18 +328,11 @@ __device__ __forceinline__ int chan_of_row(int rho) { return ((rho >> 2) & 1) * 
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // agent-coherent 16-byte accesses of the in-launch hand-over between dependent segments (same forms as the split-K exchange above)
-#ifndef DD3D_CHAIN_PLAIN_STORES
-#define DD3D_CHAIN_PLAIN_STORES 0
-#endif
 __device__ __forceinline__ void st_sc1_u4(void* p, u32x4 v) {
-#if DD3D_CHAIN_PLAIN_STORES
-  *(u32x4 __attribute__((address_space(1)))*)p = v;
-#else
   // (s_nop 1: a VMEM store of more than 8 bytes must be followed by two wait states before a VALU instruction overwrites its data registers
   // -- gfx940+; the compiler inserts them behind stores it knows, it cannot see inside this statement.  Without them the first dwords of a
   // 16-byte unit were now and then the NEXT unit's address arithmetic: profiles/r06_chain_bringup.txt)
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#endif
 }
 __device__ __forceinline__ u32x4 ld_sc1_u4(const void* p) {
   u32x4 v;

@@ -89,9 +89,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   if constexpr (CHAIN) {  // launch order = dependency order; the K slices of a tile are neighbours (a 2-D grid would dispatch ALL items' slice 1 last)
     kslice = SK ? (int)(blockIdx.x % (unsigned)a.splitk) : 0;
     bid = SK ? (int)(blockIdx.x / (unsigned)a.splitk) : (int)blockIdx.x;
-#ifdef DD3D_CHAIN_REMAP
-    bid = remap_block(bid, a.ntiles * a.nn);
-#endif
   } else {
     bid = remap_block(blockIdx.x, a.ntiles * a.nn);
     kslice = blockIdx.y;
