@@ -101,7 +101,8 @@ def test_bench_multi_gpu_command_line(hiplib, pipeline):
     assert c["rccl_nranks"] == 0 and c["exchange_selftest"]["nranks"] == 2 and c["exchange_selftest"]["backend"] == "gloo"  # (0: this run was NOT on RCCL)
     assert len(c["rank_devices"]) == 2 and all(dv["device"] == 0 and dv["pci_bus_id"] for dv in c["rank_devices"])
     assert len(c["rank_ms_per_step"]) == 2 and max(c["rank_ms_per_step"]) <= d["ms_per_step"] * 1.001 and c["graph_exchange"] is False
-    assert d["work_verified"]["identical_across_slots"] and d["work_verified"]["detections_per_image"] == [100]
+    # (the default issue mode stages four DISTINCT images per slot -- one per request position; `--pipeline 0` one)
+    assert d["work_verified"]["identical_across_slots"] and d["work_verified"]["detections_per_image"] == [100] * (1 if pipeline == "0" else 4)
 
 
 def test_bench_single_gpu_line_carries_parity_and_baselines(hiplib):
@@ -109,7 +110,8 @@ def test_bench_single_gpu_line_carries_parity_and_baselines(hiplib):
     the parity object (the metric's second half: 3D-box L1 vs the oracle, bars met) and the read-back of the timed work."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-forwards", "2", "--repeat-blocks", "1"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-forwards", "2", "--repeat-blocks", "1",
+           "--e2e-requests", "24"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
@@ -119,7 +121,18 @@ def test_bench_single_gpu_line_carries_parity_and_baselines(hiplib):
     rf, cb, pr = d["roofline"], d["cpu_baseline"], d["parity"]
     assert rf["bound"] == "mfma" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["traffic"] and rf["unit"] == "TFLOP/s"
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
-    assert pr["pass"] and pr["detections_hip"] == pr["detections_oracle"] == 100 and pr["off_cut_flips"] == 0
-    assert pr["corners_l1_rel"] <= 1e-3 and pr["box3d_l1_tvec_size_rel"] <= 1e-3 and (pr["int_mismatches"] == 0 or pr["on_cut_flips"] > 0)
-    assert d["work_verified"]["slot_positions_checked"] == 20 and d["config"]["f16x2_range"]["overflow_headroom_x"] > 4
+    # parity is that of the TIMED launch plan: slot 0's four-image plan, every request position the CPU leg ran an oracle forward for
+    assert pr["pass"] and pr["images_compared"] == 2 and pr["detections_hip"] == pr["detections_oracle"] == 200 and pr["off_cut_flips"] == 0
+    assert "4-image plan" in pr["image"] and pr["matched"] >= 198
+    assert pr["corners_l1_rel"] <= 1e-3 and pr["box3d_l1_tvec_size_rel"] <= 1e-3 and pr["box2d_rel_max"] <= 1e-3
+    assert pr["int_mismatches"] == pr["rank_swaps"] or pr["on_cut_flips"] > 0  # same detections at the same ranks, up to score ties / cuts
+    assert d["work_verified"]["slot_positions_checked"] == 20 and d["work_verified"]["distinct_images_per_slot"] == 4
+    assert d["config"]["f16x2_range"]["overflow_headroom_x"] > 4
     assert d["config"]["bs1_images_per_s"] > 0 and "DLA34" in d["config"]["workload"]
+    # the end-to-end leg (distinct host images through submit() / result(): core.py:65 ... :153-164) and the second issue geometry
+    e2e = d["config"]["e2e"]
+    for src in ("pinned", "pageable"):
+        assert e2e[src]["images_per_s"] > 0 and e2e[src]["requests"] == 24 and e2e[src]["detections_returned"] > 0
+        assert e2e[src]["host_us_per_request_stage_inputs"] > 0 and e2e[src]["host_us_per_request_collect"] > 0
+    assert e2e["pinned"]["images_per_s"] > 0.8 * d["value"]
+    assert d["config"]["alt_issue"]["median_images_per_s"] > 0 and "error" not in d["config"]["alt_issue"]
