@@ -18,7 +18,7 @@ Every slot's graphs are replayed once at construction and the untimed warm-up co
 Prints ONE JSON line (rank 0).  ``roofline`` is for the dominant kernel (the head-tower implicit-GEMM launch of the slot's plan:
 conv_igemm_planes_row_kernel<4,2,2,4,2,4,false,2> of csrc/conv_planes_row.hip at the default four images per launch): algorithmic FLOPs of
 one launch / its mean duration measured here with HIP events on the launch stream (``traffic``: the PMC-derived HBM bytes of that launch
-geometry, profiles/r05_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: tests/tools' dd3d_tools_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
+geometry, profiles/r06_tower_hbm_bytes.json; ``measured_mfma_ceiling_on_real_operands_tflops``: tests/tools' dd3d_tools_mfma_probe timed in this run), against the MFMA roofline of the arithmetic in use -- 2500 TFLOP/s dense 16-bit MFMA divided by the
 matrix products spent per f32 product (``--math``: f16x2 3, bf16x3 6, bf16x2 3, bf16 1; the f32-input MFMA peak 157.3 TFLOP/s for f32).
 ``blocks`` repeats the timed block a few times so that a reader can tell box / clock variance from a regression.  ``cpu_baseline`` is
 the CPU oracle (a restatement "port" of the reference forward) timed on this host's cores on a bounded sample of the same workload.
@@ -81,7 +81,7 @@ def parse_args():
                     help="requests of the end-to-end leg (distinct host images through submit() / result(), outside `value`); 0 skips it")
     ap.add_argument("--alt-issue", default=os.environ.get("DD3D_BENCH_ALT_ISSUE", "2x10"),
                     help="a second issue geometry SLOTSxMICROBATCH timed in the same run and reported as config.alt_issue ('' skips it)")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_tower_hbm_bytes.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r06_tower_hbm_bytes.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel, keyed by kernel signature (see profiles/README.md)")
     return ap.parse_args()
 

@@ -8,7 +8,7 @@
       boxes of one part of the validation set = 3769 images / 100 parts; ~8 ground-truth and ~30 detected boxes per image);
   f3  DeviceInputMapper: raw 370 x 1224 uint8 frame -> shortest-edge-384 resize (Pillow-exact) + intrinsics, on the device.
 
-    python tests/gpu_tta_time.py > gpurun_out/r05_tta.txt
+    python tests/gpu_tta_time.py > gpurun_out/r06_tta.txt
 """
 import os
 import sys
@@ -58,6 +58,28 @@ def tta_lines():
               f"{gflop / ms:6.1f} TFLOP/s f32-equivalent on the padded canvases); {n} merged detections; plans {plans}")
 
 
+def nusc_tta_line():
+    """NuscenesDD3DWithTTA at the nuScenes experiment's own scales (configs/experiments/dd3d_nusc_dla34.yaml:55-62: MIN_SIZES [640 ... 1152] x
+    flip on one 6-camera sample of raw 900 x 1600 frames): per camera ten copies in ONE launch plan on the 1152 x 2048 canvas, then the
+    sample aggregation (tests/golden/tta_nusc_dla34_scales.npz is the reference's result for the same sample)."""
+    from dd3d_amd.tta import NuscenesDD3DWithTTA
+    from tests.golden.make_tta_golden import NUSC_FULL_TTA_OVERRIDES, nusc_full_tta_case
+    cfg = get_cfg("dd3d_nusc_dla34", NUSC_FULL_TTA_OVERRIDES)
+    model = build_model(cfg)
+    model.load_state_dict(make_state_dict(model, calib=load_calib("dla34_nusc")))
+    model.use_graph = True
+    tta = NuscenesDD3DWithTTA(cfg, model)
+    xs = nusc_full_tta_case()
+    for x in xs:
+        x["image"] = x["image"].cuda()
+    n = sum(len(r["instances"]) for r in tta(xs))
+    ms = timed(lambda: tta(xs), reps=5, warm=1)
+    plans = sorted((p.B, p.Hp, p.Wp) for p in model._plans.values())
+    gflop = 6 * sum(220.77 * p.B * p.Hp * p.Wp / (384.0 * 1280.0) for p in model._plans.values())
+    print(f"f1 nuScenes TTA  one 6-camera sample, 5 scales x flip (60 augmented forwards on {plans}): {ms:8.2f} ms per sample = {6e3 / ms:6.1f} camera img/s "
+          f"({60e3 / ms:7.1f} augmented forwards/s, {gflop / ms:6.1f} TFLOP/s f32-equivalent on the padded canvases); {n} detections after the sample aggregation")
+
+
 def eval_lines():
     from dd3d_amd.evaluators import rotate_iou as R
     rng = np.random.default_rng(0)
@@ -95,5 +117,6 @@ def mapper_line():
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
     tta_lines()
+    nusc_tta_line()
     eval_lines()
     mapper_line()

@@ -25,7 +25,7 @@ for g, k, c in sorted(cands)[-1:]:
     h, m = sum(c.get("TCC_HIT_sum", [0])), sum(c.get("TCC_MISS_sum", [0]))
     out[k] = {"images_per_launch": $B, "hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
               "tcc_hit_rate": round(h / (h + m), 4) if h + m else None, "launches_averaged": len(c["FETCH_SIZE"]), "grid_threads": g,
-              "collected": "round 5, tests/tools/tower_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE (own pass) and --pmc WRITE_SIZE TCC_HIT_sum "
+              "collected": "round 6, tests/tools/tower_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE (own pass) and --pmc WRITE_SIZE TCC_HIT_sum "
                            "TCC_MISS_sum (own pass) over tests/gpu_pmc_probe.py towers.1,towers.2 4 $B; FETCH_SIZE x 2 x 1024 B (gfx950 reports half the bytes "
                            "of wide coalesced reads, MI355X_MICROARCH.md section HBM), WRITE_SIZE x 1024 B"}
 json.dump(out, open("$R/$OUT", "w"), indent=1)
