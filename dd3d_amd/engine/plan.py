@@ -171,6 +171,14 @@ class PlanBase:
         """Host view of the last forward's read-back words: waits for the copy `fetch()` enqueued (or, when the forward was issued without
         one -- a test replaying launches by hand -- packs and copies now, on the current stream)."""
         from types import SimpleNamespace
+        if self.dry_run:  # (host-order tests on dry-run plans: the same words straight off the plan's host tensors)
+            det_count = getattr(self, "det_count", None)
+            gathered = getattr(self, "gathered", None)
+            flags = torch.zeros((0, 2), dtype=torch.int32)
+            if gathered is not None and getattr(self, "exchange", False) and self.math == hip.MATH_F16X2:
+                flags = gathered.view(self.world_size, self.record_len)[:, self.flags_off:self.flags_off + 2].view(torch.int32).clone()
+            return SimpleNamespace(status=int(self.status), counts=det_count.clone() if det_count is not None else torch.zeros(0, dtype=torch.int32),
+                                   amax=self.amax_values() if (self.amax_names and self.math == hip.MATH_F16X2) else torch.zeros(0), flags=flags)
         self._ensure_readback()
         if self._rb_cache is not None:
             return self._rb_cache
