@@ -78,8 +78,8 @@ def kernel_signature(op):
                 pass
             if nsb is None:
                 nsb, nsa = row_rings_default(np_, bm, bn, wm * wn)
-            chain = ", true" if getattr(op, "chain", False) else ""  # (rocprofv3 prints the ninth template argument only when it is not the default)
-            return f"dd3d::conv_igemm_planes_row_kernel<{tm}, {tn}, {wm}, {wn}, {nsb}, {op.math}, {sk}, {nsa}{chain}>"
+            chain = "true" if getattr(op, "chain", False) else "false"  # (CHAIN: dependent segments in one launch, dd3d_conv_launch.chain)
+            return f"dd3d::conv_igemm_planes_row_kernel<{tm}, {tn}, {wm}, {wn}, {nsb}, {op.math}, {sk}, {nsa}, {chain}>"
         stage = np_ * (bm + bn) * 64
         ns = max(2, min(4, ((144 if (wm * wn == 8 or stage > 32768) else 72) * 1024) // stage))
         return f"dd3d::conv_igemm_planes_kernel<{tm}, {tn}, {wm}, {wn}, {ns}, {op.math}, {sk}, 0>"

@@ -123,7 +123,7 @@ def test_dependent_convolutions_become_chain_launches(kitti_dla34, hiplib, monke
     sg = c.desc["segs"]
     assert sg[3]["res"].buf is sg[1]["out"].buf and sg[3]["res"].c0 == sg[1]["out"].c0 and all(sg[1]["res"].buf is not q["out"].buf or sg[1]["res"].c0 != q["out"].c0 for q in sg)
     from dd3d_amd.engine import kernel_signature
-    assert kernel_signature(chains[-1]).endswith("false, 2, true>") and kernel_signature(by_name["towers.0"]).endswith("false, 2>")
+    assert kernel_signature(chains[-1]).endswith("false, 2, true>") and kernel_signature(by_name["towers.0"]).endswith("false, 2, false>")
     for mode, want in (("backbone", 6), ("towers", 1)):
         monkeypatch.setenv("DD3D_CHAIN", mode)
         p = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)
