@@ -360,3 +360,37 @@ def test_kitti_bev_nms_matches_oracle(hiplib, kitti_dla34):
     assert sum(len(r["scores"]) for r in ref) < 2 * cfg.DD3D.FCOS2D.INFERENCE.POST_NMS_TOPK  # something got suppressed
     for i in range(2):
         _check_final(out[i], ref[i])
+
+
+def test_readback_record_equals_the_device_state(hiplib, kitti_dla34):
+    """engine.PlanBase.fetch / readback (round 6): the forward's last launch packs detection counts, status word and range-guard maxima
+    (dd3d_pack_readback), ONE asynchronous copy into pinned memory follows the forward, `collect` reads nothing else from the device.  The
+    record must equal what the device holds, be re-used by further collects of the same forward, and be replaced by the next forward."""
+    from dd3d_amd.synthetic import make_inputs
+    cfg, _, sd = kitti_dla34
+    model = gpu_model(cfg, sd, use_graph=True)
+    a, b = make_inputs(2, 128, 256, seed=5), make_inputs(2, 128, 256, seed=77)
+    out_a = model(a)
+    plan = model.get_plan(2, 128, 256)
+    rb = plan.readback()
+    assert rb is plan.readback()  # cached: the requests sharing a forward read one record
+    assert rb.status == 0 and torch.equal(rb.counts, plan.det_count.cpu()) and rb.counts.tolist() == [len(o["instances"]) for o in out_a]
+    assert torch.equal(rb.amax, plan.amax_values()) and rb.amax.numel() == len(plan.amax_names) and float(rb.amax.max()) > 0
+    assert rb.flags.shape == (0, 2)  # (no exchange: no ranks' verdicts)
+    out_b = model(b)
+    rb2 = plan.readback()
+    assert rb2 is not rb and torch.equal(rb2.counts, plan.det_count.cpu()) and rb2.counts.tolist() == [len(o["instances"]) for o in out_b]
+    # a forward issued launch by launch WITHOUT the copy (a test replaying by hand): readback packs and fetches on demand
+    model.stage_inputs(a, plan=plan)
+    plan.launch()
+    torch.cuda.synchronize()
+    rb3 = plan.readback()
+    assert rb3.counts.tolist() == rb.counts.tolist()
+    # the status word travels in the record: an overflow raised by collect() comes out of it, with the sample that sizes the next plane scale
+    plan.status.fill_(1)
+    plan.launch()  # (the stem launch does not clear the status word: it is sticky until read)
+    torch.cuda.synchronize()
+    from dd3d_amd.engine import HalfRangeOverflow
+    with pytest.raises(HalfRangeOverflow) as ei:
+        plan.check_status(plan.readback())
+    assert ei.value.sampled_max_abs is not None and ei.value.sampled_max_abs > 0 and int(plan.status.cpu()) == 0
