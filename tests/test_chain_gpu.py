@@ -10,9 +10,9 @@ from tests.util import bundle, gpu_model
 pytestmark = pytest.mark.gpu
 
 
-def _forward(cfg, sd, inputs, chain, monkeypatch, graph=True):
+def _forward(cfg, sd, inputs, chain, monkeypatch, graph=True, math=None):
     monkeypatch.setenv("DD3D_CHAIN", chain)
-    model = gpu_model(cfg, sd, use_graph=graph)
+    model = gpu_model(cfg, sd, use_graph=graph, math=math)
     plan, sizes = model.stage_inputs(inputs)
     for _ in range(3):  # the third forward runs on warm caches and counters that earlier launches have used and cleared
         plan.run()
@@ -54,6 +54,21 @@ def test_chain_launches_equal_one_launch_per_convolution(hiplib, monkeypatch, ex
     _same_plan_state(pc, pf)
     for op in chains:  # the counters are zero again
         assert int(op.chain_sync.abs().sum()) == 0, op.name
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("math", ["bf16x3", "bf16x2", "bf16"])
+def test_chain_launches_in_the_other_split_operand_modes(hiplib, monkeypatch, math):
+    """The CHAIN instantiations exist for every split-plane arithmetic (three planes for bf16x3: another staging layout of the write-through
+    stores, six 16-byte residual pieces): the same bit-for-bit comparison on the small DLA-34 case."""
+    from dd3d_amd.engine import ConvOp
+    from dd3d_amd.synthetic import make_inputs
+    cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti")
+    inputs = make_inputs(2, 128, 256)
+    mc, pc, _ = _forward(cfg, sd, inputs, "1", monkeypatch, math=math)
+    mf, pf, _ = _forward(cfg, sd, inputs, "0", monkeypatch, math=math)
+    assert any(isinstance(op, ConvOp) and op.chain for op in pc.ops) and not any(isinstance(op, ConvOp) and op.chain for op in pf.ops)
+    _same_plan_state(pc, pf)
 
 
 @pytest.mark.timeout(900)
