@@ -31,8 +31,10 @@ from dd3d_amd.engine.tiling import MATH_NAMES
 
 class ForwardPlan(PlanBase, BackboneLowering):
     """Static launch plan of DD3D.forward (inference) for one (B, Hp, Wp)."""
-    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0, exchange=None, camera_sharded=False):
+    def __init__(self, model, B, Hp, Wp, device=None, world_size=1, dry_run=False, rank=0, exchange=None, camera_sharded=False, tile_policy=None):
         super().__init__(device or model.device, dry_run=dry_run)
+        from dd3d_amd.engine.tiling import default_tile_policy
+        self.tile_policy = default_tile_policy() or tile_policy or getattr(model, "tile_policy", None) or "latency"
         self.camera_sharded = camera_sharded
         # the candidate exchange between select/decode and NMS exists when there are several ranks; `exchange=True` keeps its
         # buffers and the two-phase launch for one rank too (single-GPU check of the RCCL transport, tests/gpu_rccl_check.py)

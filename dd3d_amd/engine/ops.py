@@ -12,7 +12,7 @@ from dd3d_amd import hip
 from dd3d_amd.layers import fold_norm
 
 from dd3d_amd.engine.packing import pack_smallc_bf16x3, pack_smallc_f16x2
-from dd3d_amd.engine.tiling import MATH_TILES, PLANE_TILES, choose_tiling
+from dd3d_amd.engine.tiling import MATH_TILES, PLANE_TILES, choose_tiling, preferred_tile
 
 
 class FusedStemOp:
@@ -108,11 +108,14 @@ class ConvOp:
         if math in (hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2) and not in_planes:
             raise ValueError(f"conv {name}: math mode {math} reads split-plane input only; its input buffer has none")
         self.math, self.in_planes = math, in_planes
-        cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math, planes=in_planes)
+        cfg, sk = choose_tiling(m_list, meta["N"], meta["Kpad"], stride, math, planes=in_planes, policy=getattr(plan, "tile_policy", "latency"))
         if tile is not None:
             if tile not in (PLANE_TILES if in_planes else MATH_TILES[math]):
                 raise ValueError(f"conv {name}: tile {hip.TILE_NAMES[tile]} is not instantiated for math mode {math}")
             cfg = tile
+            pref = preferred_tile(m_list, meta["N"], meta["Kpad"], stride, math, planes=in_planes, policy=getattr(plan, "tile_policy", "latency"))
+            if pref is not None and splitk is None:  # a sweep's override / the throughput table names this exact shape
+                cfg, sk = pref
         if splitk is not None:
             sk = splitk
         if cfg == hip.TILE_256x256_W8 and any(sg.get("res") is not None for sg in segs):

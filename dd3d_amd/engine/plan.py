@@ -82,6 +82,9 @@ class PlanBase:
         # consumers read planes: dd3d_conv_seg.res_mode 2 / 3, dd3d_maxpool2x2_planes_in).  DD3D_PLANES_ONLY=0 keeps round 3's f32 twins
         # and the separate top-down kernels (A/B measurements).
         self.planes_only = os.environ.get("DD3D_PLANES_ONLY", "1") != "0"
+        # "latency" (one plan at a time: the measured per-launch table) or "throughput" (the plan shares the chip with other plans:
+        # tiling.THROUGHPUT_TILE_TABLE first); ForwardPlan takes the runner's / the model's choice, DD3D_TILE_POLICY overrides
+        self.tile_policy = "latency"
         self.ops = OpList(self)
         self.bufs = {}
         self.graph = None

@@ -128,16 +128,46 @@ def _tile_overrides():
     return out
 
 
-def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False):
+# Throughput policy (round 6): launch plans that run with OTHER plans in flight (PipelinedForward slots covering several requests) pay for
+# CU-time, not for one launch's latency.  The short-K 3 x 3 convolutions of the backbone are bound by the LDS-DMA instructions a CU can issue
+# (one 1-KiB piece per ~57 cycles), and most of a small tile's pieces are FILTER rows every block streams again: a 256-row tile with little
+# split-K moves half the filter bytes per MFMA of the 128-row tile the latency table picks -- slower alone (fewer blocks: +8 % on a slot run
+# by itself), faster in the issue mode (+2 % on the driver command, profiles/r06j_bm256_sweep.txt).  {tile_key: [tile, splitk]}, measured in situ.
+THROUGHPUT_TILE_TABLE = {m: _load_tile_table(n + "_planes_throughput") for n, m in (("f16x2", hip.MATH_F16X2), )}
+
+
+def default_tile_policy():
+    """DD3D_TILE_POLICY=latency|throughput overrides what the runners choose (latency: one plan at a time; throughput: several in flight)."""
+    v = os.environ.get("DD3D_TILE_POLICY", "").strip().lower()
+    return v if v in ("latency", "throughput") else None
+
+
+def preferred_tile(m_list, N, Kpad, stride=1, math=0, planes=False, policy="latency"):
+    """(tile_cfg, splitk) that DD3D_TILE_OVERRIDE or -- for the throughput policy -- THROUGHPUT_TILE_TABLE names for this exact shape, else None:
+    what wins even over a tile the plan builder asks for explicitly (the narrow predictors)."""
+    key = tile_key(m_list, N, Kpad, stride)
+    hit = _tile_overrides().get(key)
+    if hit is None and planes and policy == "throughput":
+        hit = THROUGHPUT_TILE_TABLE.get(math, {}).get(key)
+    if hit is None:
+        return None
+    cfg = next(c for c, nm in hip.TILE_NAMES.items() if nm == hit[0])
+    return (PLANE_TILE_ALIAS.get(cfg, cfg) if planes else cfg), int(hit[1])
+
+
+def choose_tiling(m_list, N, Kpad, stride=1, math=0, planes=False, policy="latency"):
     """Pick (tile_cfg, splitk): a measured table entry when this exact shape has one, else minimise the modelled makespan
     on 256 CUs: every block costs BM*BN*K MACs on its CU's matrix pipe (partial tiles cost the same as full ones); split-K
     adds the partial-sum exchange.  `planes`: the split-plane-input kernel (its own measured table; the f32-input kernel's
-    entries serve as the fallback for the three-term mode, their two-K-tiles-per-barrier variants mapped to the plain tile)."""
+    entries serve as the fallback for the three-term mode, their two-K-tiles-per-barrier variants mapped to the plain tile).
+    `policy` "throughput": entries of THROUGHPUT_TILE_TABLE win over the latency table (plans that share the chip with other plans)."""
     allowed = PLANE_TILES if planes else MATH_TILES[math]
     # (measured and dropped: forcing the small convolutions onto 4-wave blocks with <= 48 KiB of LDS so that other streams' blocks could
     # share their CUs -- pipelined throughput 960 -> 921 img/s, profiles/r02_notes.md)
     key = tile_key(m_list, N, Kpad, stride)
     hit = PLANE_TILE_TABLE[math].get(key) if planes else TILE_TABLE[math].get(key)
+    if planes and policy == "throughput":
+        hit = THROUGHPUT_TILE_TABLE.get(math, {}).get(key, hit)
     forced = _tile_overrides().get(key)  # DD3D_TILE_OVERRIDE="M[+M..],N,Kpad,stride=tile:splitk;..." (measurement sweeps, tests/gpu_issue_sweep.sh)
     if forced is not None:
         hit = forced

@@ -68,6 +68,9 @@ class DD3D(nn.Module):
         # plane scale of the f16x2 arithmetic (a power of two; None: DD3D_F16_ACT_SCALE / 16).  The range guard's staged fallback lowers it
         # 16 -> 4 -> 1 on an overflow before it gives up the f16x2 speed (dd3d_amd.engine.plan.relax_arithmetic)
         self.act_scale = None
+        # None / "latency": launch plans tiled for one forward at a time; "throughput": for plans that share the chip with other plans in
+        # flight (dd3d_amd.engine.tiling.THROUGHPUT_TILE_TABLE; PipelinedForward slots covering several requests choose it themselves)
+        self.tile_policy = None
         self.training = False
 
     @property
@@ -105,7 +108,7 @@ class DD3D(nn.Module):
 
     def get_plan(self, B, Hp, Wp, world_size=1, rank=0, exchange=None, camera_sharded=False):
         exchange = world_size > 1 if exchange is None else bool(exchange)
-        key = (B, Hp, Wp, world_size, rank, exchange, bool(camera_sharded), self.math, self.act_scale) + self._sync_flags()
+        key = (B, Hp, Wp, world_size, rank, exchange, bool(camera_sharded), self.math, self.act_scale, getattr(self, "tile_policy", None)) + self._sync_flags()
         plan = self._plans.pop(key, None)
         if plan is None:
             plan = ForwardPlan(self, B, Hp, Wp, world_size=world_size, rank=rank, exchange=exchange, camera_sharded=camera_sharded)

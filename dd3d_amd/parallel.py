@@ -540,7 +540,10 @@ class PipelinedForward:
         rt = self.rt
         for slot in self.slots:
             extra = dict(device="cpu", dry_run=True) if rt.dry_run else {}
-            p = ForwardPlan(self.model, self.B * self.microbatch, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange, **extra)
+            # several slots in flight: tiled for CU-time, not for one launch's latency (engine.tiling.THROUGHPUT_TILE_TABLE; entries exist
+            # for the plan geometries measured in situ, everything else falls back to the per-launch table)
+            policy = "throughput" if (len(self.slots) > 1 and self.microbatch > 1) else None
+            p = ForwardPlan(self.model, self.B * self.microbatch, Hp, Wp, world_size=self.world, rank=self.rank, exchange=self.exchange, tile_policy=policy, **extra)
             rt.warm(p)
             slot.plan = p
             slot.pre_graph = rt.capture(slot, p, 0, p.num_pre_nms_ops, "pre")

@@ -116,7 +116,7 @@ def mapper_line():
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0))
+    mapper_line()  # (first: the launch plans of the TTA lines below take 14+ GB; the small allocations of this loop then measure the allocator)
+    eval_lines()
     tta_lines()
     nusc_tta_line()
-    eval_lines()
-    mapper_line()

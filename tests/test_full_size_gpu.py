@@ -63,6 +63,7 @@ def test_dla34_kitti_four_image_plan_matches_oracle(hiplib):
     from tests.parity import parity_report
     cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti")
     model = gpu_model(cfg, sd, use_graph=True)
+    model.tile_policy = "throughput"  # what a pipeline slot of several requests builds its plan with (engine.tiling.THROUGHPUT_TILE_TABLE): the TIMED plan's tiles
     B = 4
     inputs = [make_inputs(1, 384, 1280, seed=1000 + j)[0] for j in range(B)]  # (the bench's request images)
     inputs[2]["image"] = inputs[2]["image"][:, :370, :1224].contiguous()
@@ -72,6 +73,8 @@ def test_dla34_kitti_four_image_plan_matches_oracle(hiplib):
     assert (plan.B, plan.Hp, plan.Wp) == (4, 384, 1280) and plan.graph is not None
     towers = [op for op in plan.ops if op.name.startswith("towers.")]
     assert towers and all(op.info["tile_name"] == "256x256w8" for op in towers), [op.info["tile_name"] for op in towers]
+    by_name = {op.name: op for op in plan.ops}
+    assert plan.tile_policy == "throughput" and by_name["level3.tree2.tree1.conv2"].info["tile_name"] == "256x128" and by_name["level5.tree2.conv1"].info["splitk"] == 4
     plan.run()
     torch.cuda.synchronize()
     plan.check_status()
@@ -88,7 +91,7 @@ def test_dla34_kitti_four_image_plan_matches_oracle(hiplib):
     print(f"[margin] DLA-34 four-image plan: {sum(len(c['scores']) for c in st['candidates'])} oracle candidates, {flips} on-the-cut flips")
     # four single-image requests through one pipeline slot: the same plan geometry, the same detections
     runner = PipelinedForward(model, 1, 384, 1280, depth=2, compute_streams=2, microbatch=4)
-    assert towers[0].info["tile_name"] == [op for op in runner.plan.ops if op.name.startswith("towers.")][0].info["tile_name"]
+    assert runner.plan.tile_policy == "throughput" and [getattr(op, "info", {}).get("tile_name") for op in runner.plan.ops] == [getattr(op, "info", {}).get("tile_name") for op in plan.ops]
     handles = [runner.submit([x]) for x in inputs]  # (the raw-KITTI-sized frame lands on the plan's 384 x 1280 canvas like in the batch above)
     for i, h in enumerate(handles):
         o = runner.result(h)[0]["instances"]

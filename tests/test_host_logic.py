@@ -751,3 +751,39 @@ def test_stage_inputs_fills_the_host_mirrors_and_one_flush_ships_them(kitti_dla3
         model.stage_inputs(reqs[0] + reqs[1], plan=plan, first=3, partial=True)
     model.stage_inputs(reqs[3], plan=plan, first=3, partial=True)  # flush=True: shipped at once
     assert plan.in_sizes.tolist()[3] == [128, 256]
+
+
+def test_throughput_tile_policy_of_pipeline_slots(kitti_dla34, hiplib, monkeypatch):
+    """engine.tiling.THROUGHPUT_TILE_TABLE (round 6): a launch plan that shares the chip with other plans -- a PipelinedForward slot covering
+    several requests -- tiles the backbone's short-K 3 x 3 convolutions for CU-time (256 x 128, little split-K: half the filter bytes through
+    LDS per MFMA), the plan of one forward at a time keeps the per-launch table; same buffers, same conv work; DD3D_TILE_POLICY overrides."""
+    from dd3d_amd import hip
+    from dd3d_amd.engine import ConvOp, ForwardPlan, choose_tiling
+    from dd3d_amd.parallel import HostOrderRuntime, PipelinedForward
+    cfg, model, sd = kitti_dla34
+    model.load_state_dict(sd)
+    assert choose_tiling([30720], 128, 1152, 1, hip.MATH_F16X2, planes=True)[0] != hip.TILE_256x128
+    assert choose_tiling([30720], 128, 1152, 1, hip.MATH_F16X2, planes=True, policy="throughput") == (hip.TILE_256x128, 1)
+    assert choose_tiling([7680], 256, 2304, 1, hip.MATH_F16X2, planes=True, policy="throughput") == (hip.TILE_256x128, 2)
+    assert choose_tiling([1920], 512, 4608, 1, hip.MATH_F16X2, planes=True, policy="throughput") == (hip.TILE_256x128, 4)
+    assert choose_tiling([30720], 128, 1152, 1, hip.MATH_BF16X3, planes=True, policy="throughput")[0] != hip.TILE_256x128  # (measured for f16x2 only)
+    lat = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True)
+    thr = ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True, tile_policy="throughput")
+    tiles = lambda p: {op.name: (op.info["tile_name"], op.info["splitk"]) for op in p.ops if isinstance(op, ConvOp)}
+    tl, tt = tiles(lat), tiles(thr)
+    changed = sorted(n for n in tl if tl[n] != tt[n])
+    assert len(changed) == 17 and all(n.startswith(("level3", "level4", "level5")) and ".conv" in n for n in changed)  # the stride-1 3 x 3 convolutions: 7 + 7 + 3
+    assert tt["level3.tree1.tree2.conv1"] == ("256x128", 1) and tt["level4.tree2.tree1.conv2"] == ("256x128", 2) and tt["level5.tree2.conv2"] == ("256x128", 4)
+    assert tt["towers.0"] == tl["towers.0"] == ("256x256w8", 1) and lat.conv_macs == thr.conv_macs and sorted(lat.bufs) == sorted(thr.bufs)
+    runner = PipelinedForward(model, 1, 384, 1280, depth=2, microbatch=4, runtime=HostOrderRuntime())
+    assert runner.plan.tile_policy == "throughput" and tiles(runner.plan) == tt
+    single = PipelinedForward(model, 1, 384, 1280, depth=2, microbatch=1, runtime=HostOrderRuntime())
+    assert single.plan.tile_policy == "latency"
+    monkeypatch.setenv("DD3D_TILE_POLICY", "latency")
+    assert PipelinedForward(model, 1, 384, 1280, depth=2, microbatch=4, runtime=HostOrderRuntime()).plan.tile_policy == "latency"
+    monkeypatch.delenv("DD3D_TILE_POLICY")
+    model.tile_policy = "throughput"  # a model-wide choice (model(batched_inputs) of a serving loop that keeps several forwards in flight)
+    try:
+        assert ForwardPlan(model, 4, 384, 1280, device="cpu", dry_run=True).tile_policy == "throughput"
+    finally:
+        model.tile_policy = None
