@@ -17,6 +17,7 @@ python -c "
 import json; d=json.load(open('$O/${TAG}_bench_serial.json')); print('one image at a time', d['value'], d['blocks']['median_images_per_s'], d['roofline']['avg_launch_us'], d['roofline']['frac'])"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --repeat-blocks 0 > $O/bench_prof.json 2>/dev/null
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
+python $R/tests/tools/kernel_stats_by_grid.py $(find $O/prof -name "*kernel_trace.csv" | head -1) > $O/${TAG}_bench_kernel_stats_by_grid.csv; head -4 $O/${TAG}_bench_kernel_stats_by_grid.csv | cut -c1-200
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_serial -o p -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --pipeline 0 --no-cpu-baseline --repeat-blocks 0 > $O/bench_prof_serial.json 2>/dev/null
 cp $(find $O/prof_serial -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_serial_kernel_stats.csv
 head -6 $O/${TAG}_bench_kernel_stats.csv | cut -c1-200; head -4 $O/${TAG}_bench_serial_kernel_stats.csv | cut -c1-200
