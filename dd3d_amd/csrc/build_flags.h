@@ -101,4 +101,19 @@
 #else
 #define DD3D_BF_17 ""
 #endif
-#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13 DD3D_BF_14 DD3D_BF_15 DD3D_BF_16 DD3D_BF_17
+#ifdef DD3D_ROW_STAMP
+#define DD3D_BF_18 " DD3D_ROW_STAMP=" DD3D_BF_STR(DD3D_ROW_STAMP)
+#else
+#define DD3D_BF_18 ""
+#endif
+#ifdef DD3D_ROW_B_WAVES
+#define DD3D_BF_19 " DD3D_ROW_B_WAVES=" DD3D_BF_STR(DD3D_ROW_B_WAVES)
+#else
+#define DD3D_BF_19 ""
+#endif
+#ifdef DD3D_ROW_B_SADDR
+#define DD3D_BF_20 " DD3D_ROW_B_SADDR=" DD3D_BF_STR(DD3D_ROW_B_SADDR)
+#else
+#define DD3D_BF_20 ""
+#endif
+#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13 DD3D_BF_14 DD3D_BF_15 DD3D_BF_16 DD3D_BF_17 DD3D_BF_18 DD3D_BF_19 DD3D_BF_20

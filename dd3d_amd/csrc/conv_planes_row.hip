@@ -43,7 +43,28 @@ DD3D_NOTE_BUILD_FLAGS
 #define DD3D_EPI_T 1  // 1: transposed accumulators + the 16-bytes-per-lane epilogue (conv_common.h::conv_epilogue_t); 0: round-3 form (A/B)
 #endif
 
+#ifndef DD3D_ROW_B_WAVES
+#define DD3D_ROW_B_WAVES 0  // > 0: in the 8-wave tiles only the first DD3D_ROW_B_WAVES waves (one per SIMD: the ones the MFMA arbiter favours) issue the filter stages' LDS-DMA (measured neutral: r06o)
+#endif
+#ifndef DD3D_ROW_B_SADDR
+#define DD3D_ROW_B_SADDR 1  // 1: filter pieces use the scalar-base form of the LDS-DMA (s[base] + a constant 32-bit lane offset: no per-piece address arithmetic, half the address registers; round 6: towers -0.8 %, one image -1.1 %, profiles/r06o_bwaves_ab.txt); 0: the builtin's 64-bit-per-lane form (A/B)
+#endif
+#ifndef DD3D_ROW_STAMP
+#define DD3D_ROW_STAMP 0  // 1: every wave of the first 512 blocks records s_memtime stamps of its phases (timing probe: dd3d_debug_row_stamps; results unchanged)
+#endif
+
 namespace dd3d {
+
+#if DD3D_ROW_STAMP
+// per wave: [0] entry, [1] prologue issued, [2] first data landed (prologue barrier passed), [3] K loop done, [4] kernel end,
+// [5] sum over steps of (after-barrier -> own work done: fragment reads landed, MFMAs issued), [6] of the vmcnt wait, [7] of the barrier wait
+__device__ unsigned long long g_row_stamps[512 * 8 * 8];
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#endif
 
 // CHAIN (dd3d_conv_launch.chain): the launch's segments DEPEND on each other -- segment i reads, as its input (and possibly as its
 // residual), what segments < i of the same launch write: the stride-1 3 x 3 convolutions of a DLA level (dla.py:50-62, conv1 -> conv2 +
@@ -71,19 +92,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   constexpr int A_STAGE = NP * PLA, B_STAGE = NP * PLB;
   constexpr int B_BASE = NSA * A_STAGE;
   constexpr int NPA = (AROWS / 16) * NP, NPB = (BN / 16) * NP;  // 1-KiB pieces of an A stage / a B stage
-  constexpr int PA = (NPA + NW - 1) / NW, PB = (NPB + NW - 1) / NW;  // per wave (the surplus re-fetches the last piece)
+  // Filter (B) pieces may be issued by the first BW waves only (DD3D_ROW_B_WAVES): of the two waves that share a SIMD the matrix pipe serves the
+  // first-dispatched one first (measured: its 48 MFMAs of a step are out after 2370 cycles, the other's after 3590, profiles/r06n_*), so the
+  // second runs the end of every step ALONE and each of its LDS-DMA issue stalls (~60 cycles a piece) idles the pipe; the favoured wave's stalls
+  // are covered by the other's MFMAs.  Built, parity-green, and measured NEUTRAL (towers 322 vs 321 us, profiles/r06o_bwaves_ab.txt): a knob, off.
+  constexpr int BW = (NW == 8 && DD3D_ROW_B_WAVES > 0 && DD3D_ROW_B_WAVES < NW) ? DD3D_ROW_B_WAVES : NW;
+  constexpr int PA = (NPA + NW - 1) / NW, PB = (NPB + BW - 1) / BW;  // per wave (the surplus re-fetches the last piece)
   constexpr int ZERO_OFF = B_BASE + NSB * B_STAGE;  // 16 zero bytes invalid taps read (64 reserved)
   constexpr int EV_OFF = ZERO_OFF + 64;              // [scale | bias | lo][BN] floats of the epilogue (conv_epilogue_t)
   static_assert(NSB >= 2 && NSB <= 6 && NSA >= 2 && NSA <= 4 && EV_OFF + 12 * BN <= 160 * 1024, "LDS rings");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* lds = reinterpret_cast<unsigned char*>(smem);
   typedef unsigned char __attribute__((address_space(3))) * ldsbp;
+#if DD3D_ROW_B_SADDR
+  const unsigned lds_base32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(ldsbp)lds);  // LDS byte address of the rings (M0 of the scalar-base LDS-DMA)
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN;
   const int wn = wave - wm * WN;
+  const bool bwave = BW == NW || wave < BW;  // (wave-uniform) this wave issues filter pieces
+#if DD3D_ROW_STAMP
+  unsigned long long st_t[8] = {stamp_now(), 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = 0;
+#endif
 
   int bid, kslice;
   if constexpr (CHAIN) {  // launch order = dependency order; the K slices of a tile are neighbours (a 2-D grid would dispatch ALL items' slice 1 last)
@@ -131,11 +165,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     a_dst[q] = pl * PLA + rb * 1024;
     a_pix[q] = m0 - 1 + rb * 16 + (lane >> 2);
   }
+#if DD3D_ROW_B_SADDR
+  unsigned b_src[PB];  // byte offset of this lane's filter row from the filter base: K-tile 0, plane and k-slot included
+#else
   gcbp b_src[PB];  // this lane's filter row, K-tile 0, plane and k-slot included
+#endif
   int b_dst[PB];
 #pragma unroll
   for (int q = 0; q < PB; ++q) {
-    const int piece = min(q * NW + wave, NPB - 1);
+    const int piece = min(q * BW + (BW == NW ? wave : wave % BW), NPB - 1);
     const int rb = piece / NP, pl = piece - rb * NP;
 #if DD3D_EPI_T  // LDS row R of the B stage holds filter row chan_of_row(R) of its 32-row block (conv_common.h::conv_epilogue_t)
     const int brow = rb * 16 + (lane >> 2);
@@ -144,7 +182,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     const int n = min(n0 + rb * 16 + (lane >> 2), a.Npad - 1);  // rows past Npad feed columns >= N, which are never stored
 #endif
     b_dst[q] = B_BASE + pl * PLB + rb * 1024;
+#if DD3D_ROW_B_SADDR
+    b_src[q] = (unsigned)((long)n * nk * (NP * 64) + pl * 64 + slot16);  // (launch_conv_planes_row checks that the filter stays below 4 GiB)
+#else
     b_src[q] = g_w + (long)n * nk * (NP * 64) + pl * 64 + slot16;
+#endif
   }
 
   // ---- streams: A walks the groups (chunk, dh), B walks the K-tiles; past the end both re-fetch their last element (exact DMA counts)
@@ -170,9 +212,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   };
   auto emit_b = [&](int stage) {  // K-tile ld_kt, then advance
     const long koff = (long)ld_kt * (NP * 64);
+#if DD3D_ROW_B_SADDR
+    // global_load_lds_dwordx4 vOFFSET, s[BASE:BASE+1]: address = base + zext(lane offset); the LDS destination of the wave instruction = M0 + 16 lane.
+    // (The builtin only emits the 64-bit-per-lane form.  The compiler does not see these loads: its own waits only get more conservative --
+    // vector-memory loads return in order -- and the K loop's waits are explicit.)
+    // (readfirstlane: the operands ARE wave-uniform; this makes the compiler keep them in scalar registers whatever it proves about them)
+    const unsigned long kaddr = (unsigned long)(g_w + koff);
+    const unsigned long kbase = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(kaddr >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kaddr);
+    const unsigned lds0 = lds_base32 + (unsigned)(stage * B_STAGE);
+    // M0 is on the clobber list: the compiler re-materialises it before its own LDS-DMA sequences (the activation pieces).  clang warns that it
+    // will not PRESERVE a reserved register across the statement -- nothing here asks it to.  (Saving and restoring M0 by hand instead is WRONG:
+    // the compiler may then move its own `s_mov m0` across the unannounced writes; the convolution tests caught that form.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + (unsigned)b_dst[q]), "v"(b_src[q]), "s"(kbase) : "memory", "m0");
+#pragma clang diagnostic pop
+#else
 #pragma unroll
     for (int q = 0; q < PB; ++q)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(b_src[q] + koff), (ldsbp)(lds + stage * B_STAGE + b_dst[q]), 16, 0, 0);
+#endif
     ld_kt += (ld_kt + 1 < kt_end);
   };
 
@@ -294,8 +356,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       // they were derived for (the B stages only moved to the front), so the waits stay sufficient.
       const int dep = s.reserved;  // 1 + index of the segment of this launch that writes this segment's input; 0: nobody does
 #if DD3D_CHAIN_B_FIRST
+      if (bwave) {
 #pragma unroll
-      for (int d = 0; d < NSB; ++d) emit_b(d);
+        for (int d = 0; d < NSB; ++d) emit_b(d);
+      }
 #endif
       if (dep > 0) {
         if (tid == 0) {
@@ -345,7 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     }
 #pragma unroll
     for (int d = 0; d < NSB; ++d) {
-      emit_b(d);
+      if (bwave) emit_b(d);
       const int k3 = NSB + 2 - d;  // = 3 k of the A group that follows this B, if any
       if (k3 % 3 == 0 && k3 / 3 >= 1 && k3 / 3 <= NSA) {
         prepare_a();
@@ -354,10 +418,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     }
     constexpr int DA0 = NSB + 2 - 3 * NSA;  // (UPFRONT == 0) A(0) follows B(DA0)
     constexpr int PRO_WAIT = UPFRONT > 0 ? (NSB - 1) * PB + (NSA - UPFRONT) * PA : (NSB - 1 - DA0) * PB + (NSA - 1) * PA;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRO_WAIT) : "memory");
+    constexpr int PRO_WAIT_NOB = UPFRONT > 0 ? (NSA - UPFRONT) * PA : (NSA - 1) * PA;  // a wave without filter pieces: only its A groups count
+    if (bwave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRO_WAIT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PRO_WAIT_NOB) : "memory");
     }
+#if DD3D_ROW_STAMP
+    st_t[1] = stamp_now();
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#if DD3D_ROW_STAMP
+    st_t[2] = st_last = stamp_now();
+#endif
 #if DD3D_EPI_T
     epi_store_vectors<BN, NTHR>(lds + EV_OFF, tid, evv);  // published by the first step's barrier
 #endif
@@ -386,13 +458,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       constexpr int steady = (NSB - 2) * PB + a_in_flight * PA;
       constexpr int a_cap = (3 * (NSA - 1) - 1) * PB + (NSA - 2) * PA;
       constexpr int wait_n = (dw == 2 && steady > a_cap) ? a_cap : steady;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(wait_n) : "memory");
+      // (a wave without filter pieces, DD3D_ROW_B_WAVES: the same counts with PB = 0)
+      constexpr int steady_nob = a_in_flight * PA, a_cap_nob = (NSA - 2) * PA;
+      constexpr int wait_nob = (dw == 2 && steady_nob > a_cap_nob) ? a_cap_nob : steady_nob;
+#if DD3D_ROW_STAMP
+      const unsigned long long st_a = stamp_now();  // (its lgkmcnt(0) = the fragment reads of this phase have landed)
+#endif
+      if (BW == NW || bwave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(wait_n) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(wait_nob) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if DD3D_ROW_STAMP
+      const unsigned long long st_b = stamp_now();
+#endif
       __builtin_amdgcn_s_barrier();  // everyone: K-tile s+1 (and, after dw == 2, the next A group) landed; B stage sb / A stage sa free
       asm volatile("" ::: "memory");
+#if DD3D_ROW_STAMP
+      {
+        const unsigned long long st_c = stamp_now();
+        st_t[5] += st_a - st_last, st_t[6] += st_b - st_a, st_t[7] += st_c - st_b;
+        st_last = st_c;
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B: refill the freed stages; chunk-0 fragments of the next K-tile under the chunk-1 MFMAs
-      emit_b(sb);
+      if (BW == NW || bwave) emit_b(sb);
       if constexpr (dw == 2) emit_a(sa);
       sb = sb == NSB - 1 ? 0 : sb + 1;
       constexpr int ndw = dw == 2 ? 0 : dw + 1;
@@ -400,7 +489,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       const int ndh = dw == 2 ? (dh == 2 ? 0 : dh + 1) : dh;
       read_frags(nsa, sb, ndw, ndh * 3 + ndw, C0);  // (past the end: surplus data, never used)
       mfma_chunk(C1);
-      sched_barrier_phase<TM * TN * NPROD, (TM + TN) * NP, PB + (dw == 2 ? PA : 0)>();
+      sched_barrier_phase<TM * TN * NPROD, (TM + TN) * NP, (BW == NW && !DD3D_ROW_B_SADDR ? PB : 0) + (dw == 2 ? PA : 0)>();
     };
     constexpr std::integral_constant<int, 0> D0{};
     constexpr std::integral_constant<int, 1> D1{};
@@ -415,6 +504,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       sa = sa == NSA - 1 ? 0 : sa + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus fetches land before the LDS is released
+#if DD3D_ROW_STAMP
+    st_t[3] = stamp_now();
+#endif
   }
 
   if constexpr (SK) {
@@ -436,6 +528,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 #else
   static_assert(!CHAIN, "dependent segments need the transposed epilogue (write-through plane stores)");
   conv_epilogue<TM, TN, MODE, WM, WN>(a, s, acc, m0, n0, wm, wn, lane);
+#endif
+#if DD3D_ROW_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stores acknowledged: what the next launch waits for)
+  st_t[4] = stamp_now();
+  if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 512) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_row_stamps[((size_t)blockIdx.x * 8 + (wave & 7)) * 8 + i] = st_t[i];
+  }
 #endif
   if constexpr (CHAIN) {
     // this tile is in memory: every wave has its write-through stores acknowledged, then ONE agent-scope arrival on the m-tile's counter
@@ -609,6 +709,10 @@ bool conv_planes_row_applicable(const ConvKArgs& ka) {
 }
 
 int launch_conv_planes_row(const ConvKArgs& ka, int math_mode, int tile_cfg, hipStream_t st) {
+#if DD3D_ROW_B_SADDR
+  // filter rows are addressed as base + a 32-bit byte offset per lane (at most 3 planes of Kpad halves per filter)
+  DD3D_REQUIRE((long)ka.Npad * ka.Kpad * 6 < (1l << 32), "dd3d_conv2d_igemm_f32: filter of %d x %d beyond the 4 GiB the row kernel addresses", ka.Npad, ka.Kpad);
+#endif
   switch (math_mode) {
     case DD3D_MATH_BF16X3: return launch_row_mode<DD3D_MATH_BF16X3>(ka, tile_cfg, st);
     case DD3D_MATH_BF16X2: return launch_row_mode<DD3D_MATH_BF16X2>(ka, tile_cfg, st);
@@ -619,3 +723,15 @@ int launch_conv_planes_row(const ConvKArgs& ka, int math_mode, int tile_cfg, hip
 }
 
 }  // namespace dd3d
+
+#if DD3D_ROW_STAMP
+// Timing probe (variant builds only, tests/gpu_row_stamp_probe.py): copies the stamps out and clears them.
+extern "C" int dd3d_debug_row_stamps(unsigned long long* out, int n) {
+  const size_t bytes = sizeof(unsigned long long) * (size_t)(n < 512 * 8 * 8 ? n : 512 * 8 * 8);
+  if (hipDeviceSynchronize() != hipSuccess) return DD3D_E_LAUNCH;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dd3d::g_row_stamps), bytes) != hipSuccess) return DD3D_E_LAUNCH;
+  static unsigned long long zeros[512 * 8 * 8];
+  if (hipMemcpyToSymbol(HIP_SYMBOL(dd3d::g_row_stamps), zeros, sizeof(zeros)) != hipSuccess) return DD3D_E_LAUNCH;
+  return DD3D_OK;
+}
+#endif
