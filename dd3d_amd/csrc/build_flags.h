@@ -116,4 +116,9 @@
 #else
 #define DD3D_BF_20 ""
 #endif
-#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13 DD3D_BF_14 DD3D_BF_15 DD3D_BF_16 DD3D_BF_17 DD3D_BF_18 DD3D_BF_19 DD3D_BF_20
+#ifdef DD3D_ROW_B_WAVES_HI
+#define DD3D_BF_21 " DD3D_ROW_B_WAVES_HI=" DD3D_BF_STR(DD3D_ROW_B_WAVES_HI)
+#else
+#define DD3D_BF_21 ""
+#endif
+#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13 DD3D_BF_14 DD3D_BF_15 DD3D_BF_16 DD3D_BF_17 DD3D_BF_18 DD3D_BF_19 DD3D_BF_20 DD3D_BF_21

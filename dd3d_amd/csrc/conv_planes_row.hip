@@ -46,6 +46,9 @@ DD3D_NOTE_BUILD_FLAGS
 #ifndef DD3D_ROW_B_WAVES
 #define DD3D_ROW_B_WAVES 0  // > 0: in the 8-wave tiles only the first DD3D_ROW_B_WAVES waves (one per SIMD: the ones the MFMA arbiter favours) issue the filter stages' LDS-DMA (measured neutral: r06o)
 #endif
+#ifndef DD3D_ROW_B_WAVES_HI
+#define DD3D_ROW_B_WAVES_HI 0  // 1: the LAST DD3D_ROW_B_WAVES waves issue the filter pieces (the ones the arbiter serves second: they issue while the first run their MFMAs)
+#endif
 #ifndef DD3D_ROW_B_SADDR
 #define DD3D_ROW_B_SADDR 1  // 1: filter pieces use the scalar-base form of the LDS-DMA (s[base] + a constant 32-bit lane offset: no per-piece address arithmetic, half the address registers; round 6: towers -0.8 %, one image -1.1 %, profiles/r06o_bwaves_ab.txt); 0: the builtin's 64-bit-per-lane form (A/B)
 #endif
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN;
   const int wn = wave - wm * WN;
-  const bool bwave = BW == NW || wave < BW;  // (wave-uniform) this wave issues filter pieces
+  const bool bwave = BW == NW || (DD3D_ROW_B_WAVES_HI ? wave >= NW - BW : wave < BW);  // (wave-uniform) this wave issues filter pieces
 #if DD3D_ROW_STAMP
   unsigned long long st_t[8] = {stamp_now(), 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = 0;
@@ -481,7 +484,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
 #endif
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B: refill the freed stages; chunk-0 fragments of the next K-tile under the chunk-1 MFMAs
+#if DD3D_ROW_STAMP > 1  // (2: slot [6] = the filter pieces' issue instead of the vmcnt wait)
+      const unsigned long long st_d = stamp_now();
+#endif
       if (BW == NW || bwave) emit_b(sb);
+#if DD3D_ROW_STAMP > 1
+      st_t[6] += stamp_now() - st_d - (st_b - st_a);
+#endif
       if constexpr (dw == 2) emit_a(sa);
       sb = sb == NSB - 1 ? 0 : sb + 1;
       constexpr int ndw = dw == 2 ? 0 : dw + 1;
