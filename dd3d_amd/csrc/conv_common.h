@@ -420,7 +420,7 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvKArgs& a, const dd3d_c
   // of them partial lines).  Staged through LDS in the memory layout (16-byte units XOR-swizzled so that both sides are conflict-free)
   // and read back in address order, every store instruction of the wave writes 1 KiB of consecutive bytes.
   constexpr int UP = NP * 4;  // 16-byte units per pixel
-  constexpr int IG = (TM * TN >= 8 || TM < 2) ? 1 : 2;  // accumulator blocks whose residuals are in flight together
+  constexpr int IG = (TM * TN >= 8 || TM % 2) ? 1 : 2;  // accumulator blocks whose residuals are in flight together (pairs need an even TM)
   constexpr int NRAW = 2 * NP > 4 ? 2 * NP : 4;          // 16-byte pieces of one block's residual (f32: 4, planes: 2 per plane)
   const int nlim = s.n_limit > 0 ? s.n_limit : a.N;
   const bool w32 = s.out != nullptr, wpl = s.out_planes != nullptr;

@@ -841,7 +841,7 @@ extern "C" int dd3d_math_planes(int32_t math_mode) {
 }
 
 extern "C" int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn) {
-  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {128, 256}, {256, 256}, {128, 32}};
+  static const int shapes[DD3D_TILE_COUNT][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 32}, {64, 128}, {256, 128}, {128, 128}, {64, 64}, {128, 64}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {128, 256}, {256, 256}, {128, 32}, {192, 256}};
   DD3D_REQUIRE(tile_cfg >= 0 && tile_cfg < DD3D_TILE_COUNT, "dd3d_conv_tile_shape: unknown tile_cfg %d", tile_cfg);
   *bm = shapes[tile_cfg][0];
   *bn = shapes[tile_cfg][1];
@@ -932,8 +932,8 @@ extern "C" int dd3d_conv2d_igemm_f32(const dd3d_conv_launch* L, void* stream) {
                    i, sg.res_mode);
       DD3D_REQUIRE(sg.res_mode != 3 || ((sg.Ho % 2) == 0 && (sg.Wo % 2) == 0), "dd3d_conv2d_igemm_f32: segment %d: res_mode 3 needs even Ho, Wo (%d x %d)", i,
                    sg.Ho, sg.Wo);
-      DD3D_REQUIRE(sg.res_mode == 0 || !L->in_planes || L->tile_cfg != DD3D_TILE_256x256_W8,
-                   "dd3d_conv2d_igemm_f32: segment %d: DD3D_TILE_256x256_W8 carries no residual", i);
+      DD3D_REQUIRE(sg.res_mode == 0 || !L->in_planes || (L->tile_cfg != DD3D_TILE_256x256_W8 && L->tile_cfg != DD3D_TILE_192x256_W8),
+                   "dd3d_conv2d_igemm_f32: segment %d: the 8-wave 256-column tiles carry no residual", i);
       const int stored = sg.n_limit > 0 ? sg.n_limit : L->N;
       DD3D_REQUIRE(sg.res_mode != 1 || !L->in_planes || ((sg.res_pitch % 4) == 0 && sg.res_pitch >= ((stored + 3) & ~3)),
                    "dd3d_conv2d_igemm_f32: segment %d: an f32 residual of the split-plane kernels is read in 16-byte pieces: res_pitch=%d must be a "

@@ -671,6 +671,9 @@ static int launch_row_mode(const ConvKArgs& ka, int tile_cfg, hipStream_t st) {
     case DD3D_TILE_256x256_W8:
       if constexpr (Planes<MODE>::NP <= 2) return launch_row_tile<4, 2, 2, 4, MODE, false>(ka, st);
       break;
+    case DD3D_TILE_192x256_W8:
+      if constexpr (Planes<MODE>::NP <= 2) return launch_row_tile<3, 2, 2, 4, MODE, false>(ka, st);
+      break;
   }
   DD3D_REQUIRE(false, "dd3d_conv2d_igemm_f32: tile_cfg %d has no row-shared split-plane kernel", tile_cfg);
 }
@@ -696,6 +699,9 @@ static int row_rings_mode(int tile_cfg, int* nsb, int* nsa) {
     case DD3D_TILE_128x256_T24: DD3D_RR(2, 4, 2, 2)
     case DD3D_TILE_256x256_W8:
       if constexpr (Planes<MODE>::NP <= 2) DD3D_RR(4, 2, 2, 4)
+      break;
+    case DD3D_TILE_192x256_W8:
+      if constexpr (Planes<MODE>::NP <= 2) DD3D_RR(3, 2, 2, 4)
       break;
   }
 #undef DD3D_RR

@@ -12,7 +12,7 @@ from dd3d_amd import hip
 from dd3d_amd.layers import fold_norm
 
 from dd3d_amd.engine.packing import pack_smallc_bf16x3, pack_smallc_f16x2
-from dd3d_amd.engine.tiling import MATH_TILES, PLANE_TILES, choose_tiling, preferred_tile
+from dd3d_amd.engine.tiling import MATH_TILES, PLANE_TILES, ROW_ONLY_TILES, choose_tiling, preferred_tile
 
 
 class FusedStemOp:
@@ -118,8 +118,10 @@ class ConvOp:
                 cfg, sk = pref
         if splitk is not None:
             sk = splitk
-        if cfg == hip.TILE_256x256_W8 and any(sg.get("res") is not None for sg in segs):
-            cfg = hip.TILE_256x128  # (the 8-wave 256 x 256 tile has no registers left for a residual in flight)
+        if cfg in ROW_ONLY_TILES and not ((meta["KH"], meta["KW"], stride, pad) == (3, 3, 1, 1) and in_planes and sk == 1):
+            cfg = hip.TILE_256x256_W8  # (instantiated for the row-shared 3 x 3 kernel only)
+        if cfg in (hip.TILE_256x256_W8, hip.TILE_192x256_W8) and any(sg.get("res") is not None for sg in segs):
+            cfg = hip.TILE_256x128  # (the 8-wave 256-column tiles have no registers left for a residual in flight)
         bm, bn = hip.TILE_SHAPES[cfg]
         arr = np.zeros(len(segs), dtype=hip.CONV_SEG_DTYPE)
         tiles = []
@@ -222,7 +224,7 @@ class ConvOp:
         # underflow side of the f16x2 range guard: only launches that hand planes to a following convolution are watched
         self.chain_sync = self.chain_tile0 = None
         if chain:
-            assert len(segs) >= 2 and not (cfg == hip.TILE_256x256_W8 and sk > 1)
+            assert len(segs) >= 2 and not (cfg in (hip.TILE_256x256_W8, hip.TILE_192x256_W8) and sk > 1)
             self.chain_sync = torch.zeros(1 + len(tiles), dtype=torch.int32, device=dev)  # zero between launches (the last tile clears it)
             self.chain_tile0 = torch.tensor(self.seg_tile0, dtype=torch.int32).to(dev)
             L.chain, L.chain_sync, L.chain_tile0 = 1, self.chain_sync.data_ptr(), self.chain_tile0.data_ptr()

@@ -505,7 +505,7 @@ class PlanBase:
             m = c["meta"]
             if (m["KH"], m["KW"], c["stride"], c["pad"]) != (3, 3, 1, 1) or not op.in_planes or c["in_relu"] or c["math"] == hip.MATH_F32:
                 return False
-            if c["tile"] == hip.TILE_256x256_W8 and c["splitk"] > 1:
+            if c["tile"] in (hip.TILE_256x256_W8, hip.TILE_192x256_W8) and c["splitk"] > 1:
                 return False
             if c["splitk"] > 1 and -(-(m["Kpad"] // 32) // c["splitk"]) % 3:
                 return False  # (K slices that do not start on a filter row run on the per-tap kernel, which has no chain form)

@@ -22,8 +22,9 @@ MATH_TILES = {  # tile configurations instantiated per arithmetic mode
 }
 # the split-plane kernel (csrc/conv_planes.hip): one barrier per K-tile for every tile, so no "two K-tiles per barrier" variants
 PLANE_TILES = (hip.TILE_256x128, hip.TILE_128x128, hip.TILE_128x64, hip.TILE_64x128, hip.TILE_128x128_W4, hip.TILE_64x64_W4, hip.TILE_128x64_W4,
-               hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8, hip.TILE_128x32_W4)
-BIG_WAVE_TILES = (hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8)  # 8 accumulator blocks per wave; picked by the measured table only
+               hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8, hip.TILE_128x32_W4, hip.TILE_192x256_W8)
+ROW_ONLY_TILES = (hip.TILE_192x256_W8,)  # instantiated for the row-shared 3 x 3 kernel only
+BIG_WAVE_TILES = (hip.TILE_256x128_T42, hip.TILE_128x256_T24, hip.TILE_256x256_W8, hip.TILE_192x256_W8)  # 8 accumulator blocks per wave; picked by the measured table only
 PLANE_TILE_ALIAS = {hip.TILE_128x64_K2: hip.TILE_128x64, hip.TILE_64x128_K2: hip.TILE_64x128, hip.TILE_64x64_W4K2: hip.TILE_64x64_W4}
 for _m in (hip.MATH_BF16X2, hip.MATH_BF16, hip.MATH_F16X2):
     MATH_TILES[_m] = PLANE_TILES
@@ -50,7 +51,7 @@ def default_math():
 TILE_WAVE_GRID = {hip.TILE_256x128: (2, 2, 4, 2), hip.TILE_128x128: (2, 1, 2, 4), hip.TILE_128x64: (1, 1, 4, 2), hip.TILE_64x128: (1, 1, 2, 4),
                   hip.TILE_128x128_W4: (2, 2, 2, 2), hip.TILE_64x64_W4: (1, 1, 2, 2), hip.TILE_128x64_W4: (2, 1, 2, 2),
                   hip.TILE_256x128_T42: (4, 2, 2, 2), hip.TILE_128x256_T24: (2, 4, 2, 2), hip.TILE_256x256_W8: (4, 2, 2, 4),
-                  hip.TILE_128x32_W4: (1, 1, 4, 1)}
+                  hip.TILE_128x32_W4: (1, 1, 4, 1), hip.TILE_192x256_W8: (3, 2, 2, 4)}
 
 
 def kernel_signature(op):

@@ -23,15 +23,17 @@ CAND_FIELDS = 22
 DET_FIELDS = 32
 
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x32, TILE_64x128, TILE_256x128, TILE_128x128_W4, TILE_64x64_W4, TILE_128x64_W4, \
-    TILE_128x64_K2, TILE_64x128_K2, TILE_64x64_W4K2, TILE_256x128_T42, TILE_128x256_T24, TILE_256x256_W8, TILE_128x32_W4 = range(16)
+    TILE_128x64_K2, TILE_64x128_K2, TILE_64x64_W4K2, TILE_256x128_T42, TILE_128x256_T24, TILE_256x256_W8, TILE_128x32_W4, \
+    TILE_192x256_W8 = range(17)
 TILE_SHAPES = {TILE_128x128: (128, 128), TILE_128x64: (128, 64), TILE_64x64: (64, 64), TILE_128x32: (128, 32),
                TILE_64x128: (64, 128), TILE_256x128: (256, 128), TILE_128x128_W4: (128, 128), TILE_64x64_W4: (64, 64),
                TILE_128x64_W4: (128, 64), TILE_128x64_K2: (128, 64), TILE_64x128_K2: (64, 128), TILE_64x64_W4K2: (64, 64),
-               TILE_256x128_T42: (256, 128), TILE_128x256_T24: (128, 256), TILE_256x256_W8: (256, 256), TILE_128x32_W4: (128, 32)}
+               TILE_256x128_T42: (256, 128), TILE_128x256_T24: (128, 256), TILE_256x256_W8: (256, 256), TILE_128x32_W4: (128, 32),
+               TILE_192x256_W8: (192, 256)}
 TILE_NAMES = {TILE_128x128: "128x128", TILE_128x64: "128x64", TILE_64x64: "64x64", TILE_128x32: "128x32", TILE_64x128: "64x128",
               TILE_256x128: "256x128", TILE_128x128_W4: "128x128w4", TILE_64x64_W4: "64x64w4", TILE_128x64_W4: "128x64w4", TILE_128x64_K2: "128x64k2",
               TILE_64x128_K2: "64x128k2", TILE_64x64_W4K2: "64x64w4k2", TILE_256x128_T42: "256x128t42", TILE_128x256_T24: "128x256t24",
-              TILE_256x256_W8: "256x256w8", TILE_128x32_W4: "128x32w4"}
+              TILE_256x256_W8: "256x256w8", TILE_128x32_W4: "128x32w4", TILE_192x256_W8: "192x256w8"}
 
 # numpy mirror of `dd3d_conv_seg` (120 bytes) -- arrays of it are uploaded to the device as raw bytes.
 CONV_SEG_DTYPE = np.dtype(

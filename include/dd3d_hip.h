@@ -203,7 +203,9 @@ int dd3d_math_planes(int32_t math_mode);
 #define DD3D_TILE_128x256_T24 13 /* 4 waves (2 x 2), wave tile 64 x 128 */
 #define DD3D_TILE_256x256_W8 14  /* 8 waves (2 x 4), wave tile 128 x 64; one- and two-term modes only */
 #define DD3D_TILE_128x32_W4 15   /* split-plane kernels: 4 waves (4 x 1), 32 output columns -- the narrow predictors (N <= 32: fcos2d.py:96-110) */
-#define DD3D_TILE_COUNT 16
+#define DD3D_TILE_192x256_W8 16  /* row-shared 3 x 3 kernel only: 8 waves (2 x 4), wave tile 96 x 64 -- launches whose 256-row tiles fill only part of the chip
+                                  * (the merged FPN output convolutions: 210 blocks instead of 158 on 256 CUs); no residual, no split-K, like DD3D_TILE_256x256_W8 */
+#define DD3D_TILE_COUNT 17
 /* rows (M) and columns (N) of a block tile for a DD3D_TILE_* id; returns 0 on success */
 int dd3d_conv_tile_shape(int32_t tile_cfg, int32_t* bm, int32_t* bn);
 /* B / A ring depths (NSB, NSA) of the row-shared split-plane kernel instantiation that `tile_cfg` launches in `math_mode` -- the 5th and

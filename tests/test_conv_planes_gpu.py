@@ -56,6 +56,8 @@ ROW_CASES = [  # 3x3 / stride 1: the row-shared kernel (csrc/conv_planes_row.hip
     ("row_t24_b3", 3, 7, 9, 256, 256, 3, 1, 1, True, False, hip.TILE_128x256_T24, 1),
     ("row_t24_n320", 1, 24, 40, 64, 320, 3, 1, 1, False, True, hip.TILE_128x256_T24, 1),       # two N tiles, the second half empty
     ("row_w8_256x256", 2, 17, 23, 128, 256, 3, 1, 1, True, False, hip.TILE_256x256_W8, 1),  # (this tile carries no residual: registers)
+    ("row_w8_192x256", 2, 17, 23, 128, 256, 3, 1, 1, True, False, hip.TILE_192x256_W8, 1),  # (round 6: three accumulator row blocks per wave; row kernel only)
+    ("row_w8_192x256_n320", 1, 40, 44, 64, 320, 3, 1, 1, False, False, hip.TILE_192x256_W8, 1),  # ten m-tiles, two N tiles (the second a quarter full)
     ("t42_1x1_k448", 1, 24, 40, 448, 128, 1, 1, 0, True, False, hip.TILE_256x128_T42, 1),
     ("t24_s2_sk2", 1, 13, 21, 256, 256, 3, 2, 1, False, False, hip.TILE_128x256_T24, 2),
     ("w8_1x1", 1, 24, 40, 256, 512, 1, 1, 0, False, False, hip.TILE_256x256_W8, 1),
@@ -72,8 +74,10 @@ def test_planes_conv_matches_torch(hiplib, case, mode, row_kernel, monkeypatch):
         pytest.skip("only 3x3 / stride 1 has two kernels")
     monkeypatch.setenv("DD3D_CONV_ROW", str(row_kernel))
     math, rtol = MODES[mode]
-    if tile == hip.TILE_256x256_W8 and hip.MATH_PLANES[math] > 2:
-        pytest.skip("the 8-wave 256 x 256 tile exists for the one- and two-term modes only (register file)")
+    if tile in (hip.TILE_256x256_W8, hip.TILE_192x256_W8) and hip.MATH_PLANES[math] > 2:
+        pytest.skip("the 8-wave 256-column tiles exist for the one- and two-term modes only (register file)")
+    if tile == hip.TILE_192x256_W8 and not row_kernel:
+        pytest.skip("instantiated for the row-shared kernel only")
     g = torch.Generator().manual_seed(sum(map(ord, name)) % 1000)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k)**0.5

@@ -178,7 +178,7 @@ def test_kernel_signature_restates_the_librarys_ring_depths(hiplib):
         for cfg in PLANE_TILES:
             nsb, nsa = C.c_int32(), C.c_int32()
             rc = hiplib.dd3d_conv_row_rings(cfg, math, C.byref(nsb), C.byref(nsa))
-            if cfg == hip.TILE_256x256_W8 and hip.MATH_PLANES[math] > 2:
+            if cfg in (hip.TILE_256x256_W8, hip.TILE_192x256_W8) and hip.MATH_PLANES[math] > 2:
                 assert rc != 0
                 continue
             assert rc == 0, (hip.TILE_NAMES[cfg], math)
@@ -772,7 +772,11 @@ def test_throughput_tile_policy_of_pipeline_slots(kitti_dla34, hiplib, monkeypat
     tiles = lambda p: {op.name: (op.info["tile_name"], op.info["splitk"]) for op in p.ops if isinstance(op, ConvOp)}
     tl, tt = tiles(lat), tiles(thr)
     changed = sorted(n for n in tl if tl[n] != tt[n])
-    assert len(changed) == 17 and all(n.startswith(("level3", "level4", "level5")) and ".conv" in n for n in changed)  # the stride-1 3 x 3 convolutions: 7 + 7 + 3
+    # the stride-1 3 x 3 convolutions: 7 + 7 + 3; and the merged FPN output launch: 192-row tiles (210 blocks) when it has the chip to itself,
+    # 256-row tiles (158 blocks, fewer filter bytes per MFMA) when other slots' launches fill the other CUs (profiles/r06q_fpn192.txt)
+    assert tl["fpn_outputs"] == ("192x256w8", 1) and tt["fpn_outputs"] == ("256x256w8", 1)
+    changed.remove("fpn_outputs")
+    assert len(changed) == 17 and all(n.startswith(("level3", "level4", "level5")) and ".conv" in n for n in changed)
     assert tt["level3.tree1.tree2.conv1"] == ("256x128", 1) and tt["level4.tree2.tree1.conv2"] == ("256x128", 2) and tt["level5.tree2.conv2"] == ("256x128", 4)
     assert tt["towers.0"] == tl["towers.0"] == ("256x256w8", 1) and lat.conv_macs == thr.conv_macs and sorted(lat.bufs) == sorted(thr.bufs)
     runner = PipelinedForward(model, 1, 384, 1280, depth=2, microbatch=4, runtime=HostOrderRuntime())
