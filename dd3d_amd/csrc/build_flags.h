@@ -121,4 +121,9 @@
 #else
 #define DD3D_BF_21 ""
 #endif
-#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13 DD3D_BF_14 DD3D_BF_15 DD3D_BF_16 DD3D_BF_17 DD3D_BF_18 DD3D_BF_19 DD3D_BF_20 DD3D_BF_21
+#ifdef DD3D_ROW_PRIO_SLICE
+#define DD3D_BF_22 " DD3D_ROW_PRIO_SLICE=" DD3D_BF_STR(DD3D_ROW_PRIO_SLICE)
+#else
+#define DD3D_BF_22 ""
+#endif
+#define DD3D_BUILD_FLAGS DD3D_BF_0 DD3D_BF_1 DD3D_BF_2 DD3D_BF_3 DD3D_BF_4 DD3D_BF_5 DD3D_BF_6 DD3D_BF_7 DD3D_BF_8 DD3D_BF_9 DD3D_BF_10 DD3D_BF_11 DD3D_BF_12 DD3D_BF_13 DD3D_BF_14 DD3D_BF_15 DD3D_BF_16 DD3D_BF_17 DD3D_BF_18 DD3D_BF_19 DD3D_BF_20 DD3D_BF_21 DD3D_BF_22

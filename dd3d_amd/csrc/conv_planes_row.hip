@@ -46,6 +46,10 @@ DD3D_NOTE_BUILD_FLAGS
 #ifndef DD3D_ROW_B_WAVES
 #define DD3D_ROW_B_WAVES 0  // > 0: in the 8-wave tiles only the first DD3D_ROW_B_WAVES waves (one per SIMD: the ones the MFMA arbiter favours) issue the filter stages' LDS-DMA (measured neutral: r06o)
 #endif
+#ifndef DD3D_ROW_PRIO_SLICE
+#define DD3D_ROW_PRIO_SLICE 0  // 8-wave tiles: 1: waves 4-7 run at priority 2 in the first half of a barrier interval and 0 in the second (waves 0-3 stay at 1): the
+                               // second-served wave of a SIMD goes FIRST for half its MFMAs, so that nobody runs the end of the interval alone; 2: the roles swapped
+#endif
 #ifndef DD3D_ROW_B_WAVES_HI
 #define DD3D_ROW_B_WAVES_HI 0  // 1: the LAST DD3D_ROW_B_WAVES waves issue the filter pieces (the ones the arbiter serves second: they issue while the first run their MFMAs)
 #endif
@@ -116,6 +120,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN;
   const int wn = wave - wm * WN;
+#if DD3D_ROW_PRIO_SLICE
+  const bool prio_wave = NW == 8 && (DD3D_ROW_PRIO_SLICE == 1 ? wave >= 4 : wave < 4);  // the waves that alternate between priority 2 and 0
+  if (NW == 8 && !prio_wave) __builtin_amdgcn_s_setprio(1);
+#endif
   const bool bwave = BW == NW || (DD3D_ROW_B_WAVES_HI ? wave >= NW - BW : wave < BW);  // (wave-uniform) this wave issues filter pieces
 #if DD3D_ROW_STAMP
   unsigned long long st_t[8] = {stamp_now(), 0, 0, 0, 0, 0, 0, 0};
@@ -446,6 +454,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
     // A group is an HBM / MALL round trip, and the short steps of the small tiles (a few hundred cycles) do not cover one with NSA = 2.
     auto step = [&](int sa, int dh, auto dw_c) {
       constexpr int dw = decltype(dw_c)::value;
+#if DD3D_ROW_PRIO_SLICE
+      if constexpr (NW == 8) {  // second half of the barrier interval
+        if (prio_wave) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       const int tap = dh * 3 + dw;
       // ---- phase A: chunk-1 fragments under the chunk-0 MFMAs; addresses of the next A group (used after the barrier when dw == 2)
       read_frags(sa, sb, dw, tap, C1);
@@ -483,6 +497,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_planes_row_kernel(con
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
+#if DD3D_ROW_PRIO_SLICE
+      if constexpr (NW == 8) {  // first half of the barrier interval
+        if (prio_wave) __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       // ---- phase B: refill the freed stages; chunk-0 fragments of the next K-tile under the chunk-1 MFMAs
 #if DD3D_ROW_STAMP > 1  // (2: slot [6] = the filter pieces' issue instead of the vmcnt wait)
       const unsigned long long st_d = stamp_now();
