@@ -51,19 +51,21 @@ def test_v99_kitti_bs16_full_size_matches_oracle(hiplib):
 
 
 @pytest.mark.timeout(900)
-def test_dla34_kitti_four_image_plan_matches_oracle(hiplib):
+@pytest.mark.parametrize("policy", ["throughput", "latency"])
+def test_dla34_kitti_four_image_plan_matches_oracle(hiplib, policy):
     """The launch plan bench.py's `value` is measured on (round-5 verdict): DD3D-DLA34 384x1280 with FOUR images per launch -- the
     4-image entries of the shipped tile table (the 8-wave 256 x 256 tower tile, the split-K choices of the backbone) -- on four DIFFERENT
     images (one of raw KITTI size inside the padded batch), captured as a hipGraph like a pipeline slot's: backbone features and every head
     map vs the oracle, candidate flips only ON a selection cut, then -- on identical head maps -- integer exactness and <= 1e-3 relative
     floats of the final detections; and end to end through `PipelinedForward(microbatch=4)` (four single-image requests sharing one plan),
-    whose results must equal the one-plan forward's bit for bit."""
+    whose results must equal the one-plan forward's bit for bit.  `policy` "latency": the same four images on the tiles of a plan that runs by
+    itself (`model(batched_inputs)`: per-launch table, the 192-row tile of the merged FPN output launch) against the same oracle."""
     from dd3d_amd.parallel import PipelinedForward
     from dd3d_amd.synthetic import make_inputs
     from tests.parity import parity_report
     cfg, sd = bundle("dd3d_kitti_dla34", "dla34_kitti")
     model = gpu_model(cfg, sd, use_graph=True)
-    model.tile_policy = "throughput"  # what a pipeline slot of several requests builds its plan with (engine.tiling.THROUGHPUT_TILE_TABLE): the TIMED plan's tiles
+    model.tile_policy = policy  # "throughput": what a pipeline slot of several requests builds its plan with (engine.tiling.THROUGHPUT_TILE_TABLE): the TIMED plan's tiles
     B = 4
     inputs = [make_inputs(1, 384, 1280, seed=1000 + j)[0] for j in range(B)]  # (the bench's request images)
     inputs[2]["image"] = inputs[2]["image"][:, :370, :1224].contiguous()
@@ -74,7 +76,11 @@ def test_dla34_kitti_four_image_plan_matches_oracle(hiplib):
     towers = [op for op in plan.ops if op.name.startswith("towers.")]
     assert towers and all(op.info["tile_name"] == "256x256w8" for op in towers), [op.info["tile_name"] for op in towers]
     by_name = {op.name: op for op in plan.ops}
-    assert plan.tile_policy == "throughput" and by_name["level3.tree2.tree1.conv2"].info["tile_name"] == "256x128" and by_name["level5.tree2.conv1"].info["splitk"] == 4
+    if policy == "throughput":
+        assert plan.tile_policy == "throughput" and by_name["level3.tree2.tree1.conv2"].info["tile_name"] == "256x128" and by_name["level5.tree2.conv1"].info["splitk"] == 4
+        assert by_name["fpn_outputs"].info["tile_name"] == "256x256w8"
+    else:
+        assert plan.tile_policy == "latency" and by_name["level3.tree2.tree1.conv2"].info["tile_name"] != "256x128" and by_name["fpn_outputs"].info["tile_name"] == "192x256w8"
     plan.run()
     torch.cuda.synchronize()
     plan.check_status()
@@ -89,6 +95,14 @@ def test_dla34_kitti_four_image_plan_matches_oracle(hiplib):
         assert rep["off_cut_flips"] == 0 and rep["pass"], (i, rep)
         flips += rep["on_cut_flips"]
     print(f"[margin] DLA-34 four-image plan: {sum(len(c['scores']) for c in st['candidates'])} oracle candidates, {flips} on-the-cut flips")
+    if policy == "latency":  # (pipeline slots are built with the throughput tiles: other split-K choices, not the same bits)
+        oracle_heads_to_plan(plan, st, C)
+        plan.launch(first=plan.num_pre_nms_ops - 1)
+        torch.cuda.synchronize()
+        out = model.collect(plan, inputs, image_sizes)
+        for i in range(B):
+            _check_final(out[i], ref[i])
+        return
     # four single-image requests through one pipeline slot: the same plan geometry, the same detections
     runner = PipelinedForward(model, 1, 384, 1280, depth=2, compute_streams=2, microbatch=4)
     assert runner.plan.tile_policy == "throughput" and [getattr(op, "info", {}).get("tile_name") for op in runner.plan.ops] == [getattr(op, "info", {}).get("tile_name") for op in plan.ops]
